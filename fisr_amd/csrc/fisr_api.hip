@@ -1,0 +1,720 @@
+// C-ABI of libfisr_hip.so (see include/fisr.h): context, weight re-packing, the FISRnet
+// forward as a schedule of hand-written gfx950 kernels, glue kernels, op-level entries.
+//
+// Forward schedule follows FISRnet.model (reference FISRnet.py:73-173) over the blocks of
+// ops.py:39-76; every launch below names the reference line it implements.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fisr.h"
+#include "conv3x3.h"
+#include "glue_kernels.h"
+
+using namespace fisr;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct ConvW {
+  int ci = 0, co = 0;
+  std::vector<float> w, b;  // host copies in TF layout (HWIO, [Co])
+  bool have_w = false, have_b = false;
+  // device, packed
+  void* d_w = nullptr;
+  float* d_b = nullptr;
+  int cin_pad = 0, cout_pad = 0, nt = 2;
+};
+
+struct ProfEntry {
+  hipEvent_t a, b;
+  int cls;
+  double flops, bytes;
+};
+
+}  // namespace
+
+struct fisr_ctx {
+  int dev = 0;
+  int precision = -1;
+  bool finalized = false;
+  std::map<std::string, ConvW> convs;  // keyed by conv name (without /w, /b)
+  std::string err;
+  // profiling
+  bool prof = false;
+  std::vector<std::string> prof_names;
+  std::vector<ProfEntry> prof_entries;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<double> prof_ms, prof_flops, prof_bytes;
+  std::vector<int64_t> prof_launches;
+  double* d_scalar = nullptr;
+};
+
+namespace {
+
+int fail(fisr_ctx* ctx, int code, const std::string& msg) {
+  g_err = msg;
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIP_OK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, FISR_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int ilog2(int v) { int k = 0; while ((1 << (k + 1)) <= v) ++k; return k; }
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int grid_for(size_t work, int block = 256) {
+  size_t g = (work + block - 1) / block;
+  return (int)std::min<size_t>(std::max<size_t>(g, 1), 256 * 16);
+}
+
+// The 138 conv names with their channel counts (reference ops.py:48-76, FISRnet.py:83-106;
+// same order as fisr_amd/weights.py conv_specs()).
+struct Spec { std::string name; int ci, co; };
+std::vector<Spec> all_specs() {
+  std::vector<Spec> out;
+  for (int lv = 1; lv <= 3; ++lv) {
+    const std::string P = "FISRnet/level_" + std::to_string(lv);
+    const int cin = lv == 1 ? 29 : 38;
+    auto rb = [&](const std::string& p, int c, int i) {
+      out.push_back({p + "/res_block/" + std::to_string(i) + "/conv/0", c, c});
+      out.push_back({p + "/res_block/" + std::to_string(i) + "/conv/1", c, c});
+    };
+    const int ec[3][2] = {{cin, 64}, {64, 128}, {128, 256}};
+    for (int l = 0; l < 3; ++l) {
+      const std::string p = P + "/enc/level_" + std::to_string(l);
+      out.push_back({p + "/conv/0", ec[l][0], ec[l][1]});
+      rb(p, ec[l][1], 0);
+      rb(p, ec[l][1], 1);
+    }
+    out.push_back({P + "/bottleneck/conv/0", 256, 512});
+    rb(P + "/bottleneck", 512, 0);
+    const int dc[3][3] = {{2, 512, 256}, {1, 256, 128}, {0, 128, 64}};
+    for (auto& d : dc) {
+      const std::string p = P + "/dec/level_" + std::to_string(d[0]);
+      out.push_back({p + "/resize", d[1], d[2]});
+      out.push_back({p + "/conv/0", d[2] * 2, d[2]});
+      rb(p, d[2], 0);
+      rb(p, d[2], 1);
+    }
+    const char* heads[2] = {"FI-SR", "SR"};
+    const int hco[2] = {6, 3};
+    for (int h = 0; h < 2; ++h) {
+      const std::string p = P + "/" + heads[h];
+      out.push_back({p + "/conv/0", 64, 64});
+      rb(p, 64, 0);
+      out.push_back({p + "/conv/1", 64, 256});
+      out.push_back({p + "/conv/2", 64, hco[h]});
+    }
+  }
+  return out;
+}
+
+template <typename T> constexpr int chunk_ch() { return Prec<T>::CC; }
+
+// Re-pack HWIO weights to [Cin/CC][9][CoutPad][CC] (channel innermost, 64-byte records) so
+// that a workgroup's weight slab for one K chunk is 9 contiguous runs it copies straight to LDS.
+template <typename T>
+void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, int cout_pad,
+                  std::vector<T>& wp, std::vector<float>& bp) {
+  constexpr int CC = Prec<T>::CC;
+  wp.assign((size_t)cin_pad * 9 * cout_pad, (T)0);
+  bp.assign(cout_pad, 0.f);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < ci; ++c)
+      for (int n = 0; n < co; ++n) {
+        const int kc = c / CC, cc = c % CC;
+        wp[(((size_t)kc * 9 + tap) * cout_pad + n) * CC + cc] = (T)w[((size_t)tap * ci + c) * co + n];
+      }
+  for (int n = 0; n < co; ++n) bp[n] = b[n];
+}
+
+inline int nt_for(int co) { return co <= 32 ? 1 : 2; }
+
+template <typename T>
+int upload_conv(fisr_ctx* ctx, ConvW& cw) {
+  constexpr int CC = Prec<T>::CC;
+  cw.nt = nt_for(cw.co);
+  cw.cin_pad = round_up(cw.ci, CC);
+  cw.cout_pad = round_up(cw.co, 32 * cw.nt);
+  std::vector<T> wp;
+  std::vector<float> bp;
+  pack_weights<T>(cw.w.data(), cw.b.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad, wp, bp);
+  if (cw.d_w) { (void)hipFree(cw.d_w); cw.d_w = nullptr; }
+  if (cw.d_b) { (void)hipFree(cw.d_b); cw.d_b = nullptr; }
+  HIP_OK(ctx, hipMalloc(&cw.d_w, wp.size() * sizeof(T)));
+  HIP_OK(ctx, hipMalloc((void**)&cw.d_b, bp.size() * sizeof(float)));
+  HIP_OK(ctx, hipMemcpy(cw.d_w, wp.data(), wp.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIP_OK(ctx, hipMemcpy(cw.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ---- kernel launch helpers ----
+
+template <typename T, int NT, bool OUT_F32>
+hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  constexpr size_t lds = conv_lds_bytes<T, NT>();
+  auto kern = conv3x3_mfma_kernel<T, NT, OUT_F32>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
+  dim3 grid(tiles, a.CoutPad / (32 * NT));
+  hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, st, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_conv(const ConvArgs& a, int nt, bool out_f32, hipStream_t st) {
+  if (nt == 1) return out_f32 ? launch_conv_variant<T, 1, true>(a, st) : launch_conv_variant<T, 1, false>(a, st);
+  return out_f32 ? launch_conv_variant<T, 2, true>(a, st) : launch_conv_variant<T, 2, false>(a, st);
+}
+
+int prof_class(fisr_ctx* ctx, const std::string& name) {
+  for (size_t i = 0; i < ctx->prof_names.size(); ++i)
+    if (ctx->prof_names[i] == name) return (int)i;
+  ctx->prof_names.push_back(name);
+  ctx->prof_ms.push_back(0);
+  ctx->prof_flops.push_back(0);
+  ctx->prof_bytes.push_back(0);
+  ctx->prof_launches.push_back(0);
+  return (int)ctx->prof_names.size() - 1;
+}
+
+hipEvent_t prof_event(fisr_ctx* ctx) {
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    ctx->ev_pool.push_back(e);
+  }
+  return ctx->ev_pool[ctx->ev_used++];
+}
+
+struct ProfScope {
+  fisr_ctx* ctx;
+  hipStream_t st;
+  bool on;
+  ProfEntry pe;
+  ProfScope(fisr_ctx* c, hipStream_t s, const std::string& cls, double flops, double bytes)
+      : ctx(c), st(s), on(c && c->prof) {
+    if (!on) return;
+    pe.cls = prof_class(ctx, cls);
+    pe.flops = flops;
+    pe.bytes = bytes;
+    pe.a = prof_event(ctx);
+    pe.b = prof_event(ctx);
+    (void)hipEventRecord(pe.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(pe.b, st);
+    ctx->prof_entries.push_back(pe);
+  }
+};
+
+int prof_flush(fisr_ctx* ctx) {
+  for (auto& pe : ctx->prof_entries) {
+    (void)hipEventSynchronize(pe.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, pe.a, pe.b);
+    ctx->prof_ms[pe.cls] += ms;
+    ctx->prof_flops[pe.cls] += pe.flops;
+    ctx->prof_bytes[pe.cls] += pe.bytes;
+    ctx->prof_launches[pe.cls] += 1;
+  }
+  ctx->prof_entries.clear();
+  ctx->ev_used = 0;
+  return 0;
+}
+
+ColorConsts make_color_consts() {
+  // utils.py:106-110 / warp script :35-40 (YUV2RGB) and :48-52 (RGB2YUV)
+  const double tinv[3][3] = {{0.00456621, 0., 0.00625893},
+                             {0.00456621, -0.00153632, -0.00318811},
+                             {0.00456621, 0.00791071, 0.}};
+  const double tf[3][3] = {{65.481, 128.553, 24.966}, {-37.797, -74.203, 112}, {112, -93.786, -18.214}};
+  ColorConsts cc;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      cc.t[i][j] = 255 * tinv[i][j];
+      cc.f[i][j] = tf[i][j] / 255;
+    }
+    // offset = (255*Tinv) @ [16,128,128]^T
+    volatile double s = cc.t[i][0] * 16.0;
+    s = s + cc.t[i][1] * 128.0;
+    s = s + cc.t[i][2] * 128.0;
+    cc.off[i] = s;
+  }
+  return cc;
+}
+
+// ---- the forward schedule ----
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;
+  void* alloc(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    peak = std::max(peak, off);
+    return dry ? nullptr : base + a;
+  }
+};
+
+template <typename T>
+struct Runner {
+  fisr_ctx* ctx;
+  hipStream_t st;
+  Arena ar;
+  int rc = 0;
+
+  T* talloc(size_t elems) { return (T*)ar.alloc(elems * sizeof(T)); }
+
+  void check(hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == 0) rc = fail(ctx, FISR_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  }
+
+  // ops.py:7-11 (+ fused neighbours, see conv3x3.h)
+  void conv(const std::string& name, const T* in0, int c0, const T* in1, int c1, const T* res, void* out,
+            int n, int h, int w, int flags, bool out_f32 = false, int cstride = 0, int coff = 0,
+            int split = 1 << 30, int gap = 0) {
+    if (rc) return;
+    auto it = ctx->convs.find(name);
+    if (it == ctx->convs.end()) { rc = fail(ctx, FISR_EMISSING, "unknown conv " + name); return; }
+    const ConvW& cw = it->second;
+    if (c0 + c1 != cw.cin_pad) {
+      rc = fail(ctx, FISR_EINVAL, name + ": channel mismatch " + std::to_string(c0 + c1) + " vs " + std::to_string(cw.cin_pad));
+      return;
+    }
+    if (ar.dry) return;
+    ConvArgs a;
+    a.in0 = in0; a.in1 = in1; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
+    a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cw.co; a.CoutPad = cw.cout_pad;
+    a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
+    a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
+    a.d2s = (flags & FISR_CONV_D2S) != 0;
+    a.d2s_shift = a.d2s ? ilog2(cw.co / 4) : 0;
+    a.out_cstride = cstride ? cstride : cw.co;
+    a.out_coff = coff; a.out_split = split; a.out_gap = gap;
+    const double px = (double)n * h * w;
+    char cls[96];
+    snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", sizeof(T) == 4 ? "f32" : "f16", cw.nt, out_f32 ? "_f32out" : "");
+    ProfScope ps(ctx, st, cls, 2.0 * 9 * cw.ci * cw.co * px,
+                 px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
+    check(launch_conv<T>(a, cw.nt, out_f32, st), name.c_str());
+  }
+
+  // ops.py:39-44 res_block, in place on X with scratch A.
+  void rb(const std::string& name, T* X, T* A, int c, int n, int h, int w, bool relu_out) {
+    conv(name + "/conv/0", X, c, nullptr, 0, nullptr, A, n, h, w, FISR_CONV_RELU_IN | FISR_CONV_RELU_OUT);
+    conv(name + "/conv/1", A, c, nullptr, 0, X, X, n, h, w, relu_out ? FISR_CONV_RELU_OUT : 0);
+  }
+
+  void pool(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:54
+    if (rc || ar.dry) return;
+    const size_t work = (size_t)n * (h / 2) * (w / 2) * c / (16 / sizeof(T));
+    ProfScope ps(ctx, st, "maxpool2", 0, (double)n * h * w * c * sizeof(T) * 1.25);
+    hipLaunchKernelGGL(maxpool2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
+    check(hipGetLastError(), "maxpool2");
+  }
+  void up(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:69
+    if (rc || ar.dry) return;
+    const size_t work = (size_t)n * h * w * 4 * c / (16 / sizeof(T));
+    ProfScope ps(ctx, st, "upsample2", 0, (double)n * h * w * c * sizeof(T) * 5.0);
+    hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
+    check(hipGetLastError(), "upsample2");
+  }
+  void prep(const float* img, const float* pred, T* out, int n, int H, int W, int s, int cpad) {
+    if (rc || ar.dry) return;
+    const size_t work = (size_t)n * (H / s) * (W / s) * cpad;
+    ProfScope ps(ctx, st, "prep_level_input", 0, (double)work * (4 + sizeof(T)));
+    hipLaunchKernelGGL(prep_level_input_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, img, pred, out, n, H, W, s, cpad);
+    check(hipGetLastError(), "prep_level_input");
+  }
+
+  // One U-Net + the two heads at working resolution rh x rw (FISRnet.py:83-108).
+  // xin: [n,rh,rw,cin_pad]; pred: float32 [n,2rh,2rw,9].
+  void level(int lv, const T* xin, int cin_pad, int n, int rh, int rw, float* pred) {
+    const std::string P = "FISRnet/level_" + std::to_string(lv);
+    const int ch[3] = {64, 128, 256};
+    const T* cur = xin;
+    int cc = cin_pad, h = rh, w = rw;
+    T* skip[3];
+    for (int l = 0; l < 3; ++l) {  // Enc_level_res ops.py:48-55
+      const std::string e = P + "/enc/level_" + std::to_string(l);
+      const size_t px = (size_t)n * h * w;
+      T* X = talloc(px * ch[l]);
+      T* A = talloc(px * ch[l]);
+      conv(e + "/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
+      rb(e + "/res_block/0", X, A, ch[l], n, h, w, false);
+      rb(e + "/res_block/1", X, A, ch[l], n, h, w, true);  // n = relu(res_block(...)); skip = n
+      skip[l] = X;
+      T* Pl = talloc(px / 4 * ch[l]);
+      pool(X, Pl, n, h, w, ch[l]);
+      cur = Pl; cc = ch[l]; h /= 2; w /= 2;
+    }
+    {  // Bottleneck_res ops.py:59-63
+      const size_t px = (size_t)n * h * w;
+      T* X = talloc(px * 512);
+      T* A = talloc(px * 512);
+      conv(P + "/bottleneck/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
+      rb(P + "/bottleneck/res_block/0", X, A, 512, n, h, w, true);
+      cur = X; cc = 512;
+    }
+    for (int l = 2; l >= 0; --l) {  // Dec_level_res ops.py:67-76
+      const std::string d = P + "/dec/level_" + std::to_string(l);
+      T* U = talloc((size_t)n * h * w * 4 * cc);
+      up(cur, U, n, h, w, cc);
+      h *= 2; w *= 2;
+      const size_t px = (size_t)n * h * w;
+      T* D = talloc(px * ch[l]);
+      conv(d + "/resize", U, cc, nullptr, 0, nullptr, D, n, h, w, FISR_CONV_RELU_OUT);
+      T* X = talloc(px * ch[l]);
+      T* A = talloc(px * ch[l]);
+      conv(d + "/conv/0", D, ch[l], skip[l], ch[l], nullptr, X, n, h, w, 0);  // concat([n, skip])
+      rb(d + "/res_block/0", X, A, ch[l], n, h, w, false);
+      rb(d + "/res_block/1", X, A, ch[l], n, h, w, true);
+      cur = X; cc = ch[l];
+    }
+    // heads FISRnet.py:95-108
+    const size_t px = (size_t)n * h * w;
+    T* Hx = talloc(px * 64);
+    T* A = talloc(px * 64);
+    T* S = talloc(px * 4 * 64);
+    for (int hd = 0; hd < 2; ++hd) {
+      const std::string p = P + (hd == 0 ? "/FI-SR" : "/SR");
+      conv(p + "/conv/0", cur, 64, nullptr, 0, nullptr, Hx, n, h, w, 0);
+      rb(p + "/res_block/0", Hx, A, 64, n, h, w, false);
+      conv(p + "/conv/1", Hx, 64, nullptr, 0, nullptr, S, n, h, w,
+           FISR_CONV_RELU_IN | FISR_CONV_RELU_OUT | FISR_CONV_D2S);
+      // pred = concat([fr1, SR, fr2]): FI-SR channels 0-2 -> 0-2, 3-5 -> 6-8; SR -> 3-5
+      if (hd == 0) conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 0, 3, 3);
+      else         conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 3);
+    }
+  }
+
+  // FISRnet.py:73-173
+  int forward(const float* in, int n, int h, int w, float* l3, float* l2, float* l1) {
+    constexpr int CC = Prec<T>::CC;
+    if (!l1) l1 = (float*)ar.alloc((size_t)n * (h / 2) * (w / 2) * 9 * sizeof(float));
+    if (!l2) l2 = (float*)ar.alloc((size_t)n * h * w * 9 * sizeof(float));
+    const size_t mark = ar.off;
+    const int c1 = round_up(29, CC), c23 = round_up(38, CC);
+    {
+      T* x = talloc((size_t)n * (h / 4) * (w / 4) * c1);
+      prep(in, nullptr, x, n, h, w, 4, c1);
+      level(1, x, c1, n, h / 4, w / 4, l1);
+    }
+    ar.off = mark;
+    {
+      T* x = talloc((size_t)n * (h / 2) * (w / 2) * c23);
+      prep(in, l1, x, n, h, w, 2, c23);
+      level(2, x, c23, n, h / 2, w / 2, l2);
+    }
+    ar.off = mark;
+    {
+      T* x = talloc((size_t)n * h * w * c23);
+      prep(in, l2, x, n, h, w, 1, c23);
+      level(3, x, c23, n, h, w, l3);
+    }
+    return rc;
+  }
+};
+
+template <typename T>
+size_t ws_bytes_t(fisr_ctx* ctx, int n, int h, int w) {
+  Runner<T> r;
+  r.ctx = ctx; r.st = nullptr; r.ar.dry = true;
+  r.forward(nullptr, n, h, w, (float*)1, nullptr, nullptr);
+  return r.ar.peak + 256;
+}
+
+}  // namespace
+
+// =============================== C ABI ===============================
+
+extern "C" {
+
+const char* fisr_version(void) { return "fisr_hip 0.1 (gfx950)"; }
+
+const char* fisr_last_error(const fisr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int fisr_create(fisr_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, FISR_EINVAL, "fisr_create: out is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, FISR_EHIP, std::string("fisr_create: no HIP device (") + hipGetErrorString(e) + ")");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, FISR_EINVAL, "fisr_create: bad device id");
+  HIP_OK(nullptr, hipSetDevice(device_id));
+  fisr_ctx* c = new fisr_ctx();
+  c->dev = device_id;
+  for (auto& s : all_specs()) {
+    ConvW cw;
+    cw.ci = s.ci; cw.co = s.co;
+    c->convs[s.name] = cw;
+  }
+  if (hipMalloc((void**)&c->d_scalar, 64) != hipSuccess) { delete c; return fail(nullptr, FISR_EHIP, "hipMalloc"); }
+  *out = c;
+  return 0;
+}
+
+void fisr_destroy(fisr_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->dev);
+  for (auto& kv : ctx->convs) {
+    if (kv.second.d_w) (void)hipFree(kv.second.d_w);
+    if (kv.second.d_b) (void)hipFree(kv.second.d_b);
+  }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
+  delete ctx;
+}
+
+int fisr_set_weight(fisr_ctx* ctx, const char* name, const float* host, const int64_t* shape, int rank) {
+  if (!ctx || !name || !host || !shape) return fail(ctx, FISR_EINVAL, "fisr_set_weight: null argument");
+  std::string s(name);
+  // TF names may carry a ":0" suffix
+  const size_t colon = s.rfind(':');
+  if (colon != std::string::npos) s = s.substr(0, colon);
+  if (s.size() < 3) return 1;
+  const std::string kind = s.substr(s.size() - 2);
+  const std::string base = s.substr(0, s.size() - 2);
+  auto it = ctx->convs.find(base);
+  if (it == ctx->convs.end() || (kind != "/w" && kind != "/b")) return 1;  // not ours (Adam slot, step, ...)
+  ConvW& cw = it->second;
+  if (kind == "/w") {
+    if (rank != 4 || shape[0] != 3 || shape[1] != 3 || shape[2] != cw.ci || shape[3] != cw.co)
+      return fail(ctx, FISR_EINVAL, s + ": expected shape [3,3," + std::to_string(cw.ci) + "," + std::to_string(cw.co) + "]");
+    cw.w.assign(host, host + (size_t)9 * cw.ci * cw.co);
+    cw.have_w = true;
+  } else {
+    if (rank != 1 || shape[0] != cw.co)
+      return fail(ctx, FISR_EINVAL, s + ": expected shape [" + std::to_string(cw.co) + "]");
+    cw.b.assign(host, host + cw.co);
+    cw.have_b = true;
+  }
+  ctx->finalized = false;
+  return 0;
+}
+
+int fisr_num_variables_set(const fisr_ctx* ctx) {
+  if (!ctx) return 0;
+  int k = 0;
+  for (auto& kv : ctx->convs) k += (int)kv.second.have_w + (int)kv.second.have_b;
+  return k;
+}
+
+int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
+  if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_finalize_weights: ctx is NULL");
+  if (precision != FISR_PREC_F32 && precision != FISR_PREC_F16)
+    return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
+  for (auto& s : all_specs()) {
+    const ConvW& cw = ctx->convs[s.name];
+    if (!cw.have_w) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/w");
+    if (!cw.have_b) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/b");
+  }
+  HIP_OK(ctx, hipSetDevice(ctx->dev));
+  for (auto& kv : ctx->convs) {
+    int rc = precision == FISR_PREC_F32 ? upload_conv<float>(ctx, kv.second) : upload_conv<_Float16>(ctx, kv.second);
+    if (rc) return rc;
+  }
+  ctx->precision = precision;
+  ctx->finalized = true;
+  return 0;
+}
+
+size_t fisr_workspace_bytes(const fisr_ctx* cctx, int n, int h, int w) {
+  fisr_ctx* ctx = const_cast<fisr_ctx*>(cctx);
+  if (!ctx || !ctx->finalized || n < 1 || h < 32 || w < 32 || h % 32 || w % 32) return 0;
+  return ctx->precision == FISR_PREC_F32 ? ws_bytes_t<float>(ctx, n, h, w) : ws_bytes_t<_Float16>(ctx, n, h, w);
+}
+
+int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out_l3, float* out_l2,
+                 float* out_l1, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_forward: ctx is NULL");
+  if (!ctx->finalized) return fail(ctx, FISR_ESTATE, "fisr_forward: weights not finalized");
+  if (!in || !out_l3 || !workspace) return fail(ctx, FISR_EINVAL, "fisr_forward: null tensor");
+  if (n < 1 || h < 32 || w < 32 || h % 32 || w % 32)
+    return fail(ctx, FISR_EINVAL, "fisr_forward: h and w must be positive multiples of 32 (FISRnet.py:820-824)");
+  const size_t need = fisr_workspace_bytes(ctx, n, h, w);
+  if (workspace_bytes < need)
+    return fail(ctx, FISR_ENOMEM, "fisr_forward: workspace " + std::to_string(workspace_bytes) + " < " + std::to_string(need));
+  HIP_OK(ctx, hipSetDevice(ctx->dev));
+  hipStream_t st = (hipStream_t)stream;
+  auto run = [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    Runner<T> r;
+    r.ctx = ctx; r.st = st;
+    r.ar.base = (char*)workspace; r.ar.cap = workspace_bytes;
+    return r.forward(in, n, h, w, out_l3, out_l2, out_l1);
+  };
+  return ctx->precision == FISR_PREC_F32 ? run(float()) : run(_Float16());
+}
+
+int fisr_profile_enable(fisr_ctx* ctx, int on) {
+  if (!ctx) return FISR_EINVAL;
+  ctx->prof = on != 0;
+  return 0;
+}
+int fisr_profile_reset(fisr_ctx* ctx) {
+  if (!ctx) return FISR_EINVAL;
+  prof_flush(ctx);
+  for (size_t i = 0; i < ctx->prof_names.size(); ++i) {
+    ctx->prof_ms[i] = 0; ctx->prof_flops[i] = 0; ctx->prof_bytes[i] = 0; ctx->prof_launches[i] = 0;
+  }
+  return 0;
+}
+int fisr_profile_read(fisr_ctx* ctx, int cap, const char** name, double* total_ms, int64_t* launches,
+                      double* flops, double* bytes) {
+  if (!ctx) return FISR_EINVAL;
+  prof_flush(ctx);
+  const int k = (int)ctx->prof_names.size();
+  for (int i = 0; i < k && i < cap; ++i) {
+    if (name) name[i] = ctx->prof_names[i].c_str();
+    if (total_ms) total_ms[i] = ctx->prof_ms[i];
+    if (launches) launches[i] = ctx->prof_launches[i];
+    if (flops) flops[i] = ctx->prof_flops[i];
+    if (bytes) bytes[i] = ctx->prof_bytes[i];
+  }
+  return k;
+}
+
+// ---- glue ----
+
+int fisr_warp(const float* src, const float* flow, float scale, int h, int w, int quantized, float* dst, void* stream) {
+  if (!src || !flow || !dst || h < 1 || w < 1) return fail(nullptr, FISR_EINVAL, "fisr_warp: bad argument");
+  static const ColorConsts cc = make_color_consts();
+  hipLaunchKernelGGL(warp_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, src, flow, scale,
+                     h, w, quantized, dst, cc);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+int fisr_pack_input(const uint8_t* const* fr, const float* const* fl, const float* const* wp, int h0, int w0,
+                    int h, int w, float* out, void* stream) {
+  if (!fr || !fl || !wp || !out || h > h0 || w > w0 || h < 1 || w < 1)
+    return fail(nullptr, FISR_EINVAL, "fisr_pack_input: bad argument");
+  PackPtrs pp;
+  for (int i = 0; i < 3; ++i) pp.fr[i] = fr[i];
+  for (int i = 0; i < 4; ++i) { pp.fl[i] = fl[i]; pp.wp[i] = wp[i]; }
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, pp, h0, w0, h, w, out);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+int fisr_unpack_output(const float* pred, int h, int w, uint8_t* yuv_u8, uint8_t* rgb_u8, void* stream) {
+  if (!pred || h < 1 || w < 1) return fail(nullptr, FISR_EINVAL, "fisr_unpack_output: bad argument");
+  static const ColorConsts cc = make_color_consts();
+  hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, pred, h, w,
+                     yuv_u8, rgb_u8, cc);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+int fisr_stitch(const float* tile, int th, int tw, int sy, int sx, int ch, int cw, float* full, int fh, int fw,
+                int dy, int dx, void* stream) {
+  if (!tile || !full || sy < 0 || sx < 0 || sy + ch > th || sx + cw > tw || dy < 0 || dx < 0 || dy + ch > fh || dx + cw > fw)
+    return fail(nullptr, FISR_EINVAL, "fisr_stitch: region out of range");
+  hipLaunchKernelGGL(stitch_kernel, dim3(grid_for((size_t)ch * cw * 9)), dim3(256), 0, (hipStream_t)stream, tile, tw, sy,
+                     sx, ch, cw, full, fw, dy, dx);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+int fisr_sse_vs_u8(const float* pred, const uint8_t* gt, size_t count, double* out_host, void* stream) {
+  if (!pred || !gt || !out_host) return fail(nullptr, FISR_EINVAL, "fisr_sse_vs_u8: null argument");
+  double* d = nullptr;
+  HIP_OK(nullptr, hipMalloc((void**)&d, sizeof(double)));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_OK(nullptr, hipMemsetAsync(d, 0, sizeof(double), st));
+  hipLaunchKernelGGL(sse_u8_kernel, dim3(grid_for(count)), dim3(256), 0, st, pred, gt, count, d);
+  HIP_OK(nullptr, hipGetLastError());
+  HIP_OK(nullptr, hipMemcpyAsync(out_host, d, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_OK(nullptr, hipStreamSynchronize(st));
+  (void)hipFree(d);
+  return 0;
+}
+
+// ---- op-level entries ----
+
+int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
+                    int cout, const void* res, void* out, int n, int h, int w, int flags, int precision,
+                    int out_f32, void* stream) {
+  if (!in0 || !w_host || !b_host || !out || n < 1 || h < 1 || w < 1 || cout < 1)
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: bad argument");
+  const int cc = precision == FISR_PREC_F32 ? Prec<float>::CC : Prec<_Float16>::CC;
+  if (c0 % cc || c1 % cc || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
+  if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4)))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two");
+  ConvW cw;
+  cw.ci = c0 + c1; cw.co = cout;
+  cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
+  cw.b.assign(b_host, b_host + cout);
+  int rc = precision == FISR_PREC_F32 ? upload_conv<float>(nullptr, cw) : upload_conv<_Float16>(nullptr, cw);
+  if (rc) return rc;
+  ConvArgs a;
+  a.in0 = in0; a.in1 = in1; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
+  a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
+  a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
+  a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
+  a.d2s = (flags & FISR_CONV_D2S) != 0;
+  a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
+  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = precision == FISR_PREC_F32 ? launch_conv<float>(a, cw.nt, out_f32 != 0, st)
+                                            : launch_conv<_Float16>(a, cw.nt, out_f32 != 0, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(cw.d_w);
+  (void)hipFree(cw.d_b);
+  if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv sync: ") + hipGetErrorString(e2));
+  return 0;
+}
+
+int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {
+  if (!in || !out || h % 2 || w % 2) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: bad argument");
+  const int epu = precision == FISR_PREC_F32 ? 4 : 8;
+  if (c % epu) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: c must be a multiple of 16 bytes");
+  const size_t work = (size_t)n * (h / 2) * (w / 2) * c / epu;
+  if (precision == FISR_PREC_F32)
+    hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, n, h, w, c);
+  else
+    hipLaunchKernelGGL(maxpool2_kernel<_Float16>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, n, h, w, c);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {
+  if (!in || !out) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: bad argument");
+  const int epu = precision == FISR_PREC_F32 ? 4 : 8;
+  if (c % epu) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of 16 bytes");
+  const size_t work = (size_t)n * h * w * 4 * c / epu;
+  if (precision == FISR_PREC_F32)
+    hipLaunchKernelGGL(upsample2_kernel<float>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, n, h, w, c);
+  else
+    hipLaunchKernelGGL(upsample2_kernel<_Float16>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, n, h, w, c);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

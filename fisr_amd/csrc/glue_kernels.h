@@ -1,0 +1,285 @@
+// HBM-bound glue kernels around the conv hot path (NHWC everywhere).
+// Each kernel cites the reference call site it replaces (paths relative to the
+// reference root).  All of them stream 16-byte vectors per lane where the layout
+// allows it and are launched with >= 2048 workgroups' worth of grid-stride work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv3x3.h"
+
+namespace fisr {
+
+// ---- level input: strided sub-sample + concat with the previous prediction + channel pad ----
+// FISRnet.py:81,112 (legacy BICUBIC resize at integer factor == x[:, ::s, ::s, :])
+// FISRnet.py:113,144 (tf.concat((img_lk, pred_l{k-1}), axis=3)).  Output has cpad >= 29(+9)
+// channels (zero filled) so that the first conv sees whole 64-byte channel chunks.
+template <typename T>
+__global__ void prep_level_input_kernel(const float* __restrict__ img, const float* __restrict__ pred,
+                                        T* __restrict__ out, int N, int H, int W, int s, int cpad) {
+  const int oh = H / s, ow = W / s;
+  const size_t total = (size_t)N * oh * ow * cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const size_t pix = i / cpad;
+    const int x = (int)(pix % ow);
+    const int y = (int)((pix / ow) % oh);
+    const int n = (int)(pix / ((size_t)ow * oh));
+    float v = 0.f;
+    if (c < 29) v = img[(((size_t)n * H + (size_t)y * s) * W + (size_t)x * s) * 29 + c];
+    else if (pred != nullptr && c < 38) v = pred[pix * 9 + (c - 29)];
+    out[i] = Prec<T>::from_f32(v);
+  }
+}
+
+// ---- 2x2/2 max pool: ops.py:54 tf.nn.max_pool(..., 'SAME') on even sizes ----
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
+  constexpr int EPU = 16 / sizeof(T);
+  const int oh = H / 2, ow = W / 2, cv = C / EPU;
+  const size_t total = (size_t)N * oh * ow * cv;
+  const uint4* src = reinterpret_cast<const uint4*>(in);
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    const size_t pix = i / cv;
+    const int x = (int)(pix % ow);
+    const int y = (int)((pix / ow) % oh);
+    const int n = (int)(pix / ((size_t)ow * oh));
+    const size_t b = (((size_t)n * H + 2 * y) * W + 2 * x) * cv + c;
+    const uint4 q0 = src[b], q1 = src[b + cv], q2 = src[b + (size_t)W * cv], q3 = src[b + (size_t)W * cv + cv];
+    uint4 r;
+    if constexpr (sizeof(T) == 4) {
+      f32x4 a = __builtin_bit_cast(f32x4, q0), b1 = __builtin_bit_cast(f32x4, q1);
+      f32x4 c1 = __builtin_bit_cast(f32x4, q2), d = __builtin_bit_cast(f32x4, q3), m;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(a[k], b1[k]), fmaxf(c1[k], d[k]));
+      r = __builtin_bit_cast(uint4, m);
+    } else {
+      f16x8 a = __builtin_bit_cast(f16x8, q0), b1 = __builtin_bit_cast(f16x8, q1);
+      f16x8 c1 = __builtin_bit_cast(f16x8, q2), d = __builtin_bit_cast(f16x8, q3), m;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        _Float16 u = a[k] > b1[k] ? a[k] : b1[k];
+        _Float16 v = c1[k] > d[k] ? c1[k] : d[k];
+        m[k] = u > v ? u : v;
+      }
+      r = __builtin_bit_cast(uint4, m);
+    }
+    dst[i] = r;
+  }
+}
+
+// ---- x2 bilinear up-sample: ops.py:69 tf.image.resize_images(BILINEAR), TF-1.13 legacy kernel ----
+// in = out*0.5, lo = floor(in), hi = min(lo+1, n-1), t = in-lo;
+// top = tl+(tr-tl)*tx; bot = bl+(br-bl)*tx; out = top+(bot-top)*ty   
+template <typename T>
+__global__ void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
+#pragma clang fp contract(off)
+  constexpr int EPU = 16 / sizeof(T);
+  const int oh = H * 2, ow = W * 2, cv = C / EPU;
+  const size_t total = (size_t)N * oh * ow * cv;
+  const uint4* src = reinterpret_cast<const uint4*>(in);
+  uint4* dst = reinterpret_cast<uint4*>(out);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    const size_t pix = i / cv;
+    const int ox = (int)(pix % ow);
+    const int oy = (int)((pix / ow) % oh);
+    const int n = (int)(pix / ((size_t)ow * oh));
+    const int y0 = oy >> 1, y1 = min(y0 + 1, H - 1);
+    const int x0 = ox >> 1, x1 = min(x0 + 1, W - 1);
+    const float ty = (oy & 1) ? 0.5f : 0.f, tx = (ox & 1) ? 0.5f : 0.f;
+    const size_t r0 = ((size_t)n * H + y0) * W, r1 = ((size_t)n * H + y1) * W;
+    const uint4 qtl = src[(r0 + x0) * cv + c], qtr = src[(r0 + x1) * cv + c];
+    const uint4 qbl = src[(r1 + x0) * cv + c], qbr = src[(r1 + x1) * cv + c];
+    uint4 r;
+    if constexpr (sizeof(T) == 4) {
+      f32x4 tl = __builtin_bit_cast(f32x4, qtl), tr = __builtin_bit_cast(f32x4, qtr);
+      f32x4 bl = __builtin_bit_cast(f32x4, qbl), br = __builtin_bit_cast(f32x4, qbr), o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float top = tl[k] + (tr[k] - tl[k]) * tx;
+        const float bot = bl[k] + (br[k] - bl[k]) * tx;
+        o[k] = top + (bot - top) * ty;
+      }
+      r = __builtin_bit_cast(uint4, o);
+    } else {
+      f16x8 tl = __builtin_bit_cast(f16x8, qtl), tr = __builtin_bit_cast(f16x8, qtr);
+      f16x8 bl = __builtin_bit_cast(f16x8, qbl), br = __builtin_bit_cast(f16x8, qbr), o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float a = (float)tl[k], b = (float)tr[k], c2 = (float)bl[k], d = (float)br[k];
+        const float top = a + (b - a) * tx;
+        const float bot = c2 + (d - c2) * tx;
+        o[k] = (_Float16)(top + (bot - top) * ty);
+      }
+      r = __builtin_bit_cast(uint4, o);
+    }
+    dst[i] = r;
+  }
+}
+
+// ---- frame warp: FISR_tfoptflow/FISR_for_video_warp_img_with_flo.py:35-67,112-129 ----
+// dst = RGB2YUV( remap( YUV2RGB(src), x + s*u, y + s*v, INTER_LINEAR, BORDER_REPLICATE ) )
+// cv2.remap (opencv_python 4.2.0.32) semantics restated: float32 map, fixed-point
+// coordinates sx = cvRound(mx*32) -> integer part sx>>5, fraction (sx&31)/32 through the
+// float bilinear table, 4-tap sum in double (the source is a float64 array in the reference),
+// taps clamped to the image.  Colour maths in double like the numpy reference.
+struct ColorConsts {
+  double t[3][3];    // 255 * Tinv                (YUV -> RGB)
+  double off[3];     // 255 * Tinv @ [16,128,128]
+  double f[3][3];    // T / 255                   (RGB -> YUV)
+};
+
+__device__ __forceinline__ void yuv2rgb_d(const ColorConsts& cc, const float* p, double* rgb) {
+#pragma clang fp contract(off)
+  const double y = (double)p[0], u = (double)p[1], v = (double)p[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double r = cc.t[k][0] * y + cc.t[k][1] * u + cc.t[k][2] * v - cc.off[k];
+    rgb[k] = fmin(fmax(r, 0.0), 255.0);
+  }
+}
+
+__global__ void warp_kernel(const float* __restrict__ src, const float* __restrict__ flow, float scale,
+                            int H, int W, int quantized, float* __restrict__ dst, const ColorConsts cc) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)(i / W);
+    const float mx = __fadd_rn(__fmul_rn(flow[i * 2 + 0], scale), (float)x);
+    const float my = __fadd_rn(__fmul_rn(flow[i * 2 + 1], scale), (float)y);
+    int ix, iy;
+    float fx, fy;
+    if (quantized) {
+      const int sx = __float2int_rn(__fmul_rn(mx, 32.f));
+      const int sy = __float2int_rn(__fmul_rn(my, 32.f));
+      ix = sx >> 5; iy = sy >> 5;
+      fx = (float)(sx & 31) * (1.f / 32.f);
+      fy = (float)(sy & 31) * (1.f / 32.f);
+    } else {
+      const float flx = floorf(mx), fly = floorf(my);
+      ix = (int)flx; iy = (int)fly;
+      fx = __fsub_rn(mx, flx); fy = __fsub_rn(my, fly);
+    }
+    const double w00 = (double)__fmul_rn(1.f - fy, 1.f - fx), w01 = (double)__fmul_rn(1.f - fy, fx);
+    const double w10 = (double)__fmul_rn(fy, 1.f - fx), w11 = (double)__fmul_rn(fy, fx);
+    const int x0 = min(max(ix, 0), W - 1), x1 = min(max(ix + 1, 0), W - 1);
+    const int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
+    double a[3], b[3], c[3], d[3], rgb[3];
+    yuv2rgb_d(cc, src + ((size_t)y0 * W + x0) * 3, a);
+    yuv2rgb_d(cc, src + ((size_t)y0 * W + x1) * 3, b);
+    yuv2rgb_d(cc, src + ((size_t)y1 * W + x0) * 3, c);
+    yuv2rgb_d(cc, src + ((size_t)y1 * W + x1) * 3, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = a[k] * w00 + b[k] * w01 + c[k] * w10 + d[k] * w11;
+    const double offs[3] = {16.0, 128.0, 128.0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = cc.f[k][0] * rgb[0] + cc.f[k][1] * rgb[1] + cc.f[k][2] * rgb[2] + offs[k];
+      dst[i * 3 + k] = (float)fmin(fmax(v, 0.0), 255.0);
+    }
+  }
+}
+
+// ---- input assembly: FISRnet.py:828-843 ----
+struct PackPtrs {
+  const uint8_t* fr[3];
+  const float* fl[4];
+  const float* wp[4];
+};
+
+__global__ void pack_input_kernel(const PackPtrs pp, int H0, int W0, int H, int W, float* __restrict__ out) {
+  const size_t total = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)(i / W);
+    const size_t s = (size_t)y * W0 + x;
+    float* o = out + i * 29;
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // np.array(img, dtype=np.double)/255. then clip (FISRnet.py:828-830), fed as float32
+        const double v = (double)pp.fr[f][s * 3 + c] / 255.0;
+        o[f * 3 + c] = (float)fmin(fmax(v, 0.0), 1.0);
+      }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // flow/96/2, clip [-1,1] in float32 (FISRnet.py:835-836)
+        const float v = __fdiv_rn(__fdiv_rn(pp.fl[f][s * 2 + c], 96.f), 2.f);
+        o[9 + f * 2 + c] = fminf(fmaxf(v, -1.f), 1.f);
+      }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // .mat value /255 in float32 (utils.py:51), clip [0,1] (FISRnet.py:840)
+        const float v = __fdiv_rn(pp.wp[f][s * 3 + c], 255.f);
+        o[17 + f * 3 + c] = fminf(fmaxf(v, 0.f), 1.f);
+      }
+  }
+}
+
+// ---- output post-processing: FISRnet.py:883, 903-909; utils.py:106-115 ----
+__global__ void unpack_output_kernel(const float* __restrict__ pred, int H, int W, uint8_t* __restrict__ yuv_u8,
+                                     uint8_t* __restrict__ rgb_u8, const ColorConsts cc) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      float q[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = fminf(fmaxf(pred[i * 9 + f * 3 + c], 0.f), 1.f);  // np.clip(., 0, 1)
+        const uint8_t b = (uint8_t)(int)((double)v * 255.0);               // np.uint8(x*255): truncation
+        if (yuv_u8) yuv_u8[i * 9 + f * 3 + c] = b;
+        q[c] = (float)b;
+      }
+      if (rgb_u8) {
+        double rgb[3];
+        yuv2rgb_d(cc, q, rgb);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb_u8[((size_t)f * total + i) * 3 + c] = (uint8_t)(int)rgb[c];
+      }
+    }
+  }
+}
+
+// ---- stitch: trim_patch_boundary (utils.py:138-159) + FISRnet.py:879-880 ----
+__global__ void stitch_kernel(const float* __restrict__ tile, int TW, int sy, int sx, int CH, int CW,
+                              float* __restrict__ full, int FW, int dy, int dx) {
+  const size_t total = (size_t)CH * CW * 9;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 9);
+    const size_t pix = i / 9;
+    const int x = (int)(pix % CW), y = (int)(pix / CW);
+    full[((size_t)(dy + y) * FW + dx + x) * 9 + c] = tile[((size_t)(sy + y) * TW + sx + x) * 9 + c];
+  }
+}
+
+// ---- sum of squared error vs uint8 ground truth: utils.py:23-26 with FISRnet.py:828-831,883 ----
+__global__ void sse_u8_kernel(const float* __restrict__ pred, const uint8_t* __restrict__ gt, size_t count,
+                              double* __restrict__ acc) {
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const double p = (double)fminf(fmaxf(pred[i], 0.f), 1.f);
+    const double g = (double)gt[i] / 255.0;
+    const double d = g - p;
+    s += d * d;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ double part[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tsum = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tsum += part[k];
+    atomicAdd(acc, tsum);
+  }
+}
+
+}  // namespace fisr

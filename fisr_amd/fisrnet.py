@@ -1,0 +1,260 @@
+"""Host-side mirror of the reference's `FISRnet` class for the inference path.
+
+Same names, argument meaning and error behaviour as the reference seams:
+
+  FISRnet.model(img, sf)            <-> FISRnet.py:73-173   (graph seam, via libfisr_hip.so)
+  FISRnet.load(checkpoint_dir)      <-> FISRnet.py:1101-1115 (weight seam)
+  FISRnet.test()                    <-> FISRnet.py:746-935
+  FISRnet.FISR_for_video(flo, mat)  <-> FISRnet.py:937-1084
+
+PyTorch is used only for device memory, streams and torch.distributed; all arithmetic of the
+hot path runs in the hand-written HIP kernels behind the C-ABI (include/fisr.h).  There is no
+CPU fallback: without a GPU / the built library every compute call raises FisrError.
+"""
+from __future__ import annotations
+
+import ctypes
+import glob
+import math
+import os
+import time
+from types import SimpleNamespace
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as _lib
+from . import tiling
+from . import weights as _weights
+from .lib import FisrError
+
+_PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
+         "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream(device) -> ctypes.c_void_p:
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def default_args(**over) -> SimpleNamespace:
+    """The reference's argparse defaults that the inference path reads (main.py:26-103)."""
+    a = SimpleNamespace(
+        net_type="FISRnet", phase="FISR_for_video", scale_factor=2, exp_num=1,
+        test_data_path="./data/test/LR_LFR", test_label_path="./data/test/HR_HFR",
+        test_flow_data_path="./data/test/flow/LR_Surfing_SlamDunk_test_ss1.flo",
+        test_warped_data_path="./data/test/warped/LR_Surfing_SlamDunk_test_ss1_warp.mat",
+        test_img_dir="./test_img_dir", checkpoint_dir="./checkpoint_dir",
+        test_patch=(2, 2), test_input_size=(1080, 1920),
+        frame_folder_path="./FISR_test_folder/scene1", FISR_input_size=(1080, 1920), frame_num=5,
+        FISR_test_patch=(2, 2), precision="fp32", device="cuda:0")
+    a.__dict__.update(over)
+    return a
+
+
+class FISRnet:
+    """MI355X-native FISRnet inference engine with the reference class's surface."""
+
+    def __init__(self, args: Optional[SimpleNamespace] = None, device: Optional[str] = None,
+                 precision: Optional[str] = None, quiet: bool = True):
+        args = args or default_args()
+        self.args = args
+        self.model_name = getattr(args, "net_type", "FISRnet")      # FISRnet.py:19
+        self.exp_num = getattr(args, "exp_num", 1)
+        self.scale_factor = int(getattr(args, "scale_factor", 2))   # main.py:29 (float default quirk fixed)
+        if self.scale_factor != 2:
+            raise ValueError("FISRnet is a x2 network (depth_to_space(.,2), FISRnet.py:99)")
+        for k in ("test_data_path", "test_label_path", "test_flow_data_path", "test_warped_data_path",
+                  "test_img_dir", "checkpoint_dir", "test_patch", "test_input_size", "frame_folder_path",
+                  "FISR_input_size", "frame_num", "FISR_test_patch"):
+            setattr(self, k, getattr(args, k, getattr(default_args(), k)))
+        self.precision = precision or getattr(args, "precision", "fp32")
+        if self.precision not in _PREC:
+            raise ValueError(f"unknown precision {self.precision!r}")
+        torch = _torch()
+        self.device = torch.device(device or getattr(args, "device", "cuda:0"))
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise FisrError("FISRnet needs a ROCm GPU (cuda device); there is no CPU fallback")
+        self._L = _lib.lib()
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self._L.fisr_create(ctypes.byref(self._ctx), self.device.index or 0))
+        self._finalized = False
+        self._ws = None
+        self.quiet = quiet
+        self.inf_time = []
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def model_dir(self) -> str:
+        return "{}_exp{}".format(self.model_name, self.exp_num)   # FISRnet.py:1086-1089
+
+    def set_weights(self, weights) -> None:
+        """Install the 276 variables (dict keyed by TF variable name) and re-pack for the kernels."""
+        _weights.check_complete(weights)
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, np.float32)
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            _lib.check(self._L.fisr_set_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                               shape, a.ndim), self._ctx)
+        _lib.check(self._L.fisr_finalize_weights(self._ctx, _PREC[self.precision]), self._ctx)
+        self._finalized = True
+
+    def load(self, checkpoint_dir: str):
+        """FISRnet.py:1101-1115: -> (ok, step).  Reads `<checkpoint_dir>/FISRnet_exp<N>/`."""
+        print(" [*] Reading checkpoints...")
+        path, kind, step = _weights.find_checkpoint(checkpoint_dir, self.model_dir)
+        if path is None:
+            print(" [*] Failed to find a checkpoint")
+            return False, 0
+        self.set_weights(_weights.load_weights(path, kind))
+        print(" [*] Success to read {}".format(os.path.basename(path)))
+        return True, step
+
+    # ------------------------------------------------------------------ graph seam
+    def _workspace(self, n: int, h: int, w: int):
+        torch = _torch()
+        need = self._L.fisr_workspace_bytes(self._ctx, n, h, w)
+        if need == 0:
+            raise FisrError("fisr_workspace_bytes: invalid shape or weights not finalized")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def model(self, img, sf: int = 2, reuse: bool = False, scope: str = "FISRnet", want_all: bool = True):
+        """FISRnet.py:73-173: img [N,H,W,29] float32 on the GPU -> (pred_l1, pred_l2, pred_l3)."""
+        torch = _torch()
+        if sf != 2:
+            raise ValueError("sf must be 2")
+        if not self._finalized:
+            raise FisrError("weights not loaded: call load() or set_weights() first")
+        if img.dim() != 4 or img.shape[3] != 29:
+            raise ValueError(f"img must be [N,H,W,29], got {tuple(img.shape)}")
+        n, h, w, _ = img.shape
+        if h % 32 or w % 32:
+            raise ValueError("H and W must be multiples of 32 (FISRnet.py:820-824)")
+        img = img.to(device=self.device, dtype=torch.float32).contiguous()
+        l3 = torch.empty((n, 2 * h, 2 * w, 9), dtype=torch.float32, device=self.device)
+        l2 = torch.empty((n, h, w, 9), dtype=torch.float32, device=self.device) if want_all else None
+        l1 = torch.empty((n, h // 2, w // 2, 9), dtype=torch.float32, device=self.device) if want_all else None
+        ws = self._workspace(n, h, w)
+        _lib.check(self._L.fisr_forward(self._ctx, _ptr(img), n, h, w, _ptr(l3), _ptr(l2), _ptr(l1), _ptr(ws),
+                                        ws.numel(), _stream(self.device)), self._ctx)
+        return l1, l2, l3
+
+    # ------------------------------------------------------------------ profiling hooks
+    def profile(self, on: bool) -> None:
+        self._L.fisr_profile_enable(self._ctx, int(on))
+        self._L.fisr_profile_reset(self._ctx)
+
+    def profile_read(self):
+        cap = 64
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_double * cap)()
+        cnt = (ctypes.c_int64 * cap)()
+        fl = (ctypes.c_double * cap)()
+        by = (ctypes.c_double * cap)()
+        k = self._L.fisr_profile_read(self._ctx, cap, names, ms, cnt, fl, by)
+        return [dict(name=names[i].decode(), ms=ms[i], launches=cnt[i], flops=fl[i], bytes=by[i]) for i in range(min(k, cap))]
+
+    # ------------------------------------------------------------------ glue kernels
+    def warp(self, src_yuv, flow, flow_scale: float = 0.5, quantized: bool = True):
+        """warp script :112-129, one direction: src_yuv [h,w,3] (uint8/float, 0..255), flow [h,w,2] px."""
+        torch = _torch()
+        src = src_yuv.to(device=self.device, dtype=torch.float32).contiguous()
+        fl = flow.to(device=self.device, dtype=torch.float32).contiguous()
+        h, w = fl.shape[:2]
+        if tuple(src.shape) != (h, w, 3) or fl.shape[2] != 2:
+            raise ValueError("warp: src must be [h,w,3] and flow [h,w,2]")
+        dst = torch.empty((h, w, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.fisr_warp(_ptr(src), _ptr(fl), flow_scale, h, w, int(quantized), _ptr(dst), _stream(self.device)))
+        return dst
+
+    def pack_input(self, frames_u8: Sequence, flows: Sequence, warps: Sequence, h: int, w: int):
+        """FISRnet.py:828-843: 3 uint8 YUV frames [h0,w0,3], 4 flows [h0,w0,2] (px), 4 warped frames
+        [h0,w0,3] (0..255 float32) -> [1,h,w,29] float32 (top-left crop to h x w)."""
+        torch = _torch()
+        fr = [f.to(device=self.device, dtype=torch.uint8).contiguous() for f in frames_u8]
+        fl = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in flows]
+        wp = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in warps]
+        if len(fr) != 3 or len(fl) != 4 or len(wp) != 4:
+            raise ValueError("pack_input needs 3 frames, 4 flows, 4 warps")
+        h0, w0 = fr[0].shape[:2]
+        out = torch.empty((1, h, w, 29), dtype=torch.float32, device=self.device)
+        a = (ctypes.c_void_p * 3)(*[f.data_ptr() for f in fr])
+        b = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in fl])
+        c = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in wp])
+        _lib.check(self._L.fisr_pack_input(a, b, c, h0, w0, h, w, _ptr(out), _stream(self.device)))
+        return out
+
+    def unpack_output(self, pred_hw9, want_rgb: bool = True):
+        """FISRnet.py:883,903-909: -> (yuv_u8 [h,w,9], rgb_u8 [3,h,w,3])."""
+        torch = _torch()
+        h, w = pred_hw9.shape[:2]
+        yuv = torch.empty((h, w, 9), dtype=torch.uint8, device=self.device)
+        rgb = torch.empty((3, h, w, 3), dtype=torch.uint8, device=self.device) if want_rgb else None
+        _lib.check(self._L.fisr_unpack_output(_ptr(pred_hw9.contiguous()), h, w, _ptr(yuv), _ptr(rgb), _stream(self.device)))
+        return yuv, rgb
+
+    def sse_vs_u8(self, pred, gt_u8) -> float:
+        out = ctypes.c_double()
+        pred = pred.contiguous()
+        gt_u8 = gt_u8.to(self.device).contiguous()
+        _lib.check(self._L.fisr_sse_vs_u8(_ptr(pred), _ptr(gt_u8), pred.numel(), ctypes.byref(out), _stream(self.device)))
+        return out.value
+
+    # ------------------------------------------------------------------ tiled forward (FISRnet.py:845-883)
+    def forward_tiled(self, inp, num_patch: Tuple[int, int] = (2, 2), tiles: Optional[Sequence[int]] = None,
+                      full=None, timed: bool = False):
+        """inp [1,h,w,29] on the GPU -> full prediction [h*2,w*2,9] float32 (not clipped; the
+        clip of FISRnet.py:883 is applied by unpack_output / sse_vs_u8).  `tiles` restricts the
+        work to a subset of tile indices (tile-parallel sharding, see fisr_amd/dist.py)."""
+        torch = _torch()
+        _, h, w, _ = inp.shape
+        sf = self.scale_factor
+        plan = tiling.plan_tiles(h, w, tuple(num_patch), sf)
+        if full is None:
+            full = torch.zeros((h * sf, w * sf, 9), dtype=torch.float32, device=self.device)
+        for t in plan:
+            if tiles is not None and t.index not in tiles:
+                continue
+            simg = inp[:, t.h_lo:t.h_hi, t.w_lo:t.w_hi, :].contiguous()
+            if timed:
+                torch.cuda.synchronize(self.device)
+                t0 = time.time()
+            _, _, pred = self.model(simg, sf, want_all=False)
+            if timed:
+                torch.cuda.synchronize(self.device)
+                self.inf_time.append(time.time() - t0)
+            _lib.check(self._L.fisr_stitch(_ptr(pred), t.in_h * sf, t.in_w * sf, t.src_y, t.src_x, t.out_h, t.out_w,
+                                           _ptr(full), h * sf, w * sf, t.dst_y, t.dst_x, _stream(self.device)))
+        return full
+
+    # ------------------------------------------------------------------ harnesses
+    def test(self):
+        from .harness import run_test
+        return run_test(self)
+
+    def FISR_for_video(self, flow_file_name, warp_file_name):
+        from .harness import run_fisr_for_video
+        return run_fisr_for_video(self, flow_file_name, warp_file_name)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._L.fisr_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,111 @@
+"""ctypes binding of libfisr_hip.so (include/fisr.h) and its in-tree build.
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an
+exception is raised (FisrError) -- nothing here ever routes through `oracle/` or a
+PyTorch/CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint8, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SO_PATH = os.path.join(_PKG, "libfisr_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+PREC_F32, PREC_F16 = 0, 1
+CONV_RELU_IN, CONV_RELU_OUT, CONV_D2S = 1, 2, 4
+
+EXPORTS = [
+    "fisr_version", "fisr_create", "fisr_destroy", "fisr_last_error", "fisr_set_weight",
+    "fisr_finalize_weights", "fisr_num_variables_set", "fisr_workspace_bytes", "fisr_forward",
+    "fisr_profile_enable", "fisr_profile_reset", "fisr_profile_read", "fisr_warp", "fisr_pack_input",
+    "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_op_conv3x3", "fisr_op_maxpool2",
+    "fisr_op_upsample2",
+]
+
+
+class FisrError(RuntimeError):
+    pass
+
+
+def hipcc_path() -> str:
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.isabs(p) and os.path.isfile(p) or not os.path.isabs(p)):
+            return p
+    return "hipcc"
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_ROOT, "include", "fisr.h")]
+
+
+def needs_build() -> bool:
+    if not os.path.isfile(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> fisr_amd/libfisr_hip.so (in-tree; cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", SO_PATH, os.path.join(CSRC, "fisr_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (never builds implicitly on a GPU box: the .so ships in-tree)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(SO_PATH):
+        raise FisrError(f"{SO_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp = c_void_p
+    L.fisr_version.restype = c_char_p
+    L.fisr_create.argtypes = [POINTER(vp), c_int]
+    L.fisr_destroy.argtypes = [vp]
+    L.fisr_destroy.restype = None
+    L.fisr_last_error.argtypes = [vp]
+    L.fisr_last_error.restype = c_char_p
+    L.fisr_set_weight.argtypes = [vp, c_char_p, POINTER(c_float), POINTER(c_int64), c_int]
+    L.fisr_finalize_weights.argtypes = [vp, c_int]
+    L.fisr_num_variables_set.argtypes = [vp]
+    L.fisr_workspace_bytes.argtypes = [vp, c_int, c_int, c_int]
+    L.fisr_workspace_bytes.restype = c_size_t
+    L.fisr_forward.argtypes = [vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    L.fisr_profile_enable.argtypes = [vp, c_int]
+    L.fisr_profile_reset.argtypes = [vp]
+    L.fisr_profile_read.argtypes = [vp, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_int64),
+                                    POINTER(c_double), POINTER(c_double)]
+    L.fisr_warp.argtypes = [vp, vp, c_float, c_int, c_int, c_int, vp, vp]
+    L.fisr_pack_input.argtypes = [POINTER(vp), POINTER(vp), POINTER(vp), c_int, c_int, c_int, c_int, vp, vp]
+    L.fisr_unpack_output.argtypes = [vp, c_int, c_int, vp, vp, vp]
+    L.fisr_stitch.argtypes = [vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, vp]
+    L.fisr_sse_vs_u8.argtypes = [vp, vp, c_size_t, POINTER(c_double), vp]
+    L.fisr_op_conv3x3.argtypes = [vp, c_int, vp, c_int, POINTER(c_float), POINTER(c_float), c_int, vp, vp,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_op_maxpool2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_op_upsample2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, ctx=None):
+    if rc < 0:
+        msg = lib().fisr_last_error(ctx).decode("utf-8", "replace")
+        raise FisrError(f"libfisr_hip error {rc}: {msg}")
+    return rc

@@ -1,0 +1,147 @@
+/* libfisr_hip.so -- C-ABI of the MI355X-native FISRnet inference hot path.
+ *
+ * The reference (JihyongOh/FISR, Python + TensorFlow 1.13) has no FFI layer; the hot
+ * path sits behind three Python seams.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference root):
+ *
+ *   graph seam   FISRnet.model(img, sf) -> (pred_l1, pred_l2, pred_l3)   FISRnet.py:73-173
+ *                executed by sess.run(test_Pred, feed_dict=...)          FISRnet.py:871-872, 1048-1049
+ *   weight seam  FISRnet.load(checkpoint_dir) / tf.train.Saver.restore   FISRnet.py:751-753, 1101-1115
+ *   warp         warp_flow() + YUV2RGB/RGB2YUV                           FISR_tfoptflow/FISR_for_video_warp_img_with_flo.py:35-67,112-129
+ *   input pack   normalise / clip / concat                               FISRnet.py:828-843
+ *   output       clip, uint8 truncation, YUV2RGB_matlab                  FISRnet.py:883,903-909; utils.py:106-115
+ *
+ * Conventions: plain C, no torch types.  Every function returns 0 on success or a
+ * negative FISR_E* code; the message is available from fisr_last_error() (never
+ * throws across the ABI).  All tensor pointers are DEVICE pointers owned by the
+ * caller (e.g. torch.Tensor.data_ptr()) unless the name says `host`.  `stream` is a
+ * hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); calls are
+ * asynchronous on it.  One ctx per device; calls on one ctx are not re-entrant.
+ * Layout is NHWC everywhere, exactly as the reference feeds TensorFlow.
+ */
+#ifndef FISR_H
+#define FISR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fisr_ctx fisr_ctx;
+
+enum {
+  FISR_OK = 0,
+  FISR_EINVAL = -1,   /* bad argument (shape not multiple of 32, null pointer, ...) */
+  FISR_ESTATE = -2,   /* wrong call order (forward before finalize, ...) */
+  FISR_EMISSING = -3, /* a required variable was never set */
+  FISR_EHIP = -4,     /* HIP runtime error */
+  FISR_ENOMEM = -5    /* workspace too small */
+};
+
+/* Arithmetic the conv kernels compute in (activations are stored in the same type). */
+enum {
+  FISR_PREC_F32 = 0, /* fp32 activations/weights, v_mfma_f32_32x32x2_f32 (exact fp32, fmaf chain) */
+  FISR_PREC_F16 = 1  /* fp16 activations/weights, v_mfma_f32_32x32x16_f16, fp32 accumulate */
+};
+
+/* flags of fisr_op_conv3x3 */
+enum {
+  FISR_CONV_RELU_IN = 1,  /* conv(relu(x))           ops.py:41-42 */
+  FISR_CONV_RELU_OUT = 2, /* relu(conv(x) [+ res])   ops.py:52,62,70,75 */
+  FISR_CONV_D2S = 4       /* tf.depth_to_space(y, 2) fused into the store, FISRnet.py:99 */
+};
+
+const char* fisr_version(void);
+
+/* ---- context: owns the (re-packed) weights; replaces the tf.Session + variables ---- */
+int fisr_create(fisr_ctx** out, int device_id);
+void fisr_destroy(fisr_ctx* ctx);
+/* ctx may be NULL: returns the last error of the calling thread. */
+const char* fisr_last_error(const fisr_ctx* ctx);
+
+/* Weight seam (replaces saver.restore, FISRnet.py:1108).  `tf_var_name` is the
+ * reference's variable name, e.g. "FISRnet/level_3/dec/level_0/resize/w"; `host` is the
+ * float32 tensor in TF layout (HWIO for .../w, [Cout] for .../b); copied.  Names outside
+ * the 276 FISRnet variables (Adam slots, global step) are ignored with return 1. */
+int fisr_set_weight(fisr_ctx* ctx, const char* tf_var_name, const float* host,
+                    const int64_t* shape, int rank);
+/* Re-pack for the MFMA kernels and upload.  Fails with FISR_EMISSING (naming the first
+ * absent variable) unless all 276 tensors were set. */
+int fisr_finalize_weights(fisr_ctx* ctx, int precision);
+int fisr_num_variables_set(const fisr_ctx* ctx);
+
+/* Graph seam.  in: [n,h,w,29] float32; h % 32 == 0 and w % 32 == 0 (FISRnet.py:820-824).
+ * out_l3 [n,2h,2w,9] float32 (required); out_l2 [n,h,w,9], out_l1 [n,h/2,w/2,9] optional
+ * (NULL to skip the copy-out).  workspace: caller-owned device scratch of at least
+ * fisr_workspace_bytes(ctx,n,h,w). */
+size_t fisr_workspace_bytes(const fisr_ctx* ctx, int n, int h, int w);
+int fisr_forward(fisr_ctx* ctx, const float* in_nhwc29, int n, int h, int w,
+                 float* out_l3, float* out_l2, float* out_l1,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-kernel timing (HIP events on `stream` around every launch of the next forwards).
+ * Off by default; bench.py uses it for the roofline figure of the dominant kernel. */
+int fisr_profile_enable(fisr_ctx* ctx, int on);
+int fisr_profile_reset(fisr_ctx* ctx);
+/* Fills up to `cap` entries; returns the number of kernel classes.  name[i] points into
+ * ctx-owned storage.  flops = algorithmic 2*9*Cin*Cout*pixels summed over launches. */
+int fisr_profile_read(fisr_ctx* ctx, int cap, const char** name, double* total_ms,
+                      int64_t* launches, double* flops, double* bytes);
+
+/* ---- glue kernels (HBM-bound) ---- */
+
+/* Frame warp, one direction (warp script :112-129): src_yuv [h,w,3] float32 0..255 (the
+ * OTHER frame of the pair), flow [h,w,2] float32 pixels, flow_scale 0.5 (:122,126),
+ * quantized!=0 reproduces cv2.remap's 1/32-px fixed-point coordinates.
+ * dst_yuv [h,w,3] float32 0..255 (what the reference stores in the .mat file). */
+int fisr_warp(const float* src_yuv, const float* flow, float flow_scale, int h, int w,
+              int quantized, float* dst_yuv, void* stream);
+
+/* Input assembly for window s (FISRnet.py:828-843): frames_u8 [3][h0,w0,3] uint8 YUV
+ * given as three device pointers, flow4 [4][h0,w0,2] float32 px and warp4 [4][h0,w0,3]
+ * float32 0..255 given as four pointers each; crops to h x w (top-left), normalises
+ * (/255 clip01; /96/2 clip+-1; /255 clip01) and writes [1,h,w,29] float32. */
+int fisr_pack_input(const uint8_t* const* frames3, const float* const* flow4,
+                    const float* const* warp4, int h0, int w0, int h, int w,
+                    float* out_nhwc29, void* stream);
+
+/* Output post-processing (FISRnet.py:883,903-909): pred [h,w,9] float32 -> clip[0,1],
+ * yuv_u8 [h,w,9] = uint8(x*255) (truncation), rgb_u8 [3][h,w,3] = YUV2RGB_matlab(yuv)
+ * truncated (either may be NULL). */
+int fisr_unpack_output(const float* pred_hw9, int h, int w, uint8_t* yuv_u8, uint8_t* rgb_u8,
+                       void* stream);
+
+/* Copy the trimmed interior of a tile prediction into the full frame
+ * (trim_patch_boundary utils.py:138-159 + the stitch at FISRnet.py:879-880).
+ * tile [th,tw,9] -> full[fh,fw,9] at (dst_y,dst_x), taking rows/cols from (src_y,src_x),
+ * size (ch,cw). */
+int fisr_stitch(const float* tile, int th, int tw, int src_y, int src_x, int ch, int cw,
+                float* full, int fh, int fw, int dst_y, int dst_x, void* stream);
+
+/* Sum of squared error of a prediction against uint8 ground truth, in double, as the
+ * reference's PSNR sees it (utils.py:23-26 over FISRnet.py:828-831,883):
+ * sum((gt_u8/255.0 - clip(pred,0,1))^2).  The result is written to *out_host after the
+ * stream is synchronised. */
+int fisr_sse_vs_u8(const float* pred, const uint8_t* gt_u8, size_t count, double* out_host,
+                   void* stream);
+
+/* ---- op-level entry points (parity tests of the individual kernels) ---- */
+
+/* y = conv3x3_SAME(concat(in0,in1)) + b [+ res], ops.py:7-11.  Activations are float32
+ * (FISR_PREC_F32) or float16 (FISR_PREC_F16) device tensors; in1/res may be NULL;
+ * c0 (and c1) must be multiples of 16 (f32) / 32 (f16) elements; w_host [3,3,c0+c1,cout]
+ * and b_host [cout] are HOST float32.  With FISR_CONV_D2S, cout % 4 == 0 and out is
+ * [n,2h,2w,cout/4].  out_f32 != 0 stores float32 regardless of precision.
+ * Synchronous (packs and uploads the weights on every call). */
+int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host,
+                    const float* b_host, int cout, const void* res, void* out, int n, int h,
+                    int w, int flags, int precision, int out_f32, void* stream);
+int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
+int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISR_H */

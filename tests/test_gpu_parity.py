@@ -1,0 +1,354 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box): the HIP path, called through the
+C-ABI of libfisr_hip.so, against the CPU oracle on the same seeded inputs and against the
+committed golden fixtures.  /root/reference is never read here.
+
+Tolerances: north_star asks for +-0.02 dB PSNR / 1e-3 SSIM against the reference; the fp32
+MFMA path is held to a much tighter max-abs bound against the float64 oracle.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import c_oracle as C          # noqa: E402
+import fisr_oracle as O       # noqa: E402
+from fisr_amd import lib as flib  # noqa: E402
+from fisr_amd.fisrnet import FISRnet  # noqa: E402
+
+F32_FWD_TOL = 2e-4      # max |hip_fp32 - oracle_fp64| on O(1) outputs after 138 convs
+F32_OP_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def net32(dev, syn_weights):
+    n = FISRnet(device="cuda:0", precision="fp32")
+    n.set_weights(syn_weights)
+    yield n
+    n.close()
+
+
+@pytest.fixture(scope="module")
+def net16(dev, syn_weights):
+    n = FISRnet(device="cuda:0", precision="fp16")
+    n.set_weights(syn_weights)
+    yield n
+    n.close()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def hip_conv(x0, w, b, x1=None, res=None, flags=0, prec="fp32", out_f32=False):
+    """fisr_op_conv3x3 on numpy inputs -> numpy float32 output."""
+    L = flib.lib()
+    tdt = torch.float32 if prec == "fp32" else torch.float16
+    n, h, wd, c0 = x0.shape
+    cout = w.shape[3]
+    d0 = torch.from_numpy(np.ascontiguousarray(x0, np.float32)).cuda().to(tdt).contiguous()
+    d1 = torch.from_numpy(np.ascontiguousarray(x1, np.float32)).cuda().to(tdt).contiguous() if x1 is not None else None
+    dr = torch.from_numpy(np.ascontiguousarray(res, np.float32)).cuda().to(tdt).contiguous() if res is not None else None
+    if flags & flib.CONV_D2S:
+        oshape = (n, 2 * h, 2 * wd, cout // 4)
+    else:
+        oshape = (n, h, wd, cout)
+    out = torch.full(oshape, float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
+    wc = np.ascontiguousarray(w, np.float32)
+    bc = np.ascontiguousarray(b, np.float32)
+    rc = L.fisr_op_conv3x3(ctypes.c_void_p(d0.data_ptr()), c0,
+                           ctypes.c_void_p(d1.data_ptr() if d1 is not None else 0), x1.shape[3] if x1 is not None else 0,
+                           _fp(wc), _fp(bc), cout, ctypes.c_void_p(dr.data_ptr() if dr is not None else 0),
+                           ctypes.c_void_p(out.data_ptr()), n, h, wd, flags, 0 if prec == "fp32" else 1,
+                           int(out_f32), _stream())
+    flib.check(rc)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def ref_conv(x0, w, b, x1=None, res=None, flags=0):
+    x = x0 if x1 is None else np.concatenate([x0, x1], axis=3)
+    x = x.astype(np.float64)
+    if flags & flib.CONV_RELU_IN:
+        x = O.relu(x)
+    y = O.conv2d(x, w, b)
+    if res is not None:
+        y = res.astype(np.float64) + y
+    if flags & flib.CONV_RELU_OUT:
+        y = O.relu(y)
+    if flags & flib.CONV_D2S:
+        y = O.depth_to_space2(y)
+    return y
+
+
+def _report(got, exp, tol, what):
+    err = np.abs(got.astype(np.float64) - exp)
+    bad = np.argwhere(~(err <= tol))
+    msg = f"{what}: max err {np.nanmax(err) if err.size else 0:.3e}, nan {int(np.isnan(got).sum())}, bad {len(bad)}/{err.size}"
+    if len(bad):
+        msg += f"; first bad idx {bad[:6].tolist()} got {[float(got[tuple(i)]) for i in bad[:3]]} exp {[float(exp[tuple(i)]) for i in bad[:3]]}"
+    assert len(bad) == 0, msg
+
+
+# ----------------------------------------------------------------------------- conv kernel
+@pytest.mark.parametrize("shape", [
+    # n, h, w, c0, c1, cout, flags, use_res
+    (1, 8, 32, 16, 0, 64, 0, False),            # exactly one tile, one chunk
+    (1, 8, 32, 64, 0, 64, 0, False),            # 4 chunks
+    (1, 16, 64, 32, 0, 64, 3, True),            # relu in/out + residual, 2x2 tiles
+    (2, 24, 24, 64, 0, 128, 1, False),          # batch 2, ragged width (96x96 cfg level-1 size)
+    (1, 3, 3, 32, 0, 64, 0, False),             # deepest level of the 96x96 config
+    (1, 12, 12, 128, 0, 256, 2, False),
+    (1, 17, 45, 16, 0, 64, 0, False),           # odd sizes: masks on both axes
+    (1, 16, 40, 64, 64, 64, 0, False),          # dual-source concat (decoder conv/0)
+    (1, 8, 32, 64, 0, 256, 7, False),           # relu, relu, depth_to_space store (heads conv/1)
+    (1, 10, 33, 64, 0, 256, 6, False),          # d2s with ragged tile
+    (1, 16, 64, 64, 0, 6, 0, False),            # FI-SR conv/2 (NT=1, Cout 6 of 32)
+    (1, 9, 31, 64, 0, 3, 0, False),             # SR conv/2
+    (1, 8, 32, 48, 0, 64, 0, False),            # level-2/3 first conv (38 -> pad 48)
+    (1, 8, 8, 512, 0, 512, 0, True),            # bottleneck shape
+])
+def test_conv3x3_fp32_vs_oracle(dev, shape):
+    n, h, w, c0, c1, cout, flags, use_res = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+    wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+    got = hip_conv(x0, wt, b, x1, res, flags)
+    exp = ref_conv(x0, wt, b, x1, res, flags)
+    _report(got, exp, F32_OP_TOL, f"conv {shape}")
+
+
+def test_conv3x3_transpose_detecting(dev):
+    """A = delta input, asymmetric weights: catches swapped rows/cols, taps or channel order."""
+    x = np.zeros((1, 8, 32, 16), np.float32)
+    x[0, 2, 5, 3] = 1.0
+    w = np.zeros((3, 3, 16, 64), np.float32)
+    for dy in range(3):
+        for dx in range(3):
+            for o in range(64):
+                w[dy, dx, 3, o] = 100 * dy + 10 * dx + o / 100.0
+    got = hip_conv(x, w, np.zeros(64, np.float32))
+    exp = ref_conv(x, w, np.zeros(64, np.float32))
+    _report(got, exp, 1e-5, "delta conv")
+
+
+def test_conv3x3_fp16_vs_oracle(dev):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 16, 40, 64)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, 64)) * 0.06).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    got = hip_conv(x, w, b, flags=3, prec="fp16", out_f32=True)
+    exp = ref_conv(x, w, b, flags=3)
+    _report(got, exp, 2e-3, "fp16 conv (fp32 accumulate, inputs exactly representable)")
+    assert np.abs(got - exp).max() < 1e-4  # products exact in fp32; only summation order differs
+
+
+def test_conv_in_place_residual_alias(dev):
+    """res may alias out (the schedule runs res_block conv/1 in place)."""
+    L = flib.lib()
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((1, 16, 32, 64)).astype(np.float32)
+    xres = rng.standard_normal((1, 16, 32, 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 64, 64)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    da = torch.from_numpy(a).cuda()
+    dx = torch.from_numpy(xres).cuda()
+    flib.check(L.fisr_op_conv3x3(ctypes.c_void_p(da.data_ptr()), 64, None, 0, _fp(w), _fp(b), 64,
+                                 ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(dx.data_ptr()), 1, 16, 32, 0, 0, 0, _stream()))
+    torch.cuda.synchronize()
+    _report(dx.cpu().numpy(), ref_conv(a, w, b, res=xres), F32_OP_TOL, "in-place residual")
+
+
+def test_op_argument_errors(dev):
+    L = flib.lib()
+    x = torch.zeros((1, 8, 8, 24), device="cuda")
+    w = np.zeros((3, 3, 24, 8), np.float32)
+    b = np.zeros(8, np.float32)
+    rc = L.fisr_op_conv3x3(ctypes.c_void_p(x.data_ptr()), 24, None, 0, _fp(w), _fp(b), 8, None,
+                           ctypes.c_void_p(x.data_ptr()), 1, 8, 8, 0, 0, 0, _stream())
+    assert rc == -1 and b"multiples" in L.fisr_last_error(None)
+
+
+# ----------------------------------------------------------------------------- pool / upsample
+def test_pool_upsample_bit_exact(dev):
+    L = flib.lib()
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 6, 10, 64)).astype(np.float32)
+    dx = torch.from_numpy(x).cuda()
+    po = torch.empty((2, 3, 5, 64), device="cuda")
+    up = torch.empty((2, 12, 20, 64), device="cuda")
+    flib.check(L.fisr_op_maxpool2(ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(po.data_ptr()), 2, 6, 10, 64, 0, _stream()))
+    flib.check(L.fisr_op_upsample2(ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(up.data_ptr()), 2, 6, 10, 64, 0, _stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(po.cpu().numpy(), O.max_pool2(x))
+    assert np.array_equal(up.cpu().numpy(), O.resize_bilinear_x2(x))   # float32 evaluation order kept
+    # fp16 storage
+    xh = torch.from_numpy(x).cuda().half()
+    poh = torch.empty((2, 3, 5, 64), device="cuda", dtype=torch.float16)
+    uph = torch.empty((2, 12, 20, 64), device="cuda", dtype=torch.float16)
+    flib.check(L.fisr_op_maxpool2(ctypes.c_void_p(xh.data_ptr()), ctypes.c_void_p(poh.data_ptr()), 2, 6, 10, 64, 1, _stream()))
+    flib.check(L.fisr_op_upsample2(ctypes.c_void_p(xh.data_ptr()), ctypes.c_void_p(uph.data_ptr()), 2, 6, 10, 64, 1, _stream()))
+    torch.cuda.synchronize()
+    xr = xh.float().cpu().numpy()
+    assert np.array_equal(poh.float().cpu().numpy(), O.max_pool2(xr))
+    assert np.abs(uph.float().cpu().numpy() - O.resize_bilinear_x2(xr)).max() < 2e-3
+
+
+# ----------------------------------------------------------------------------- whole forward
+def test_forward_fp32_vs_golden_32x64(net32, gold_dir):
+    g = np.load(os.path.join(gold_dir, "model_32x64.npz"))
+    l1, l2, l3 = net32.model(torch.from_numpy(g["x"]).cuda())
+    torch.cuda.synchronize()
+    _report(l1.cpu().numpy(), g["l1"], F32_FWD_TOL, "pred_l1")
+    _report(l2.cpu().numpy(), g["l2"], F32_FWD_TOL, "pred_l2")
+    _report(l3.cpu().numpy(), g["l3"], F32_FWD_TOL, "pred_l3")
+
+
+def test_forward_fp32_cfg1_96x96_windows(net32, gold_dir):
+    """cfg1 of BASELINE.json: the three 96x96 windows of the scene1 crop (golden from the oracle)."""
+    g = np.load(os.path.join(gold_dir, "model_96.npz"))
+    for s in range(3):
+        _, _, l3 = net32.model(torch.from_numpy(g["inp"][s:s + 1]).cuda(), want_all=False)
+        _report(l3.cpu().numpy()[0], g["l3"][s].astype(np.float64), F32_FWD_TOL + 1e-6, f"window {s}")
+
+
+def test_forward_batch_and_determinism(net32):
+    rng = np.random.default_rng(21)
+    x = rng.random((2, 32, 64, 29)).astype(np.float32)
+    x[1] = x[0]
+    a = net32.model(torch.from_numpy(x).cuda())[2].cpu().numpy()
+    b = net32.model(torch.from_numpy(x).cuda())[2].cpu().numpy()
+    assert np.array_equal(a, b), "two runs differ"
+    assert np.array_equal(a[0], a[1]), "batch entries with identical input differ"
+
+
+def _psnr_protocol(hip, oracle, rng):
+    """pseudo ground truth = oracle + Gaussian noise at the reference's published
+    quality (37.86 dB FI-SR channels, 48.07 dB SR channels); the HIP path must score within
+    0.02 dB of the oracle against it."""
+    out = []
+    for sl, db in ((slice(0, 3), 37.86), (slice(3, 6), 48.07), (slice(6, 9), 37.86)):
+        sigma = 10 ** (-db / 20)
+        o = np.clip(oracle[..., sl], 0, 1)
+        gt = o + rng.standard_normal(o.shape) * sigma
+        out.append(abs(O.compute_psnr(gt, np.clip(hip[..., sl], 0, 1)) - O.compute_psnr(gt, o)))
+    return out
+
+
+def test_forward_fp16_within_reference_tolerance(net16, gold_dir):
+    g = np.load(os.path.join(gold_dir, "model_96.npz"))
+    rng = np.random.default_rng(8)
+    for s in range(3):
+        _, _, l3 = net16.model(torch.from_numpy(g["inp"][s:s + 1]).cuda(), want_all=False)
+        hip = l3.cpu().numpy()[0].astype(np.float64)
+        ref = g["l3"][s].astype(np.float64)
+        d = _psnr_protocol(hip, ref, rng)
+        rms = float(np.sqrt(np.mean((hip - ref) ** 2)))
+        print(f"fp16 window {s}: rms err {rms:.3e}, max {np.abs(hip - ref).max():.3e}, dPSNR {d}")
+        assert max(d) <= 0.02, d
+        q_h, q_r = O.quantize_u8(np.clip(hip, 0, 1)), O.quantize_u8(np.clip(ref, 0, 1))
+        for f in range(3):
+            assert abs(O.ssim_pil(q_h[..., 3 * f:3 * f + 3], q_r[..., 3 * f:3 * f + 3]) - 1.0) <= 1e-3
+
+
+def test_forward_errors(net32, dev):
+    with pytest.raises(ValueError):
+        net32.model(torch.zeros((1, 48, 64, 29), device="cuda"))
+    with pytest.raises(ValueError):
+        net32.model(torch.zeros((1, 64, 64, 28), device="cuda"))
+    n = FISRnet(device="cuda:0")
+    with pytest.raises(flib.FisrError):
+        n.model(torch.zeros((1, 32, 32, 29), device="cuda"))
+    L = flib.lib()
+    assert L.fisr_finalize_weights(n._ctx, 0) == -3 and b"missing variable" in L.fisr_last_error(n._ctx)
+    n.close()
+
+
+# ----------------------------------------------------------------------------- harness kernels
+def test_warp_vs_oracle_and_golden(net32, gold_dir):
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    for p in range(4):
+        for d, src in ((0, p + 1), (1, p)):
+            got = net32.warp(torch.from_numpy(g["frames"][src]).cuda(), torch.from_numpy(g["flows"][0, 2 * p + d]).cuda())
+            exp = g["warps"][0, 2 * p + d]
+            diff = np.abs(got.cpu().numpy().astype(np.float64) - exp)
+            assert diff.max() <= 3.1e-5, (p, d, diff.max())     # <= 1 ulp of float32 at 255
+            assert (diff > 0).mean() < 1e-3
+    # large flows leaving the frame (BORDER_REPLICATE) and the exact-coordinate mode
+    rng = np.random.default_rng(12)
+    src = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    flow = (rng.standard_normal((37, 53, 2)) * 40).astype(np.float32)
+    for q in (True, False):
+        got = net32.warp(torch.from_numpy(src).cuda(), torch.from_numpy(flow).cuda(), quantized=q).cpu().numpy()
+        exp = O.warp_frame(src, flow, quantized=q)
+        assert np.abs(got.astype(np.float64) - exp).max() <= 3.1e-5, q
+
+
+def test_pack_unpack_stitch_bit_exact(net32, gold_dir):
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    fl = O.merge_seq_dim(g["flows"])
+    wp = O.merge_seq_dim(g["warps"] / np.float32(255.))
+    for s in range(3):
+        frames = [torch.from_numpy(g["frames"][s + k]).cuda() for k in range(3)]
+        flows = [torch.from_numpy(g["flows"][0, 2 * s + k]).cuda() for k in range(4)]
+        warps = [torch.from_numpy(g["warps"][0, 2 * s + k]).cuda() for k in range(4)]
+        got = net32.pack_input(frames, flows, warps, 64, 96).cpu().numpy()
+        img9 = np.concatenate([g["frames"][s + k] for k in range(3)], axis=2)
+        exp = O.assemble_input(img9[:64, :96], fl[0, :64, :96, 4 * s:4 * s + 8], wp[0, :64, :96, 6 * s:6 * s + 12])
+        assert np.array_equal(got, exp.astype(np.float32)), s
+    rng = np.random.default_rng(13)
+    pred = (rng.random((40, 56, 9)) * 1.4 - 0.2).astype(np.float32)
+    yuv, rgb = net32.unpack_output(torch.from_numpy(pred).cuda())
+    q = O.quantize_u8(np.clip(pred.astype(np.float64), 0, 1))
+    assert np.array_equal(yuv.cpu().numpy(), q)
+    for f in range(3):
+        assert np.array_equal(rgb[f].cpu().numpy(), O.yuv_u8_to_rgb_u8(q[..., 3 * f:3 * f + 3])), f
+    gt = rng.integers(0, 256, pred.shape).astype(np.uint8)
+    sse = net32.sse_vs_u8(torch.from_numpy(pred).cuda(), torch.from_numpy(gt))
+    exp_sse = np.sum(np.square(gt.astype(np.float64) / 255. - np.clip(pred.astype(np.float64), 0, 1)))
+    assert abs(sse - exp_sse) <= 1e-9 * exp_sse
+
+
+def test_tiled_forward_vs_oracle(net32, syn_blob):
+    """FISRnet.py:845-883 tile loop (2x2 patches, 32-px halo, trim, stitch) on a 128x192 frame."""
+    rng = np.random.default_rng(14)
+    inp = rng.random((1, 128, 192, 29)).astype(np.float32)
+    inp[..., 9:17] = (inp[..., 9:17] - 0.5) * 0.4
+    got = net32.forward_tiled(torch.from_numpy(inp).cuda(), (2, 2)).cpu().numpy()
+    exp = O.tiled_forward(inp, None, (2, 2), forward=lambda t: C.forward(t, syn_blob, True)[2])
+    _report(np.clip(got, 0, 1), exp, F32_FWD_TOL, "tiled forward")
+    # a tile subset only touches its own rectangle (tile-parallel sharding)
+    part = net32.forward_tiled(torch.from_numpy(inp).cuda(), (2, 2), tiles=[1]).cpu().numpy()
+    assert np.array_equal(part[:128, 192:], got[:128, 192:]) and not part[128:].any() and not part[:128, :192].any()
+
+
+def test_full_size_tile_sparse_golden(net32, gold_dir):
+    """One full reference tile (544x992x29 -> 1088x1984x9, cfg2 of BASELINE.json) against oracle
+    values committed on a sparse grid (tests/golden/model_544x992_sparse.npz)."""
+    path = os.path.join(gold_dir, "model_544x992_sparse.npz")
+    if not os.path.isfile(path):
+        pytest.skip("sparse full-size fixture not generated")
+    g = np.load(path)
+    from tests_support import make_full_size_input
+    x = make_full_size_input(int(g["seed"]), 544, 992)
+    _, _, l3 = net32.model(torch.from_numpy(x).cuda(), want_all=False)
+    got = l3[0, ::int(g["stride"]), ::int(g["stride"]), :].cpu().numpy()
+    _report(got, g["l3_sparse"], F32_FWD_TOL, "544x992 tile sparse grid")

@@ -1,0 +1,172 @@
+"""CPU tests of the oracle: known answers for every op semantic, cross-checks
+against torch-CPU and between the numpy and C restatements, and the fixtures captured from the
+reference's own numpy helpers (tests/golden/ref_utils.npz, made by oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import c_oracle as C
+import fisr_oracle as O
+
+
+# ------------------------------------------------------------- op known answers
+def test_bicubic_down_is_strided_subsample():  # App. B.2
+    x = np.arange(16, dtype=np.float64).reshape(1, 1, 16, 1)
+    assert O.resize_bicubic_down(np.tile(x, (1, 4, 1, 1)), 4)[0, 0, :, 0].tolist() == [0, 4, 8, 12]
+
+
+def test_bilinear_x2_legacy():  # App. B.3
+    x = np.array([0., 2., 4.]).reshape(1, 1, 3, 1)
+    assert O.resize_bilinear_x2(x)[0, 0, :, 0].tolist() == [0, 1, 2, 3, 4, 4]
+    assert O.resize_bilinear_x2(x)[0, 1, :, 0].tolist() == [0, 1, 2, 3, 4, 4]  # last row replicates
+    y = np.array([[1., 3.], [5., 7.]]).reshape(1, 2, 2, 1)
+    out = O.resize_bilinear_x2(y)[0, :, :, 0]
+    assert out.tolist() == [[1, 2, 3, 3], [3, 4, 5, 5], [5, 6, 7, 7], [5, 6, 7, 7]]
+
+
+def test_depth_to_space_dcr():  # App. B.5
+    x = np.arange(256, dtype=np.float64).reshape(1, 1, 1, 256)
+    o = O.depth_to_space2(x)
+    assert o.shape == (1, 2, 2, 64)
+    assert o[0, 0, 0].tolist() == list(range(0, 64))
+    assert o[0, 0, 1].tolist() == list(range(64, 128))
+    assert o[0, 1, 0].tolist() == list(range(128, 192))
+    assert o[0, 1, 1].tolist() == list(range(192, 256))
+
+
+def test_max_pool():
+    x = np.arange(16, dtype=np.float64).reshape(1, 4, 4, 1)
+    assert O.max_pool2(x)[0, :, :, 0].tolist() == [[5, 7], [13, 15]]
+
+
+def test_conv_same_is_cross_correlation():  # App. B.1
+    x = np.zeros((1, 3, 3, 1)); x[0, 1, 1, 0] = 1.0
+    w = np.arange(9, dtype=np.float32).reshape(3, 3, 1, 1)
+    y = O.conv2d(x, w, np.zeros(1, np.float32))[0, :, :, 0]
+    # impulse response of a cross-correlation is the flipped kernel
+    assert y.tolist() == [[8, 7, 6], [5, 4, 3], [2, 1, 0]]
+
+
+def test_conv_and_pool_vs_torch():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 9, 11, 5))
+    w = rng.standard_normal((3, 3, 5, 7)).astype(np.float32)
+    b = rng.standard_normal(7).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2),
+                                     torch.from_numpy(w.astype(np.float64)).permute(3, 2, 0, 1),
+                                     torch.from_numpy(b.astype(np.float64)), padding=1).permute(0, 2, 3, 1).numpy()
+    assert np.abs(O.conv2d(x, w, b) - ref).max() < 1e-12
+    assert np.abs(C.conv3x3(x, w, b) - ref).max() < 1e-12
+    assert np.abs(C.conv3x3(x, w, b, relu_in=True) - O.conv2d(O.relu(x), w, b)).max() < 1e-12
+    x2 = rng.standard_normal((1, 8, 6, 3))
+    refp = torch.nn.functional.max_pool2d(torch.from_numpy(x2).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(O.max_pool2(x2), refp)
+
+
+def test_c_oracle_matches_numpy_twin(syn_weights, syn_blob):
+    rng = np.random.default_rng(3)
+    x = rng.random((1, 32, 32, 29)).astype(np.float32)
+    a = O.model(x, syn_weights)
+    b = C.forward(x, syn_blob, double=True)
+    c = C.forward(x, syn_blob, double=False)
+    for u, v, s in zip(a, b, c):
+        assert np.abs(u - v).max() < 1e-12
+        assert np.abs(u - s).max() < 5e-5
+
+
+def test_golden_model_fixtures(gold_dir, syn_blob):
+    g = np.load(os.path.join(gold_dir, "model_32x64.npz"))
+    l1, l2, l3 = C.forward(g["x"], syn_blob, double=True)
+    assert np.abs(l1 - g["l1"]).max() < 1e-12
+    assert np.abs(l2 - g["l2"]).max() < 1e-12
+    assert np.abs(l3 - g["l3"]).max() < 1e-12
+    g96 = np.load(os.path.join(gold_dir, "model_96.npz"))
+    out = C.forward(g96["inp"][:1], syn_blob, double=True)[2]
+    assert np.abs(out[0] - g96["l3"][0]).max() < 1e-6
+
+
+# ------------------------------------------------------------- pinned to the reference's helpers
+@pytest.fixture(scope="module")
+def ref(gold_dir):
+    return np.load(os.path.join(gold_dir, "ref_utils.npz"))
+
+
+def test_tiling_vs_reference(ref):
+    for row in ref["tiling"]:
+        h, w, nh, nw, p, hl, hh, wl, wh, ah, aw, th, tw = (int(v) for v in row)
+        pH, pW = p // nw, p % nw
+        assert O.get_hw_boundary(32, h, w, pH, h // nh, pW, w // nw) == (hl, hh, wl, wh, ah, aw)
+        t = np.zeros((1, (hh - hl) * 2, (wh - wl) * 2, 1), np.int8)
+        assert O.trim_patch_boundary(t, 32, h, w, pH, h // nh, pW, w // nw, 2).shape[1:3] == (th, tw)
+    # SURVEY 8c known answers for the default 1080p config
+    assert O.get_hw_boundary(32, 1024, 1920, 1, 512, 1, 960) == (480, 1024, 928, 1920, 32, 32)
+    for p in range(4):
+        b = O.get_hw_boundary(32, 128, 192, p // 2, 64, p % 2, 96)
+        th, tw = (b[1] - b[0]) * 2, (b[3] - b[2]) * 2
+        t = np.arange(th * tw, dtype=np.int64).reshape(1, th, tw, 1)
+        assert np.array_equal(O.trim_patch_boundary(t, 32, 128, 192, p // 2, 64, p % 2, 96, 2), ref[f"trim_{p}"])
+
+
+def test_seq_dim_vs_reference(ref):
+    assert np.array_equal(O.merge_seq_dim(ref["seq_in"]), ref["merge_seq"])
+    assert np.array_equal(O.split_seq_dim(ref["merge_seq"]), ref["split_seq"])
+    m = O.merge_seq_dim(np.arange(2 * 3 * 2 * 2 * 3).reshape(2, 3, 2, 2, 3))
+    assert m[0, 0, 0].tolist() == [0, 1, 2, 12, 13, 14, 24, 25, 26]
+
+
+def test_colour_vs_reference(ref):
+    assert np.array_equal(O.yuv2rgb_matlab(ref["yuv_u8"]), ref["yuv2rgb_matlab"])
+    assert np.array_equal(O.yuv2rgb_matlab(ref["yuv_f32"]), ref["warp_yuv2rgb"])
+    assert np.array_equal(O.rgb2yuv(ref["rgb_f64"]), ref["warp_rgb2yuv"])
+    k = O.yuv2rgb_matlab(np.array([[[128, 128, 128], [16, 128, 128], [235, 128, 128]]], np.uint8))
+    assert abs(k[0, 0, 0] - 130.4109576) < 1e-6 and k[0, 1, 0] == 0 and abs(k[0, 2, 0] - 254.99999745) < 1e-6
+
+
+def test_psnr_vs_reference(ref):
+    assert O.compute_psnr(ref["psnr_a"], ref["psnr_b"], 1.0) == float(ref["psnr"])
+    assert abs(O.compute_psnr(np.zeros(4), np.full(4, 0.1), 1.0) - 20.0) < 1e-12
+
+
+def test_flo_vs_reference(ref, tmp_path):
+    p = str(tmp_path / "t.flo")
+    O.write_flo5(p, ref["flo_in"])
+    with open(p, "rb") as f:
+        assert np.array_equal(np.frombuffer(f.read(), np.uint8), ref["flo_bytes"])
+    assert np.array_equal(O.read_flo5(p), ref["flo_read_by_ref"])
+    with open(p, "r+b") as f:
+        f.write(b"\0\0\0\0")
+    with pytest.raises(ValueError):
+        O.read_flo5(p)
+
+
+# ------------------------------------------------------------- warp restatement
+def test_remap_identity_and_border():
+    rng = np.random.default_rng(1)
+    src = rng.random((5, 7, 3)) * 255
+    gx, gy = np.meshgrid(np.arange(7, dtype=np.float32), np.arange(5, dtype=np.float32))
+    assert np.array_equal(O.remap_linear_replicate(src, gx, gy), src)
+    # half-pixel shift = average of neighbours; beyond the border replicates the edge
+    out = O.remap_linear_replicate(src, gx + np.float32(0.5), gy)
+    assert np.allclose(out[:, :-1], 0.5 * (src[:, :-1] + src[:, 1:]))
+    assert np.allclose(out[:, -1], src[:, -1])
+    far = O.remap_linear_replicate(src, gx - 100, gy + 100)
+    assert np.allclose(far, np.broadcast_to(src[-1:, :1], src.shape))
+    # 1/32-px quantisation: a shift of 1/64 rounds half-to-even to 0
+    q = O.remap_linear_replicate(src, gx + np.float32(1 / 64), gy)
+    assert np.array_equal(q, src)
+
+
+def test_warp_fixture_reproduces(gold_dir):
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    w0 = O.warp_frame(g["frames"][1], g["flows"][0, 0])
+    assert np.array_equal(w0, g["warps"][0, 0])
+    assert w0.dtype == np.float32 and w0.min() >= 0 and w0.max() <= 255
+
+
+def test_ssim_identity():
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (21, 28, 3)).astype(np.uint8)
+    assert abs(O.ssim_pil(a, a) - 1.0) < 1e-12
+    assert O.ssim_pil(a, 255 - a) < 0.5

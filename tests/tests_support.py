@@ -1,0 +1,13 @@
+"""Shared helpers for the tests (seeded synthetic inputs that can be regenerated on any box)."""
+import numpy as np
+
+
+def make_full_size_input(seed: int, h: int, w: int, n: int = 1) -> np.ndarray:
+    """[n,h,w,29] float32: 21 image-like channels in [0,1] (coarse structure + fine noise) and
+    8 flow channels in [-0.2, 0.2], laid out as FISRnet.py:843 (9 img, 8 flow, 12 warp)."""
+    rng = np.random.default_rng(seed)
+    coarse = rng.random((n, h // 16 + 1, w // 16 + 1, 29)).astype(np.float32)
+    x = np.repeat(np.repeat(coarse, 16, axis=1), 16, axis=2)[:, :h, :w, :]
+    x = 0.75 * x + 0.25 * rng.random((n, h, w, 29), dtype=np.float32)
+    x[..., 9:17] = (x[..., 9:17] - 0.5) * 0.4
+    return np.ascontiguousarray(x, np.float32)
