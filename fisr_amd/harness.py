@@ -1,0 +1,196 @@
+"""The reference's evaluation / video drivers on top of the HIP hot path.
+
+  run_test            <-> FISRnet.test            (FISRnet.py:746-935)
+  run_fisr_for_video  <-> FISRnet.FISR_for_video  (FISRnet.py:937-1084)
+  warp_img            <-> FISR_for_video_Warp_Img (FISR_tfoptflow/FISR_for_video_warp_img_with_flo.py:97-151)
+
+Everything between "frames are on the GPU" and "uint8 predictions come back" runs in
+libfisr_hip.so kernels (pack -> tiled forward -> stitch -> clip/quantise/colour -> SSE).  PNG
+decoding/encoding and the SSIM statistic stay on the host like in the reference.
+
+Deliberate deviations from the reference: file lists are sorted
+(`glob.glob` is unsorted at FISRnet.py:953), and the final timing print of FISR_for_video uses
+FISR_test_patch (the reference uses test_patch, FISRnet.py:1084).
+"""
+from __future__ import annotations
+
+import glob
+import math
+import os
+import re
+import time
+
+import numpy as np
+
+from . import io as fio
+from . import tiling
+
+
+def _natural_key(p):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]
+
+
+def sorted_pngs(folder):
+    return sorted(glob.glob(os.path.join(folder, "*.png")), key=_natural_key)
+
+
+def ssim_pil(a_u8: np.ndarray, b_u8: np.ndarray, tile: int = 7) -> float:
+    """Host restatement of SSIM_PIL.compare_ssim (requirements.txt:13; call site FISRnet.py:890-891):
+    non-overlapping 7x7 tiles per channel, C1=(0.01*255)^2, C2=(0.03*255)^2, unbiased variance,
+    mean over tiles and channels.  SSIM_PIL is not in the reference tree: parity unpinned."""
+    a = np.asarray(a_u8, np.float64)
+    b = np.asarray(b_u8, np.float64)
+    h, w, c = a.shape
+    th, tw = h // tile, w // tile
+    a = a[:th * tile, :tw * tile].reshape(th, tile, tw, tile, c)
+    b = b[:th * tile, :tw * tile].reshape(th, tile, tw, tile, c)
+    n = tile * tile
+    ma = a.mean(axis=(1, 3))
+    mb = b.mean(axis=(1, 3))
+    da = a - ma[:, None, :, None]
+    db = b - mb[:, None, :, None]
+    va = (da * da).sum(axis=(1, 3)) / (n - 1)
+    vb = (db * db).sum(axis=(1, 3)) / (n - 1)
+    cov = (da * db).sum(axis=(1, 3)) / (n - 1)
+    c1, c2 = (255 * 0.01) ** 2, (255 * 0.03) ** 2
+    s = ((2 * ma * mb + c1) * (2 * cov + c2)) / ((ma * ma + mb * mb + c1) * (va + vb + c2))
+    return float(s.mean())
+
+
+def _psnr_from_sse(sse: float, count: int, peak: float = 1.0) -> float:
+    """utils.py:23-26."""
+    return 10 * math.log10(peak * peak / (sse / count))
+
+
+def warp_img(net, frame_paths, flow, out_path=None):
+    """frames (sorted PNG paths, YUV) + flow [num_fr-1, 2, h, w, 2] -> pred [num_fr-1, 2, h, w, 3]
+    float32 0..255, pair fr: [0] = warp(frame fr+1, 0.5*flow[fr,0]) ("1 -> 2"), [1] = warp(frame fr,
+    0.5*flow[fr,1]) ("2 -> 1") -- warp script :112-129."""
+    import torch
+    num_pairs = flow.shape[0]
+    h, w = flow.shape[2:4]
+    pred = np.zeros((num_pairs, 2, h, w, 3), np.float32)
+    frames = [torch.from_numpy(fio.read_png(p)[:h, :w]).to(net.device) for p in frame_paths[:num_pairs + 1]]
+    for fr in range(num_pairs):
+        f01 = torch.from_numpy(np.ascontiguousarray(flow[fr, 0])).to(net.device)
+        f10 = torch.from_numpy(np.ascontiguousarray(flow[fr, 1])).to(net.device)
+        pred[fr, 0] = net.warp(frames[fr + 1], f01).cpu().numpy()
+        pred[fr, 1] = net.warp(frames[fr], f10).cpu().numpy()
+    if out_path:
+        fio.write_warp_file(out_path, pred)
+    return pred
+
+
+def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_test_in_seq, H, W, num_patch):
+    """Device tensors for one 3-frame window (FISRnet.py:803-843)."""
+    import torch
+    h, w = tiling.crop_hw(H, W, num_patch)
+    frames = [torch.from_numpy(fio.read_png(frame_paths[scene_i * n_test_in_seq + sample_i + k])).to(net.device)
+              for k in range(3)]
+    # flow[scene, :, :, 4*s : 4*s+8] = flow sequence entries 2s..2s+3; warp likewise (6s..6s+12)
+    flows = [torch.from_numpy(np.ascontiguousarray(flow_seq[scene_i, 2 * sample_i + k])).to(net.device) for k in range(4)]
+    warps = [torch.from_numpy(np.ascontiguousarray(warp_seq[scene_i, 2 * sample_i + k])).to(net.device) for k in range(4)]
+    return net.pack_input(frames, flows, warps, h, w), h, w
+
+
+def run_test(net):
+    """`--phase test`.  Returns a dict with the averages the reference prints."""
+    import torch
+    ok, _ = (True, 0) if net._finalized else net.load(net.checkpoint_dir)
+    if not ok:
+        raise FileNotFoundError(f"no checkpoint under {os.path.join(net.checkpoint_dir, net.model_dir)}")
+    data_paths = sorted_pngs(net.test_data_path)
+    label_paths = sorted_pngs(net.test_label_path)
+    print(" Start to read flow data (test).")
+    flow = fio.read_flo_file_5dim(net.test_flow_data_path)        # [N_scenes, 8, H, W, 2]
+    print(" Start to read warped data (test).")
+    warp = fio.read_warp_file(net.test_warped_data_path, "pred")  # [N_scenes, 8, H, W, 3] 0..255
+    num_patch = tuple(net.test_patch)
+    H, W = net.test_input_size
+    sf = net.scale_factor
+    n_in_seq, n_test_in_seq = 3, 5
+    n_gt_seq, n_test_label_seq = 3, 7
+    test_img_dir = os.path.join(net.test_img_dir, net.model_dir)
+    os.makedirs(test_img_dir, exist_ok=True)
+    fisr_psnr, sr_psnr, fisr_ssim, sr_ssim = [], [], [], []
+    net.inf_time = []
+    start = time.time()
+    n_scenes = len(data_paths) // n_test_in_seq
+    for scene_i in range(n_scenes):
+        for sample_i in range(n_test_in_seq - n_in_seq + 1):
+            inp, h, w = _window_inputs(net, data_paths, flow, warp, scene_i, sample_i, n_test_in_seq, H, W, num_patch)
+            full = net.forward_tiled(inp, num_patch, timed=True)
+            yuv_u8, rgb_u8 = net.unpack_output(full)
+            have_gt = len(label_paths) >= (scene_i + 1) * n_test_label_seq
+            psnr, ssim = [float("nan")] * 3, [float("nan")] * 3
+            yuv_host = yuv_u8.cpu().numpy()
+            for seq_i in range(n_gt_seq):
+                name = (os.path.basename(label_paths[scene_i * n_test_label_seq + sample_i * 2 + seq_i])[3:]
+                        if have_gt else f"s{scene_i}_w{sample_i}_f{seq_i}.png")
+                if have_gt:
+                    gt = fio.read_png(label_paths[scene_i * n_test_label_seq + sample_i * 2 + seq_i])[:h * sf, :w * sf]
+                    gt_d = torch.from_numpy(np.ascontiguousarray(gt)).to(net.device)
+                    sse = net.sse_vs_u8(full[:, :, 3 * seq_i:3 * seq_i + 3].contiguous(), gt_d)
+                    psnr[seq_i] = _psnr_from_sse(sse, gt.size)
+                    # FISRnet.py:890-891: both sides as uint8(x*255) (GT: uint8 -> /255 -> *255 truncation)
+                    gt_q = (np.clip(gt.astype(np.float64) / 255., 0, 1) * 255).astype("uint8")
+                    ssim[seq_i] = ssim_pil(yuv_host[:, :, 3 * seq_i:3 * seq_i + 3], gt_q)
+                fio.write_png(os.path.join(test_img_dir, "pred_{}".format(name)), rgb_u8[seq_i].cpu().numpy())
+            print(" <Test> [%4d/%4d]-th image, scene: %2d-%d, time: %4.4f(minutes), test_PSNR: fr1 (FI-SR) %.8f[dB], "
+                  "fr2 (SR) %.8f[dB], fr3 (FI-SR) %.8f[dB]  " % (scene_i * 3 + sample_i, n_scenes * 3, scene_i, sample_i,
+                                                                 (time.time() - start) / 60, psnr[0], psnr[1], psnr[2]))
+            fisr_psnr.append(psnr[0]); sr_psnr.append(psnr[1])
+            fisr_ssim.append(ssim[0]); sr_ssim.append(ssim[1])
+            if sample_i == 2:                                     # FISRnet.py:918-920
+                fisr_psnr.append(psnr[2]); fisr_ssim.append(ssim[2])
+    res = dict(FISR_PSNR=float(np.mean(fisr_psnr)), SR_PSNR=float(np.mean(sr_psnr)),
+               FISR_SSIM=float(np.mean(fisr_ssim)), SR_SSIM=float(np.mean(sr_ssim)),
+               inference_time_per_frame=float(np.mean(net.inf_time)) * num_patch[0] * num_patch[1])
+    print("######### Test (average) test_PSNR: FISR %.8f[dB], SR %.8f[dB]  #########" % (res["FISR_PSNR"], res["SR_PSNR"]))
+    print("######### Test (average) test_SSIM: FISR %.8f, SR %.8f #########" % (res["FISR_SSIM"], res["SR_SSIM"]))
+    print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % res["inference_time_per_frame"])
+    return res
+
+
+def run_fisr_for_video(net, flow_file_name, warp_file_name):
+    """`--phase FISR_for_video`: writes <frame_folder>/FISR_frames/pred_{k}.png (RGB) and
+    pred_YUV_{k}.png, k = 2*fr + seq_i, later windows overwrite earlier (FISRnet.py:1064-1077)."""
+    import torch
+    ok, _ = (True, 0) if net._finalized else net.load(net.checkpoint_dir)
+    if not ok:
+        raise FileNotFoundError(f"no checkpoint under {os.path.join(net.checkpoint_dir, net.model_dir)}")
+    paths = sorted_pngs(net.frame_folder_path)
+    num_fr = net.frame_num
+    out_dir = os.path.join(net.frame_folder_path, "FISR_frames")
+    os.makedirs(out_dir, exist_ok=True)
+    flow = fio.read_flo_file_5dim(flow_file_name) if isinstance(flow_file_name, str) else np.asarray(flow_file_name)
+    warp = fio.read_warp_file(warp_file_name, "pred") if isinstance(warp_file_name, str) else np.asarray(warp_file_name)
+    # [N, 2, ...] pairs -> windows of two consecutive pairs (FISRnet.py:965-966, 972-973)
+    flow = np.concatenate((flow[0:num_fr - 2], flow[1:num_fr - 1]), axis=1)
+    warp = np.concatenate((warp[0:num_fr - 2], warp[1:num_fr - 1]), axis=1)
+    num_patch = tuple(net.FISR_test_patch)
+    H, W = net.FISR_input_size
+    sf = net.scale_factor
+    digits = math.ceil(math.log10(2 * (num_fr - 1)))
+    net.inf_time = []
+    start = time.time()
+    written = []
+    for fr in range(num_fr - 2):
+        h, w = tiling.crop_hw(H, W, num_patch)
+        frames = [torch.from_numpy(fio.read_png(paths[fr + k])).to(net.device) for k in range(3)]
+        flows = [torch.from_numpy(np.ascontiguousarray(flow[fr, k])).to(net.device) for k in range(4)]
+        warps = [torch.from_numpy(np.ascontiguousarray(warp[fr, k])).to(net.device) for k in range(4)]
+        inp = net.pack_input(frames, flows, warps, h, w)
+        full = net.forward_tiled(inp, num_patch, timed=True)
+        yuv_u8, rgb_u8 = net.unpack_output(full)
+        yuv_host = yuv_u8.cpu().numpy()
+        for seq_i in range(3):
+            k = str(fr * 2 + seq_i).zfill(digits)
+            fio.write_png(os.path.join(out_dir, f"pred_{k}.png"), rgb_u8[seq_i].cpu().numpy())
+            fio.write_png(os.path.join(out_dir, f"pred_YUV_{k}.png"), yuv_host[:, :, 3 * seq_i:3 * seq_i + 3])
+            written.append(k)
+        print(" <FISR processing> [%4d/%4d]-th input multiple data sample (stride1), time: %4.4f(minutes)  "
+              % (fr + 1, num_fr - 2, (time.time() - start) / 60))
+    per_frame = float(np.mean(net.inf_time)) * num_patch[0] * num_patch[1]
+    print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % per_frame)
+    return dict(frames=sorted(set(written)), out_dir=out_dir, inference_time_per_frame=per_frame)
