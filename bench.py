@@ -51,6 +51,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")
+    ap.add_argument("--batch", default="stack", choices=["stack", "window", "tile"],
+                    help="how many independent tiles go through one forward: the whole 5-frame stack "
+                         "(3 windows x 4 tiles), one window (4 tiles) or one tile (the reference's schedule)")
+    ap.add_argument("--layer-profile", default=None, help="write a per-layer timing table (JSON) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -87,14 +91,22 @@ def main():
     for p in range(4):
         warps.append(net.warp(frames[p + 1], flows[2 * p]))
         warps.append(net.warp(frames[p], flows[2 * p + 1]))
-    full = torch.zeros((h * 2, w * 2, 9), dtype=torch.float32, device=dev)
+    full = torch.zeros((3, h * 2, w * 2, 9), dtype=torch.float32, device=dev)
 
     def step():
         outs = None
-        for s in range(3):                                   # FISRnet.py:799 sliding windows
-            inp = net.pack_input(frames[s:s + 3], flows[2 * s:2 * s + 4], warps[2 * s:2 * s + 4], h, w)
-            net.forward_tiled(inp, patch, full=full)         # FISRnet.py:847-880
-            outs = net.unpack_output(full)                   # FISRnet.py:883, 903-909
+        if args.batch == "stack":
+            # the 3 sliding windows (FISRnet.py:799) x 4 tiles (:847) are independent -> one batched forward
+            inp = torch.cat([net.pack_input(frames[s:s + 3], flows[2 * s:2 * s + 4], warps[2 * s:2 * s + 4], h, w)
+                             for s in range(3)], dim=0)
+            net.forward_tiled(inp, patch, full=full)
+            for s in range(3):
+                outs = net.unpack_output(full[s])            # FISRnet.py:883, 903-909
+        else:
+            for s in range(3):
+                inp = net.pack_input(frames[s:s + 3], flows[2 * s:2 * s + 4], warps[2 * s:2 * s + 4], h, w)
+                net.forward_tiled(inp, patch, full=full[s:s + 1], batch_tiles=(args.batch == "window"))
+                outs = net.unpack_output(full[s])
         return outs
 
     def sync():
@@ -129,6 +141,18 @@ def main():
         torch.cuda.synchronize(dev)
         prof = net.profile_read()
         net.profile(False)
+        if args.layer_profile and rank == 0:
+            net.profile(2)
+            step()
+            torch.cuda.synchronize(dev)
+            layers = net.profile_read()
+            net.profile(False)
+            for p_ in layers:
+                p_["tflops"] = round(p_["flops"] / (p_["ms"] * 1e-3) / 1e12, 2) if p_["ms"] > 0 and p_["flops"] else 0.0
+                p_["us_per_launch"] = round(p_["ms"] * 1e3 / max(1, p_["launches"]), 1)
+            os.makedirs(os.path.dirname(os.path.abspath(args.layer_profile)), exist_ok=True)
+            with open(args.layer_profile, "w") as f:
+                json.dump(sorted(layers, key=lambda q: -q["ms"]), f, indent=1)
         convs = [p for p in prof if p["name"].startswith("conv3x3") and p["launches"]]
         if convs:
             dom = max(convs, key=lambda p: p["ms"])
@@ -175,6 +199,7 @@ def main():
                                    f"{tiles[0].in_h}x{tiles[0].in_w}x29 (32-px halo) -> 7 unique 2048x3840 frames; "
                                    "pre-made flow+warp resident in HBM; synthetic seeded weights",
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+                       "tiles_per_forward": {"stack": 3 * len(tiles), "window": len(tiles), "tile": 1}[args.batch],
                        "tflop_per_step": round(flop_per_stack / 1e12, 3),
                        "raw_fps": round(world * 9 * args.steps / elapsed, 3),
                        "forwards_per_s": round(world * 3 * args.steps / elapsed, 3),

@@ -99,7 +99,7 @@ template <typename T, int NT> constexpr size_t conv_lds_bytes() {
 }
 
 template <typename T, int NT, bool OUT_F32>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const ConvArgs p) {
   typedef Prec<T> P;
   typedef typename P::Frag Frag;
   constexpr int CC = P::CC;
@@ -133,42 +133,73 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_mfma_kernel(const ConvAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
+  // ---- loader geometry (identical for every K chunk) ----
+  // A 16-byte unit u = tid + i*256 covers pixel (u>>2) of the halo tile, slot (u&3) of its
+  // 64-byte chunk record; slot and the pixel's low part are per-thread constants.
+  constexpr int NIN = (HALO_PIX * 4 + CONV_THREADS - 1) / CONV_THREADS;  // 6
+  constexpr int NWT = (9 * BN * 4 + CONV_THREADS - 1) / CONV_THREADS;    // 9 (BN=64) / 5 (BN=32)
+  const int slot = tid & 3;
+  int in_pix[NIN];  // linear pixel index in the source image, -1 = zero padding / no unit
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int pix = (tid >> 2) + i * (CONV_THREADS / 4);
+    const int py = pix / HALO_W, px = pix - py * HALO_W;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool ok = pix < HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    in_pix[i] = ok ? (nb * p.H + gy) * p.W + gx : -1;
+  }
+  uint4 rin[NIN], rwt[NWT];
+  const char* a_base = s_in + ((wave * 2) * HALO_W + li) * REC_BYTES + kh * 16;
+  const char* b_base = s_w + li * REC_BYTES + kh * 16;
   const int nchunks = (p.C0 + p.C1) / CC;
-  for (int kc = 0; kc < nchunks; ++kc) {
-    // ---- stage the halo tile of this channel chunk and its weights in LDS ----
-    const T* src;
-    int csrc, coff;
-    {
-      const int c0 = kc * CC;
+
+  // Software pipeline: iteration kc writes chunk kc (already in registers) to LDS, issues the
+  // global loads of chunk kc+1 (they stay in flight during the MFMAs), then computes chunk kc.
+  // Iteration -1 only issues the first loads.
+  for (int kc = -1; kc < nchunks; ++kc) {
+    if (kc >= 0) {
+      __syncthreads();  // every wave is done reading the previous chunk from LDS
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        const int pix = (tid >> 2) + i * (CONV_THREADS / 4);
+        if (i < NIN - 1 || pix < HALO_PIX)
+          *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + slot * 16) = p.relu_in ? P::relu16(rin[i]) : rin[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NWT; ++i) {
+        const int r = (tid >> 2) + i * (CONV_THREADS / 4);
+        if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
+          *reinterpret_cast<uint4*>(s_w + r * REC_BYTES + slot * 16) = rwt[i];
+      }
+      __syncthreads();
+    }
+    if (kc + 1 < nchunks) {  // global -> registers for the next chunk
+      const T* src;
+      int csrc, coff;
+      const int c0 = (kc + 1) * CC;
       if (c0 < p.C0) { src = (const T*)p.in0; csrc = p.C0; coff = c0; }
       else           { src = (const T*)p.in1; csrc = p.C1; coff = c0 - p.C0; }
-    }
-    __syncthreads();  // previous chunk's LDS reads are done
-    for (int u = tid; u < HALO_PIX * 4; u += CONV_THREADS) {
-      const int pix = u >> 2, slot = u & 3;
-      const int py = pix / HALO_W, px = pix - py * HALO_W;
-      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-        v = *reinterpret_cast<const uint4*>(src + ((size_t)(nb * p.H + gy) * p.W + gx) * csrc + coff + slot * EPU);
-        if (p.relu_in) v = P::relu16(v);
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (in_pix[i] >= 0)
+          v = *reinterpret_cast<const uint4*>(src + (size_t)in_pix[i] * csrc + coff + slot * EPU);
+        rin[i] = v;
       }
-      *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + slot * 16) = v;
-    }
-    {
-      const T* wsrc = (const T*)p.wpk + (size_t)kc * 9 * p.CoutPad * CC;
-      for (int u = tid; u < 9 * BN * 4; u += CONV_THREADS) {
-        const int slot = u & 3, r = u >> 2;  // r = tap*BN + n
+      const T* wsrc = (const T*)p.wpk + (size_t)(kc + 1) * 9 * p.CoutPad * CC;
+#pragma unroll
+      for (int i = 0; i < NWT; ++i) {
+        const int r = (tid >> 2) + i * (CONV_THREADS / 4);  // r = tap*BN + n
         const int tap = r / BN, n = r - tap * BN;
-        const uint4 v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)tap * p.CoutPad + n0 + n) * CC + slot * EPU);
-        *reinterpret_cast<uint4*>(s_w + r * REC_BYTES + slot * 16) = v;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
+          v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)tap * p.CoutPad + n0 + n) * CC + slot * EPU);
+        rwt[i] = v;
       }
     }
-    __syncthreads();
+    if (kc < 0) continue;
 
     // ---- 9 taps x 2 k-groups of MFMA on the staged chunk ----
-    const char* a_base = s_in + ((wave * 2) * HALO_W + li) * REC_BYTES + kh * 16;
-    const char* b_base = s_w + li * REC_BYTES + kh * 16;
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll

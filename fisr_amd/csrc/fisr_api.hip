@@ -50,6 +50,7 @@ struct fisr_ctx {
   std::string err;
   // profiling
   bool prof = false;
+  int prof_mode = 0;  // 1: per kernel class, 2: per layer (name + shape)
   std::vector<std::string> prof_names;
   std::vector<ProfEntry> prof_entries;
   std::vector<hipEvent_t> ev_pool;
@@ -318,7 +319,13 @@ struct Runner {
     const double px = (double)n * h * w;
     char cls[96];
     snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", sizeof(T) == 4 ? "f32" : "f16", cw.nt, out_f32 ? "_f32out" : "");
-    ProfScope ps(ctx, st, cls, 2.0 * 9 * cw.ci * cw.co * px,
+    std::string cname(cls);
+    if (ctx->prof_mode == 2) {
+      char shp[64];
+      snprintf(shp, sizeof shp, " %dx%dx%d %d->%d", n, h, w, c0 + c1, cw.co);
+      cname = name.substr(name.find("level_")) + shp;
+    }
+    ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
                  px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
     check(launch_conv<T>(a, cw.nt, out_f32, st), name.c_str());
   }
@@ -574,6 +581,7 @@ int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out
 int fisr_profile_enable(fisr_ctx* ctx, int on) {
   if (!ctx) return FISR_EINVAL;
   ctx->prof = on != 0;
+  ctx->prof_mode = on;
   return 0;
 }
 int fisr_profile_reset(fisr_ctx* ctx) {

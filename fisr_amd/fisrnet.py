@@ -152,7 +152,8 @@ class FISRnet:
         return l1, l2, l3
 
     # ------------------------------------------------------------------ profiling hooks
-    def profile(self, on: bool) -> None:
+    def profile(self, on) -> None:
+        """on: 0/False off, 1/True per kernel class, 2 per layer."""
         self._L.fisr_profile_enable(self._ctx, int(on))
         self._L.fisr_profile_reset(self._ctx)
 
@@ -214,30 +215,43 @@ class FISRnet:
 
     # ------------------------------------------------------------------ tiled forward (FISRnet.py:845-883)
     def forward_tiled(self, inp, num_patch: Tuple[int, int] = (2, 2), tiles: Optional[Sequence[int]] = None,
-                      full=None, timed: bool = False):
-        """inp [1,h,w,29] on the GPU -> full prediction [h*2,w*2,9] float32 (not clipped; the
-        clip of FISRnet.py:883 is applied by unpack_output / sse_vs_u8).  `tiles` restricts the
-        work to a subset of tile indices (tile-parallel sharding, see fisr_amd/dist.py)."""
+                      full=None, timed: bool = False, batch_tiles: bool = True):
+        """inp [B,h,w,29] on the GPU (B windows of equal size) -> full prediction [B,h*2,w*2,9]
+        float32 ([h*2,w*2,9] when B == 1; not clipped -- the clip of FISRnet.py:883 is applied by
+        unpack_output / sse_vs_u8).  `tiles` restricts the work to a subset of tile indices
+        (tile-parallel sharding, see fisr_amd/dist.py).
+
+        The reference runs the tiles one sess.run at a time (FISRnet.py:847-872).  Tiles are
+        independent, so equal-shaped tiles (all four in the default 2x2 plan) go through ONE
+        batched forward here: bit-identical results, but every conv launch gets 4x (12x for a
+        whole 5-frame stack) more workgroups, which is what fills 256 CUs on the deep, small
+        layers.  batch_tiles=False restores the one-tile-per-forward schedule."""
         torch = _torch()
-        _, h, w, _ = inp.shape
+        B, h, w, _ = inp.shape
         sf = self.scale_factor
-        plan = tiling.plan_tiles(h, w, tuple(num_patch), sf)
+        plan = [t for t in tiling.plan_tiles(h, w, tuple(num_patch), sf) if tiles is None or t.index in tiles]
+        squeeze = full is None and B == 1
         if full is None:
-            full = torch.zeros((h * sf, w * sf, 9), dtype=torch.float32, device=self.device)
+            full = torch.zeros((B, h * sf, w * sf, 9), dtype=torch.float32, device=self.device)
+        fullv = full if full.dim() == 4 else full.unsqueeze(0)
+        groups = {}
         for t in plan:
-            if tiles is not None and t.index not in tiles:
-                continue
-            simg = inp[:, t.h_lo:t.h_hi, t.w_lo:t.w_hi, :].contiguous()
+            groups.setdefault((t.in_h, t.in_w) if batch_tiles else t.index, []).append(t)
+        for grp in groups.values():
+            simg = torch.cat([inp[:, t.h_lo:t.h_hi, t.w_lo:t.w_hi, :] for t in grp], dim=0).contiguous()
             if timed:
                 torch.cuda.synchronize(self.device)
                 t0 = time.time()
             _, _, pred = self.model(simg, sf, want_all=False)
             if timed:
                 torch.cuda.synchronize(self.device)
-                self.inf_time.append(time.time() - t0)
-            _lib.check(self._L.fisr_stitch(_ptr(pred), t.in_h * sf, t.in_w * sf, t.src_y, t.src_x, t.out_h, t.out_w,
-                                           _ptr(full), h * sf, w * sf, t.dst_y, t.dst_x, _stream(self.device)))
-        return full
+                self.inf_time.extend([(time.time() - t0) / (len(grp) * B)] * (len(grp) * B))
+            for gi, t in enumerate(grp):
+                for b in range(B):
+                    _lib.check(self._L.fisr_stitch(_ptr(pred[gi * B + b]), t.in_h * sf, t.in_w * sf, t.src_y, t.src_x,
+                                                   t.out_h, t.out_w, _ptr(fullv[b]), h * sf, w * sf, t.dst_y, t.dst_x,
+                                                   _stream(self.device)))
+        return full[0] if squeeze else full
 
     # ------------------------------------------------------------------ harnesses
     def test(self):
