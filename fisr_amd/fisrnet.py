@@ -158,7 +158,7 @@ class FISRnet:
         self._L.fisr_profile_reset(self._ctx)
 
     def profile_read(self):
-        cap = 64
+        cap = 1024
         names = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_double * cap)()
         cnt = (ctypes.c_int64 * cap)()
