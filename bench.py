@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 2 644 164 MAC)
-PEAK = {"fp32": 157.3, "fp16": 2500.0}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+PEAK = {"fp32": 157.3, "fp16": 2500.0, "bf16x3": 2500.0}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 UNIQUE_PER_STACK = 7                # 3 windows x 3 frames, overlaps counted once (FISRnet.py:913-920)
 
 
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16x3"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")
     ap.add_argument("--batch", default="stack", choices=["stack", "window", "tile"],
                     help="how many independent tiles go through one forward: the whole 5-frame stack "
@@ -163,6 +163,7 @@ def main():
                         "frac": round(ach / PEAK[args.precision], 4), "traffic": None,
                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                         "launches": int(dom["launches"]),
+                        "mfma_issue_frac": round((3 if args.precision == "bf16x3" else 1) * ach / PEAK[args.precision], 4),
                         "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
                         "all_conv_tflops": round(sum(p["flops"] for p in convs) / (sum(p["ms"] for p in convs) * 1e-3) / 1e12, 2),
                         "kernels": {p["name"]: {"ms": round(p["ms"], 3), "launches": int(p["launches"])} for p in prof}}
@@ -194,7 +195,8 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16 (f32 accumulate)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "fp16": "f16 (f32 accumulate)",
+                      "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"cfg2: 5-frame 1080x1920 stack -> 3 windows x {patch[0]}x{patch[1]} tiles of "
                                    f"{tiles[0].in_h}x{tiles[0].in_w}x29 (32-px halo) -> 7 unique 2048x3840 frames; "
                                    "pre-made flow+warp resident in HBM; synthetic seeded weights",

@@ -13,16 +13,29 @@
 // Workgroup = 256 threads = 4 wave64; output tile = 8 rows x 32 cols x BN channels
 // (BN = 32*NT).  Each wave owns 2 image rows (2 M-subtiles of 32 pixels) x NT
 // N-subtiles of 32 channels = 2*NT accumulators of the 32x32 MFMA (16 VGPR each).
-// The K loop walks the input channels in 64-byte chunks (16 fp32 / 32 fp16 channels):
-// the (8+2)x(32+2) halo tile of the chunk and the 9 x BN x chunk weights are staged in
-// LDS once, then all 9 taps read shifted windows of the same halo tile (9x LDS reuse of
-// every input byte).  One ds_read_b128 per lane delivers a 16-byte k-slice that feeds
-// 4 v_mfma_f32_32x32x2_f32 (fp32) or 1 v_mfma_f32_32x32x16_f16 (fp16).
+// The K loop walks the input channels in 64-byte chunks: the (8+2)x(32+2) halo tile of
+// the chunk and the 9 x BN x chunk weights are staged in LDS once, then all 9 taps read
+// shifted windows of the same halo tile (9x LDS reuse of every input byte).  One
+// ds_read_b128 per lane delivers a 16-byte k-slice.
+//
+// Three arithmetic modes share the structure (64-byte chunk records everywhere):
+//   float   : 16 fp32 channels / chunk, 4 x v_mfma_f32_32x32x2_f32 per 16-byte slice
+//             (exact fp32: bitwise an fmaf chain).
+//   _Float16: 32 fp16 channels / chunk, 1 x v_mfma_f32_32x32x16_f16 per slice, fp32 acc.
+//   bsplit  : "bf16x3".  Every value is held as hi + lo, two bf16 (x ~ hi + lo to 2^-18
+//             relative); a chunk is 16 channels = 16 hi (32 B) + 16 lo (32 B).  A product is
+//             a_hi*b_hi + a_hi*b_lo + a_lo*b_hi = 3 x v_mfma_f32_32x32x16_bf16, fp32 acc:
+//             fp32-grade results (~2^-17 relative per product) at 16/3 x the fp32 MFMA rate.
 //
 // LDS records are 64 data bytes + 16 pad = 80 B (5 x 16-B slots, odd) so that the 16
 // lanes of every ds_read_b128 service group (which always cover all residues mod 16 of
 // the pixel / channel index) land on 16 distinct 16-B slots: conflict-free
 // (MI355X_MICROARCH.md, LDS table).
+//
+// Software pipeline: the global loads of chunk k+1 are issued into registers before the
+// MFMAs of chunk k and written to LDS after them, so HBM/L2 latency hides under the MFMAs.
+// Epilogue: accumulators (+bias) go through LDS once so that every lane then handles 4-8
+// consecutive channels of one pixel: residual loads and stores are 16-byte vectors.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,7 +45,11 @@ namespace fisr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// One channel slot (hi or lo interleaved per 16 channels) of the split-bf16 format.  A tensor
+// [N,H,W,C] (C % 16 == 0) is stored per pixel as C/16 groups of {16 x bf16 hi, 16 x bf16 lo}.
+struct bsplit { uint32_t raw; };
 
 constexpr int TILE_H = 8;
 constexpr int TILE_W = 32;
@@ -42,31 +59,45 @@ constexpr int CHUNK_BYTES = 64;                  // channel bytes staged per K c
 constexpr int REC_BYTES = CHUNK_BYTES + 16;      // LDS record stride (odd number of 16-B slots)
 constexpr int CONV_THREADS = 256;
 
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+// x -> (hi, lo) with hi = bf16(x), lo = bf16(x - hi)   (both round-to-nearest-even)
+__device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) {
+  hi = bf16_bits(v);
+  lo = bf16_bits(v - bf16_to_f32(hi));
+}
+
 template <typename T> struct Prec;
 
 template <> struct Prec<float> {
-  static constexpr int CC = CHUNK_BYTES / 4;  // 16 channels per chunk
+  static constexpr int CC = 16;       // channels per 64-byte chunk
+  static constexpr int KG = 2;        // 32-byte k-groups per chunk
+  static constexpr int NF = 1;        // fragments per operand (planes)
+  static constexpr int UC = 4;        // channels per 16-byte epilogue unit
+  static constexpr bool PAIR_LOAD = false;
   typedef f32x4 Frag;
-  static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+  static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, acc, 0, 0, 0);
   }
   static __device__ __forceinline__ uint4 relu16(uint4 v) {
     f32x4 f = __builtin_bit_cast(f32x4, v);
     f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f); f.z = fmaxf(f.z, 0.f); f.w = fmaxf(f.w, 0.f);
     return __builtin_bit_cast(uint4, f);
   }
-  static __device__ __forceinline__ float to_f32(float v) { return v; }
-  static __device__ __forceinline__ float from_f32(float v) { return v; }
 };
 
 template <> struct Prec<_Float16> {
-  static constexpr int CC = CHUNK_BYTES / 2;  // 32 channels per chunk
+  static constexpr int CC = 32;
+  static constexpr int KG = 2;
+  static constexpr int NF = 1;
+  static constexpr int UC = 8;
+  static constexpr bool PAIR_LOAD = false;
   typedef f16x8 Frag;
-  static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+  static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
   }
   static __device__ __forceinline__ uint4 relu16(uint4 v) {
     f16x8 f = __builtin_bit_cast(f16x8, v);
@@ -74,14 +105,38 @@ template <> struct Prec<_Float16> {
     for (int i = 0; i < 8; ++i) f[i] = f[i] > (_Float16)0 ? f[i] : (_Float16)0;
     return __builtin_bit_cast(uint4, f);
   }
-  static __device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
-  static __device__ __forceinline__ _Float16 from_f32(float v) { return (_Float16)v; }
+};
+
+template <> struct Prec<bsplit> {
+  static constexpr int CC = 16;
+  static constexpr int KG = 1;        // one K=16 step per chunk ...
+  static constexpr int NF = 2;        // ... on two planes: [0] = hi (bytes 0..31), [1] = lo (bytes 32..63)
+  static constexpr int UC = 8;
+  static constexpr bool PAIR_LOAD = true;
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);  // lo * hi
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);  // hi * lo
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);  // hi * hi
+  }
+  static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused (pair form below)
+  // relu of 8 split values: a value is negative iff its hi part is (lo is a correction of hi)
+  static __device__ __forceinline__ void relu_pair(uint4& hi, uint4& lo) {
+    uint32_t* h = reinterpret_cast<uint32_t*>(&hi);
+    uint32_t* l = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t m = ((h[i] & 0x8000u) ? 0u : 0xffffu) | ((h[i] & 0x80000000u) ? 0u : 0xffff0000u);
+      h[i] &= m;
+      l[i] &= m;
+    }
+  }
 };
 
 struct ConvArgs {
   const void* in0;   // [N,H,W,C0]
   const void* in1;   // [N,H,W,C1] second concat source (nullable)
-  const void* wpk;   // packed weights [Cin/CC][9][CoutPad][CC]
+  const void* wpk;   // packed weights [Cin/CC][9][CoutPad][64 B]
   const float* bias; // [CoutPad]
   const void* res;   // residual [N,H,W,Cout] (nullable; may alias out)
   void* out;
@@ -90,7 +145,7 @@ struct ConvArgs {
   int Cout, CoutPad;
   int relu_in, relu_out, d2s;
   int d2s_shift;     // log2(Cout/4) when d2s (Cout/4 must be a power of two)
-  // channel scatter of the store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
+  // channel scatter of the direct store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
   int out_cstride, out_coff, out_split, out_gap;
 };
 
@@ -104,7 +159,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
   typedef typename P::Frag Frag;
   constexpr int CC = P::CC;
   constexpr int BN = 32 * NT;
-  constexpr int EPU = 16 / sizeof(T);  // elements per 16-byte unit
+  constexpr int EPU = 16 / sizeof(T);  // T elements per 16-byte unit (bsplit counts as 4-byte slots)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -134,15 +189,20 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
   // ---- loader geometry (identical for every K chunk) ----
-  // A 16-byte unit u = tid + i*256 covers pixel (u>>2) of the halo tile, slot (u&3) of its
-  // 64-byte chunk record; slot and the pixel's low part are per-thread constants.
-  constexpr int NIN = (HALO_PIX * 4 + CONV_THREADS - 1) / CONV_THREADS;  // 6
+  // The halo tile of a chunk is HALO_PIX records of four 16-byte slots.  Normal types: unit
+  // u = tid + i*256 -> pixel u>>2, slot u&3.  bsplit: a thread loads the hi slot s (0/1) and
+  // the matching lo slot s+2 of one pixel (relu needs both): pixel (tid>>1) + i*128.
+  constexpr int NIN = (HALO_PIX * 4 + CONV_THREADS - 1) / CONV_THREADS;  // 6 x 16 B per thread
   constexpr int NWT = (9 * BN * 4 + CONV_THREADS - 1) / CONV_THREADS;    // 9 (BN=64) / 5 (BN=32)
-  const int slot = tid & 3;
-  int in_pix[NIN];  // linear pixel index in the source image, -1 = zero padding / no unit
+  constexpr int NPIX_IT = P::PAIR_LOAD ? NIN / 2 : NIN;                  // pixel iterations
+  constexpr int PIX_STEP = P::PAIR_LOAD ? CONV_THREADS / 2 : CONV_THREADS / 4;
+  const int slot = P::PAIR_LOAD ? (tid & 1) : (tid & 3);
+  const int pix_lo = P::PAIR_LOAD ? (tid >> 1) : (tid >> 2);
+  const int wslot = tid & 3;
+  int in_pix[NPIX_IT];  // linear pixel index in the source image, -1 = zero padding / no unit
 #pragma unroll
-  for (int i = 0; i < NIN; ++i) {
-    const int pix = (tid >> 2) + i * (CONV_THREADS / 4);
+  for (int i = 0; i < NPIX_IT; ++i) {
+    const int pix = pix_lo + i * PIX_STEP;
     const int py = pix / HALO_W, px = pix - py * HALO_W;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
     const bool ok = pix < HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
@@ -160,16 +220,24 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
     if (kc >= 0) {
       __syncthreads();  // every wave is done reading the previous chunk from LDS
 #pragma unroll
-      for (int i = 0; i < NIN; ++i) {
-        const int pix = (tid >> 2) + i * (CONV_THREADS / 4);
-        if (i < NIN - 1 || pix < HALO_PIX)
-          *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + slot * 16) = p.relu_in ? P::relu16(rin[i]) : rin[i];
+      for (int i = 0; i < NPIX_IT; ++i) {
+        const int pix = pix_lo + i * PIX_STEP;
+        if (i < NPIX_IT - 1 || pix < HALO_PIX) {
+          if constexpr (P::PAIR_LOAD) {
+            uint4 hi = rin[2 * i], lo = rin[2 * i + 1];
+            if (p.relu_in) P::relu_pair(hi, lo);
+            *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + slot * 16) = hi;
+            *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + 32 + slot * 16) = lo;
+          } else {
+            *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + slot * 16) = p.relu_in ? P::relu16(rin[i]) : rin[i];
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
         const int r = (tid >> 2) + i * (CONV_THREADS / 4);
         if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
-          *reinterpret_cast<uint4*>(s_w + r * REC_BYTES + slot * 16) = rwt[i];
+          *reinterpret_cast<uint4*>(s_w + r * REC_BYTES + wslot * 16) = rwt[i];
       }
       __syncthreads();
     }
@@ -180,38 +248,53 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       if (c0 < p.C0) { src = (const T*)p.in0; csrc = p.C0; coff = c0; }
       else           { src = (const T*)p.in1; csrc = p.C1; coff = c0 - p.C0; }
 #pragma unroll
-      for (int i = 0; i < NIN; ++i) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (in_pix[i] >= 0)
-          v = *reinterpret_cast<const uint4*>(src + (size_t)in_pix[i] * csrc + coff + slot * EPU);
-        rin[i] = v;
+      for (int i = 0; i < NPIX_IT; ++i) {
+        if constexpr (P::PAIR_LOAD) {
+          uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
+          if (in_pix[i] >= 0) {
+            const T* q = src + (size_t)in_pix[i] * csrc + coff + slot * EPU;
+            hi = *reinterpret_cast<const uint4*>(q);
+            lo = *reinterpret_cast<const uint4*>(q + 2 * EPU);
+          }
+          rin[2 * i] = hi;
+          rin[2 * i + 1] = lo;
+        } else {
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (in_pix[i] >= 0)
+            v = *reinterpret_cast<const uint4*>(src + (size_t)in_pix[i] * csrc + coff + slot * EPU);
+          rin[i] = v;
+        }
       }
-      const T* wsrc = (const T*)p.wpk + (size_t)(kc + 1) * 9 * p.CoutPad * CC;
+      const char* wsrc = (const char*)p.wpk + (size_t)(kc + 1) * 9 * p.CoutPad * CHUNK_BYTES;
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
         const int r = (tid >> 2) + i * (CONV_THREADS / 4);  // r = tap*BN + n
         const int tap = r / BN, n = r - tap * BN;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
-          v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)tap * p.CoutPad + n0 + n) * CC + slot * EPU);
+          v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)tap * p.CoutPad + n0 + n) * CHUNK_BYTES + wslot * 16);
         rwt[i] = v;
       }
     }
     if (kc < 0) continue;
 
-    // ---- 9 taps x 2 k-groups of MFMA on the staged chunk ----
+    // ---- 9 taps x KG k-groups of MFMA on the staged chunk ----
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
+    for (int kg = 0; kg < P::KG; ++kg) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
-        Frag a[2], b[NT];
+        Frag a[2][P::NF], b[NT][P::NF];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          a[m] = *reinterpret_cast<const Frag*>(a_base + ((m + dy) * HALO_W + dx) * REC_BYTES + kg * 32);
+#pragma unroll
+          for (int f = 0; f < P::NF; ++f)
+            a[m][f] = *reinterpret_cast<const Frag*>(a_base + ((m + dy) * HALO_W + dx) * REC_BYTES + kg * 32 + f * 32);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          b[j] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32);
+#pragma unroll
+          for (int f = 0; f < P::NF; ++f)
+            b[j][f] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -220,46 +303,119 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
     }
   }
 
-  // ---- epilogue: bias, residual, relu, (pixel-shuffle / channel-scatter) store ----
   // C/D layout of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Every store address is (per-(row,subtile) base) + (compile-time pixel offset) * step.
-  const int xb = x0 + 4 * kh;        // first pixel column this lane holds
-  const int xlim = p.W - xb;         // columns xb + q are valid for q < xlim
+  if constexpr (OUT_F32) {
+    // ---- direct epilogue (the 3/6-channel heads): bias, relu, channel-scatter fp32 store ----
+    const int xb = x0 + 4 * kh;        // first pixel column this lane holds
+    const int xlim = p.W - xb;         // columns xb + q are valid for q < xlim
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 32 + li;
-    if (n >= p.Cout) continue;
-    const float bv = p.bias[n];
-    int step;          // output elements between horizontally adjacent pixels
-    int nmap, sub_y = 0, sub_x = 0;
-    if (p.d2s) {
-      const int sub = n >> p.d2s_shift;  // n / (Cout/4)
-      nmap = n & ((1 << p.d2s_shift) - 1);
-      sub_y = sub >> 1; sub_x = sub & 1;
-      step = 2 << p.d2s_shift;
-    } else {
-      nmap = n + p.out_coff + (n >= p.out_split ? p.out_gap : 0);
-      step = p.out_cstride;
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 32 + li;
+      if (n >= p.Cout) continue;
+      const float bv = p.bias[n];
+      const int nmap = n + p.out_coff + (n >= p.out_split ? p.out_gap : 0);
+      const int step = p.out_cstride;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int y = y0 + wave * 2 + m;
+        if (y >= p.H) continue;
+        const size_t pix = (size_t)(nb * p.H + y) * p.W + xb;
+        float* ob = (float*)p.out + pix * (size_t)step + nmap;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = (r & 3) + 8 * (r >> 2);
+          if (q >= xlim) continue;
+          float v = acc[m][j][r] + bv;
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          ob[q * step] = v;
+        }
+      }
     }
+  } else {
+    // ---- staged epilogue: acc + bias -> LDS [256 px][BN] fp32 -> per-lane 16-byte vectors ----
+    float* s_o = reinterpret_cast<float*>(smem);
+    __syncthreads();  // all waves are done with the last chunk's LDS reads
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int y = y0 + wave * 2 + m;
-      if (y >= p.H) continue;
-      const size_t pix = (size_t)(nb * p.H + y) * p.W + xb;
-      size_t obase;
-      if (p.d2s) obase = (((size_t)(nb * 2 * p.H + 2 * y + sub_y)) * (2 * p.W) + 2 * xb + sub_x) * (size_t)(1 << p.d2s_shift) + nmap;
-      else obase = pix * (size_t)step + nmap;
-      const T* rp = p.res ? (const T*)p.res + pix * p.Cout + n : nullptr;
+    for (int j = 0; j < NT; ++j) {
+      const float bv = p.bias[n0 + j * 32 + li];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        constexpr int dummy = 0; (void)dummy;
-        const int q = (r & 3) + 8 * (r >> 2);
-        if (q >= xlim) continue;
-        float v = acc[m][j][r] + bv;
-        if (rp) v += P::to_f32(rp[q * p.Cout]);
-        if (p.relu_out) v = fmaxf(v, 0.f);
-        if (OUT_F32) ((float*)p.out)[obase + (size_t)(q * step)] = v;
-        else ((T*)p.out)[obase + (size_t)(q * step)] = P::from_f32(v);
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = (r & 3) + 8 * (r >> 2) + 4 * kh;
+          s_o[((wave * 2 + m) * TILE_W + col) * BN + j * 32 + li] = acc[m][j][r] + bv;
+        }
+    }
+    __syncthreads();
+    constexpr int UC = P::UC;                 // channels per unit
+    constexpr int UPP = BN / UC;              // units per pixel
+    constexpr int NU = TILE_H * TILE_W * UPP / CONV_THREADS;
+    const int cq_shift = p.d2s_shift;
+#pragma unroll 4
+    for (int i = 0; i < NU; ++i) {
+      const int u = tid + i * CONV_THREADS;
+      const int px = u / UPP, cu = u - px * UPP;
+      const int row = px / TILE_W, col = px - row * TILE_W;
+      const int y = y0 + row, x = x0 + col;
+      const int n = n0 + cu * UC;
+      if (y >= p.H || x >= p.W || n >= p.Cout) continue;
+      float v[UC];
+      {
+        const f32x4* sp = reinterpret_cast<const f32x4*>(s_o + px * BN + cu * UC);
+#pragma unroll
+        for (int k = 0; k < UC / 4; ++k) {
+          const f32x4 q = sp[k];
+          v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+      }
+      const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
+      size_t oel;  // output element (channel) index
+      if (p.d2s) {
+        const int sub = n >> cq_shift, c = n & ((1 << cq_shift) - 1);
+        oel = (((size_t)(nb * 2 * p.H + 2 * y + (sub >> 1))) * (2 * p.W) + 2 * x + (sub & 1)) * ((size_t)1 << cq_shift) + c;
+      } else {
+        oel = gp * p.Cout + n;
+      }
+      if constexpr (sizeof(T) == 4 && !P::PAIR_LOAD) {  // float
+        if (p.res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>((const float*)p.res + gp * p.Cout + n);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        }
+        if (p.relu_out) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+        *reinterpret_cast<f32x4*>((float*)p.out + oel) = o;
+      } else if constexpr (sizeof(T) == 2) {  // fp16
+        if (p.res) {
+          const f16x8 rv = *reinterpret_cast<const f16x8*>((const _Float16*)p.res + gp * p.Cout + n);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
+        }
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (_Float16)(p.relu_out ? fmaxf(v[k], 0.f) : v[k]);
+        *reinterpret_cast<f16x8*>((_Float16*)p.out + oel) = o;
+      } else {  // bsplit: channel c of group g lives at byte (g*64 + (c&15)*2) [hi] and +32 [lo]
+        const int half = (n >> 3) & 1;
+        if (p.res) {
+          const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4 + half * 16;
+          const uint4 rh = *reinterpret_cast<const uint4*>(rb);
+          const uint4 rl = *reinterpret_cast<const uint4*>(rb + 32);
+          const uint16_t* h16 = reinterpret_cast<const uint16_t*>(&rh);
+          const uint16_t* l16 = reinterpret_cast<const uint16_t*>(&rl);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32(h16[k]) + bf16_to_f32(l16[k]);
+        }
+        uint4 oh, ol;
+        uint16_t* h16 = reinterpret_cast<uint16_t*>(&oh);
+        uint16_t* l16 = reinterpret_cast<uint16_t*>(&ol);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split_bf16(p.relu_out ? fmaxf(v[k], 0.f) : v[k], h16[k], l16[k]);
+        char* ob = (char*)p.out + (oel & ~(size_t)15) * 4 + half * 16;
+        *reinterpret_cast<uint4*>(ob) = oh;
+        *reinterpret_cast<uint4*>(ob + 32) = ol;
       }
     }
   }

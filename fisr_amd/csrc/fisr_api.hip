@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -127,19 +128,63 @@ std::vector<Spec> all_specs() {
 
 template <typename T> constexpr int chunk_ch() { return Prec<T>::CC; }
 
-// Re-pack HWIO weights to [Cin/CC][9][CoutPad][CC] (channel innermost, 64-byte records) so
-// that a workgroup's weight slab for one K chunk is 9 contiguous runs it copies straight to LDS.
+template <typename T> struct PrecName;
+template <> struct PrecName<float> { static const char* get() { return "f32"; } };
+template <> struct PrecName<_Float16> { static const char* get() { return "f16"; } };
+template <> struct PrecName<bsplit> { static const char* get() { return "bf16x3"; } };
+
+// call f(T()) with the activation type of `precision`
+template <typename F>
+auto with_prec(int precision, F&& f) {
+  if (precision == FISR_PREC_F32) return f(float());
+  if (precision == FISR_PREC_F16) return f(_Float16());
+  return f(bsplit());
+}
+inline bool prec_ok(int precision) {
+  return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3;
+}
+inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 ? 32 : 16; }
+inline int prec_unit(int precision) { return precision == FISR_PREC_F32 ? 4 : 8; }
+
+// host bf16 round-to-nearest-even (finite inputs)
+inline uint16_t host_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float host_bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// Re-pack HWIO weights to [Cin/CC][9][CoutPad][64-byte record] (channel innermost) so that a
+// workgroup's weight slab for one K chunk is 9 contiguous runs it copies straight to LDS.
+// Record = CC values of T (float / fp16), or 16 bf16 hi followed by 16 bf16 lo (bsplit).
 template <typename T>
 void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, int cout_pad,
-                  std::vector<T>& wp, std::vector<float>& bp) {
+                  std::vector<char>& wp, std::vector<float>& bp) {
   constexpr int CC = Prec<T>::CC;
-  wp.assign((size_t)cin_pad * 9 * cout_pad, (T)0);
+  wp.assign((size_t)(cin_pad / CC) * 9 * cout_pad * CHUNK_BYTES, 0);
   bp.assign(cout_pad, 0.f);
   for (int tap = 0; tap < 9; ++tap)
     for (int c = 0; c < ci; ++c)
       for (int n = 0; n < co; ++n) {
         const int kc = c / CC, cc = c % CC;
-        wp[(((size_t)kc * 9 + tap) * cout_pad + n) * CC + cc] = (T)w[((size_t)tap * ci + c) * co + n];
+        char* rec = wp.data() + (((size_t)kc * 9 + tap) * cout_pad + n) * CHUNK_BYTES;
+        const float v = w[((size_t)tap * ci + c) * co + n];
+        if constexpr (std::is_same<T, float>::value) {
+          reinterpret_cast<float*>(rec)[cc] = v;
+        } else if constexpr (std::is_same<T, _Float16>::value) {
+          reinterpret_cast<_Float16*>(rec)[cc] = (_Float16)v;
+        } else {
+          const uint16_t hi = host_bf16(v);
+          const uint16_t lo = host_bf16(v - host_bf16_to_f32(hi));
+          reinterpret_cast<uint16_t*>(rec)[cc] = hi;
+          reinterpret_cast<uint16_t*>(rec)[16 + cc] = lo;
+        }
       }
   for (int n = 0; n < co; ++n) bp[n] = b[n];
 }
@@ -152,14 +197,14 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw) {
   cw.nt = nt_for(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
   cw.cout_pad = round_up(cw.co, 32 * cw.nt);
-  std::vector<T> wp;
+  std::vector<char> wp;
   std::vector<float> bp;
   pack_weights<T>(cw.w.data(), cw.b.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad, wp, bp);
   if (cw.d_w) { (void)hipFree(cw.d_w); cw.d_w = nullptr; }
   if (cw.d_b) { (void)hipFree(cw.d_b); cw.d_b = nullptr; }
-  HIP_OK(ctx, hipMalloc(&cw.d_w, wp.size() * sizeof(T)));
+  HIP_OK(ctx, hipMalloc(&cw.d_w, wp.size()));
   HIP_OK(ctx, hipMalloc((void**)&cw.d_b, bp.size() * sizeof(float)));
-  HIP_OK(ctx, hipMemcpy(cw.d_w, wp.data(), wp.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIP_OK(ctx, hipMemcpy(cw.d_w, wp.data(), wp.size(), hipMemcpyHostToDevice));
   HIP_OK(ctx, hipMemcpy(cw.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }
@@ -318,7 +363,7 @@ struct Runner {
     a.out_coff = coff; a.out_split = split; a.out_gap = gap;
     const double px = (double)n * h * w;
     char cls[96];
-    snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", sizeof(T) == 4 ? "f32" : "f16", cw.nt, out_f32 ? "_f32out" : "");
+    snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
     std::string cname(cls);
     if (ctx->prof_mode == 2) {
       char shp[64];
@@ -338,14 +383,14 @@ struct Runner {
 
   void pool(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:54
     if (rc || ar.dry) return;
-    const size_t work = (size_t)n * (h / 2) * (w / 2) * c / (16 / sizeof(T));
+    const size_t work = (size_t)n * (h / 2) * (w / 2) * c / Unit<T>::UC;
     ProfScope ps(ctx, st, "maxpool2", 0, (double)n * h * w * c * sizeof(T) * 1.25);
     hipLaunchKernelGGL(maxpool2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
     check(hipGetLastError(), "maxpool2");
   }
   void up(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:69
     if (rc || ar.dry) return;
-    const size_t work = (size_t)n * h * w * 4 * c / (16 / sizeof(T));
+    const size_t work = (size_t)n * h * w * 4 * c / Unit<T>::UC;
     ProfScope ps(ctx, st, "upsample2", 0, (double)n * h * w * c * sizeof(T) * 5.0);
     hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
     check(hipGetLastError(), "upsample2");
@@ -533,8 +578,7 @@ int fisr_num_variables_set(const fisr_ctx* ctx) {
 
 int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_finalize_weights: ctx is NULL");
-  if (precision != FISR_PREC_F32 && precision != FISR_PREC_F16)
-    return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
+  if (!prec_ok(precision)) return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
   for (auto& s : all_specs()) {
     const ConvW& cw = ctx->convs[s.name];
     if (!cw.have_w) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/w");
@@ -542,7 +586,7 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   }
   HIP_OK(ctx, hipSetDevice(ctx->dev));
   for (auto& kv : ctx->convs) {
-    int rc = precision == FISR_PREC_F32 ? upload_conv<float>(ctx, kv.second) : upload_conv<_Float16>(ctx, kv.second);
+    int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second); });
     if (rc) return rc;
   }
   ctx->precision = precision;
@@ -553,7 +597,7 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
 size_t fisr_workspace_bytes(const fisr_ctx* cctx, int n, int h, int w) {
   fisr_ctx* ctx = const_cast<fisr_ctx*>(cctx);
   if (!ctx || !ctx->finalized || n < 1 || h < 32 || w < 32 || h % 32 || w % 32) return 0;
-  return ctx->precision == FISR_PREC_F32 ? ws_bytes_t<float>(ctx, n, h, w) : ws_bytes_t<_Float16>(ctx, n, h, w);
+  return with_prec(ctx->precision, [&](auto tag) { return ws_bytes_t<decltype(tag)>(ctx, n, h, w); });
 }
 
 int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out_l3, float* out_l2,
@@ -575,7 +619,7 @@ int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out
     r.ar.base = (char*)workspace; r.ar.cap = workspace_bytes;
     return r.forward(in, n, h, w, out_l3, out_l2, out_l1);
   };
-  return ctx->precision == FISR_PREC_F32 ? run(float()) : run(_Float16());
+  return with_prec(ctx->precision, run);
 }
 
 int fisr_profile_enable(fisr_ctx* ctx, int on) {
@@ -670,7 +714,15 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
                     int out_f32, void* stream) {
   if (!in0 || !w_host || !b_host || !out || n < 1 || h < 1 || w < 1 || cout < 1)
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: bad argument");
-  const int cc = precision == FISR_PREC_F32 ? Prec<float>::CC : Prec<_Float16>::CC;
+  if (!prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: unknown precision");
+  const int cc = prec_chunk(precision);
+  if (cout % prec_unit(precision)) {
+    // partial channel units only exist on the fp32-output heads (direct epilogue, no residual)
+    if (precision == FISR_PREC_F32) out_f32 = 1;
+    if (!out_f32) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: cout must be a multiple of 8 unless out_f32");
+  }
+  if (out_f32 && (res || (flags & FISR_CONV_D2S)))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: the fp32-output (direct) epilogue has no residual / d2s");
   if (c0 % cc || c1 % cc || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
   if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4)))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two");
@@ -678,7 +730,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
   cw.b.assign(b_host, b_host + cout);
-  int rc = precision == FISR_PREC_F32 ? upload_conv<float>(nullptr, cw) : upload_conv<_Float16>(nullptr, cw);
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw); });
   if (rc) return rc;
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
@@ -689,8 +741,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = precision == FISR_PREC_F32 ? launch_conv<float>(a, cw.nt, out_f32 != 0, st)
-                                            : launch_conv<_Float16>(a, cw.nt, out_f32 != 0, st);
+  hipError_t e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
   hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(cw.d_w);
   (void)hipFree(cw.d_b);
@@ -700,27 +751,29 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
 }
 
 int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {
-  if (!in || !out || h % 2 || w % 2) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: bad argument");
-  const int epu = precision == FISR_PREC_F32 ? 4 : 8;
-  if (c % epu) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: c must be a multiple of 16 bytes");
-  const size_t work = (size_t)n * (h / 2) * (w / 2) * c / epu;
-  if (precision == FISR_PREC_F32)
-    hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, n, h, w, c);
-  else
-    hipLaunchKernelGGL(maxpool2_kernel<_Float16>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, n, h, w, c);
+  if (!in || !out || h % 2 || w % 2 || !prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: bad argument");
+  const int uc = prec_unit(precision);
+  if (c % (precision == FISR_PREC_BF16X3 ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: c must be a multiple of the channel unit");
+  const size_t work = (size_t)n * (h / 2) * (w / 2) * c / uc;
+  with_prec(precision, [&](auto tag) {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL(maxpool2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, n, h, w, c);
+    return 0;
+  });
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }
 
 int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {
-  if (!in || !out) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: bad argument");
-  const int epu = precision == FISR_PREC_F32 ? 4 : 8;
-  if (c % epu) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of 16 bytes");
-  const size_t work = (size_t)n * h * w * 4 * c / epu;
-  if (precision == FISR_PREC_F32)
-    hipLaunchKernelGGL(upsample2_kernel<float>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const float*)in, (float*)out, n, h, w, c);
-  else
-    hipLaunchKernelGGL(upsample2_kernel<_Float16>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)in, (_Float16*)out, n, h, w, c);
+  if (!in || !out || !prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: bad argument");
+  const int uc = prec_unit(precision);
+  if (c % (precision == FISR_PREC_BF16X3 ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of the channel unit");
+  const size_t work = (size_t)n * h * w * 4 * c / uc;
+  with_prec(precision, [&](auto tag) {
+    typedef decltype(tag) T;
+    hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, n, h, w, c);
+    return 0;
+  });
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }

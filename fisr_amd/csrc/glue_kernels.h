@@ -9,6 +9,58 @@
 
 namespace fisr {
 
+// ---- channel units: 16-byte vectors of each activation format, as floats ----
+// float: 4 ch / unit; fp16: 8 ch / unit; bsplit: 8 ch / unit = 16 B of hi + 16 B of lo
+// (per 16 channels: 32 B hi then 32 B lo, see conv3x3.h).
+template <typename T> struct Unit;
+template <> struct Unit<float> {
+  static constexpr int UC = 4;
+  static __device__ __forceinline__ void load(const float* pix, int cu, float* v) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(pix + cu * 4);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  }
+  static __device__ __forceinline__ void store(float* pix, int cu, const float* v) {
+    f32x4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+    *reinterpret_cast<f32x4*>(pix + cu * 4) = q;
+  }
+};
+template <> struct Unit<_Float16> {
+  static constexpr int UC = 8;
+  static __device__ __forceinline__ void load(const _Float16* pix, int cu, float* v) {
+    const f16x8 q = *reinterpret_cast<const f16x8*>(pix + cu * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (float)q[k];
+  }
+  static __device__ __forceinline__ void store(_Float16* pix, int cu, const float* v) {
+    f16x8 q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = (_Float16)v[k];
+    *reinterpret_cast<f16x8*>(pix + cu * 8) = q;
+  }
+};
+template <> struct Unit<bsplit> {
+  static constexpr int UC = 8;
+  static __device__ __forceinline__ void load(const bsplit* pix, int cu, float* v) {
+    const char* b = reinterpret_cast<const char*>(pix) + (cu >> 1) * 64 + (cu & 1) * 16;
+    const uint4 h = *reinterpret_cast<const uint4*>(b);
+    const uint4 l = *reinterpret_cast<const uint4*>(b + 32);
+    const uint16_t* h16 = reinterpret_cast<const uint16_t*>(&h);
+    const uint16_t* l16 = reinterpret_cast<const uint16_t*>(&l);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(h16[k]) + bf16_to_f32(l16[k]);  // exact in fp32
+  }
+  static __device__ __forceinline__ void store(bsplit* pix, int cu, const float* v) {
+    uint4 h, l;
+    uint16_t* h16 = reinterpret_cast<uint16_t*>(&h);
+    uint16_t* l16 = reinterpret_cast<uint16_t*>(&l);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split_bf16(v[k], h16[k], l16[k]);
+    char* b = reinterpret_cast<char*>(pix) + (cu >> 1) * 64 + (cu & 1) * 16;
+    *reinterpret_cast<uint4*>(b) = h;
+    *reinterpret_cast<uint4*>(b + 32) = l;
+  }
+};
+
 // ---- level input: strided sub-sample + concat with the previous prediction + channel pad ----
 // FISRnet.py:81,112 (legacy BICUBIC resize at integer factor == x[:, ::s, ::s, :])
 // FISRnet.py:113,144 (tf.concat((img_lk, pred_l{k-1}), axis=3)).  Output has cpad >= 29(+9)
@@ -27,45 +79,41 @@ __global__ void prep_level_input_kernel(const float* __restrict__ img, const flo
     float v = 0.f;
     if (c < 29) v = img[(((size_t)n * H + (size_t)y * s) * W + (size_t)x * s) * 29 + c];
     else if (pred != nullptr && c < 38) v = pred[pix * 9 + (c - 29)];
-    out[i] = Prec<T>::from_f32(v);
+    if constexpr (sizeof(T) == 4 && Unit<T>::UC == 4) {
+      out[i] = v;
+    } else if constexpr (sizeof(T) == 2) {
+      out[i] = (_Float16)v;
+    } else {
+      uint16_t hi, lo;
+      split_bf16(v, hi, lo);
+      uint16_t* o = reinterpret_cast<uint16_t*>(out) + (pix * cpad + (c & ~15)) * 2 + (c & 15);
+      o[0] = hi;
+      o[16] = lo;
+    }
   }
 }
 
 // ---- 2x2/2 max pool: ops.py:54 tf.nn.max_pool(..., 'SAME') on even sizes ----
 template <typename T>
 __global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
-  constexpr int EPU = 16 / sizeof(T);
-  const int oh = H / 2, ow = W / 2, cv = C / EPU;
+  constexpr int UC = Unit<T>::UC;
+  const int oh = H / 2, ow = W / 2, cv = C / UC;
   const size_t total = (size_t)N * oh * ow * cv;
-  const uint4* src = reinterpret_cast<const uint4*>(in);
-  uint4* dst = reinterpret_cast<uint4*>(out);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv);
     const size_t pix = i / cv;
     const int x = (int)(pix % ow);
     const int y = (int)((pix / ow) % oh);
     const int n = (int)(pix / ((size_t)ow * oh));
-    const size_t b = (((size_t)n * H + 2 * y) * W + 2 * x) * cv + c;
-    const uint4 q0 = src[b], q1 = src[b + cv], q2 = src[b + (size_t)W * cv], q3 = src[b + (size_t)W * cv + cv];
-    uint4 r;
-    if constexpr (sizeof(T) == 4) {
-      f32x4 a = __builtin_bit_cast(f32x4, q0), b1 = __builtin_bit_cast(f32x4, q1);
-      f32x4 c1 = __builtin_bit_cast(f32x4, q2), d = __builtin_bit_cast(f32x4, q3), m;
+    const T* p00 = in + (((size_t)n * H + 2 * y) * W + 2 * x) * C;
+    float a[UC], b[UC], c2[UC], d[UC], m[UC];
+    Unit<T>::load(p00, c, a);
+    Unit<T>::load(p00 + C, c, b);
+    Unit<T>::load(p00 + (size_t)W * C, c, c2);
+    Unit<T>::load(p00 + (size_t)W * C + C, c, d);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(a[k], b1[k]), fmaxf(c1[k], d[k]));
-      r = __builtin_bit_cast(uint4, m);
-    } else {
-      f16x8 a = __builtin_bit_cast(f16x8, q0), b1 = __builtin_bit_cast(f16x8, q1);
-      f16x8 c1 = __builtin_bit_cast(f16x8, q2), d = __builtin_bit_cast(f16x8, q3), m;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        _Float16 u = a[k] > b1[k] ? a[k] : b1[k];
-        _Float16 v = c1[k] > d[k] ? c1[k] : d[k];
-        m[k] = u > v ? u : v;
-      }
-      r = __builtin_bit_cast(uint4, m);
-    }
-    dst[i] = r;
+    for (int k = 0; k < UC; ++k) m[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c2[k], d[k]));
+    Unit<T>::store(out + pix * C, c, m);
   }
 }
 
@@ -75,11 +123,9 @@ __global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, i
 template <typename T>
 __global__ void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
 #pragma clang fp contract(off)
-  constexpr int EPU = 16 / sizeof(T);
-  const int oh = H * 2, ow = W * 2, cv = C / EPU;
+  constexpr int UC = Unit<T>::UC;
+  const int oh = H * 2, ow = W * 2, cv = C / UC;
   const size_t total = (size_t)N * oh * ow * cv;
-  const uint4* src = reinterpret_cast<const uint4*>(in);
-  uint4* dst = reinterpret_cast<uint4*>(out);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv);
     const size_t pix = i / cv;
@@ -90,32 +136,18 @@ __global__ void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, 
     const int x0 = ox >> 1, x1 = min(x0 + 1, W - 1);
     const float ty = (oy & 1) ? 0.5f : 0.f, tx = (ox & 1) ? 0.5f : 0.f;
     const size_t r0 = ((size_t)n * H + y0) * W, r1 = ((size_t)n * H + y1) * W;
-    const uint4 qtl = src[(r0 + x0) * cv + c], qtr = src[(r0 + x1) * cv + c];
-    const uint4 qbl = src[(r1 + x0) * cv + c], qbr = src[(r1 + x1) * cv + c];
-    uint4 r;
-    if constexpr (sizeof(T) == 4) {
-      f32x4 tl = __builtin_bit_cast(f32x4, qtl), tr = __builtin_bit_cast(f32x4, qtr);
-      f32x4 bl = __builtin_bit_cast(f32x4, qbl), br = __builtin_bit_cast(f32x4, qbr), o;
+    float tl[UC], tr[UC], bl[UC], br[UC], o[UC];
+    Unit<T>::load(in + (r0 + x0) * C, c, tl);
+    Unit<T>::load(in + (r0 + x1) * C, c, tr);
+    Unit<T>::load(in + (r1 + x0) * C, c, bl);
+    Unit<T>::load(in + (r1 + x1) * C, c, br);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float top = tl[k] + (tr[k] - tl[k]) * tx;
-        const float bot = bl[k] + (br[k] - bl[k]) * tx;
-        o[k] = top + (bot - top) * ty;
-      }
-      r = __builtin_bit_cast(uint4, o);
-    } else {
-      f16x8 tl = __builtin_bit_cast(f16x8, qtl), tr = __builtin_bit_cast(f16x8, qtr);
-      f16x8 bl = __builtin_bit_cast(f16x8, qbl), br = __builtin_bit_cast(f16x8, qbr), o;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float a = (float)tl[k], b = (float)tr[k], c2 = (float)bl[k], d = (float)br[k];
-        const float top = a + (b - a) * tx;
-        const float bot = c2 + (d - c2) * tx;
-        o[k] = (_Float16)(top + (bot - top) * ty);
-      }
-      r = __builtin_bit_cast(uint4, o);
+    for (int k = 0; k < UC; ++k) {
+      const float top = tl[k] + (tr[k] - tl[k]) * tx;
+      const float bot = bl[k] + (br[k] - bl[k]) * tx;
+      o[k] = top + (bot - top) * ty;
     }
-    dst[i] = r;
+    Unit<T>::store(out + pix * C, c, o);
   }
 }
 

@@ -18,6 +18,7 @@ torch = pytest.importorskip("torch")
 import c_oracle as C          # noqa: E402
 import fisr_oracle as O       # noqa: E402
 from fisr_amd import lib as flib  # noqa: E402
+from fisr_amd import splitfmt  # noqa: E402
 from fisr_amd.fisrnet import FISRnet  # noqa: E402
 
 F32_FWD_TOL = 2e-4      # max |hip_fp32 - oracle_fp64| on O(1) outputs after 138 convs
@@ -40,6 +41,14 @@ def net32(dev, syn_weights):
 
 
 @pytest.fixture(scope="module")
+def netx3(dev, syn_weights):
+    n = FISRnet(device="cuda:0", precision="bf16x3")
+    n.set_weights(syn_weights)
+    yield n
+    n.close()
+
+
+@pytest.fixture(scope="module")
 def net16(dev, syn_weights):
     n = FISRnet(device="cuda:0", precision="fp16")
     n.set_weights(syn_weights)
@@ -55,30 +64,56 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
 
 
+PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2}
+
+
+def to_dev(x, prec):
+    """numpy float32 [N,H,W,C] -> device tensor in the activation format of `prec`."""
+    x = np.ascontiguousarray(x, np.float32)
+    if prec == "fp32":
+        return torch.from_numpy(x).cuda()
+    if prec == "fp16":
+        return torch.from_numpy(x).cuda().half().contiguous()
+    return torch.from_numpy(splitfmt.to_split(x).view(np.int16)).cuda()
+
+
+def from_dev(t, prec, shape):
+    if prec == "fp32":
+        return t.cpu().numpy().reshape(shape)
+    if prec == "fp16":
+        return t.float().cpu().numpy().reshape(shape)
+    s = t.cpu().numpy().view(np.uint16).reshape(shape[:-1] + (shape[-1] // 16, 2, 16))
+    return splitfmt.from_split(s)
+
+
+def empty_dev(shape, prec):
+    if prec == "fp32":
+        return torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
+    if prec == "fp16":
+        return torch.full(shape, float("nan"), dtype=torch.float16, device="cuda")
+    return torch.full(shape[:-1] + (shape[-1] // 16, 2, 16), 0x7fc0, dtype=torch.int16, device="cuda")  # bf16 NaN
+
+
 def hip_conv(x0, w, b, x1=None, res=None, flags=0, prec="fp32", out_f32=False):
     """fisr_op_conv3x3 on numpy inputs -> numpy float32 output."""
     L = flib.lib()
-    tdt = torch.float32 if prec == "fp32" else torch.float16
     n, h, wd, c0 = x0.shape
     cout = w.shape[3]
-    d0 = torch.from_numpy(np.ascontiguousarray(x0, np.float32)).cuda().to(tdt).contiguous()
-    d1 = torch.from_numpy(np.ascontiguousarray(x1, np.float32)).cuda().to(tdt).contiguous() if x1 is not None else None
-    dr = torch.from_numpy(np.ascontiguousarray(res, np.float32)).cuda().to(tdt).contiguous() if res is not None else None
-    if flags & flib.CONV_D2S:
-        oshape = (n, 2 * h, 2 * wd, cout // 4)
-    else:
-        oshape = (n, h, wd, cout)
-    out = torch.full(oshape, float("nan"), dtype=torch.float32 if out_f32 else tdt, device="cuda")
+    d0 = to_dev(x0, prec)
+    d1 = to_dev(x1, prec) if x1 is not None else None
+    dr = to_dev(res, prec) if res is not None else None
+    oshape = (n, 2 * h, 2 * wd, cout // 4) if flags & flib.CONV_D2S else (n, h, wd, cout)
+    out = empty_dev(oshape, "fp32" if out_f32 else prec)
     wc = np.ascontiguousarray(w, np.float32)
     bc = np.ascontiguousarray(b, np.float32)
     rc = L.fisr_op_conv3x3(ctypes.c_void_p(d0.data_ptr()), c0,
                            ctypes.c_void_p(d1.data_ptr() if d1 is not None else 0), x1.shape[3] if x1 is not None else 0,
                            _fp(wc), _fp(bc), cout, ctypes.c_void_p(dr.data_ptr() if dr is not None else 0),
-                           ctypes.c_void_p(out.data_ptr()), n, h, wd, flags, 0 if prec == "fp32" else 1,
+                           ctypes.c_void_p(out.data_ptr()), n, h, wd, flags, PREC_ID[prec],
                            int(out_f32), _stream())
     flib.check(rc)
     torch.cuda.synchronize()
-    return out.float().cpu().numpy()
+    return from_dev(out, "fp32" if out_f32 else prec, oshape)
 
 
 def ref_conv(x0, w, b, x1=None, res=None, flags=0):
@@ -131,9 +166,37 @@ def test_conv3x3_fp32_vs_oracle(dev, shape):
     wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
     b = rng.standard_normal(cout).astype(np.float32)
     res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
-    got = hip_conv(x0, wt, b, x1, res, flags)
+    got = hip_conv(x0, wt, b, x1, res, flags, out_f32=(cout % 4 != 0))
     exp = ref_conv(x0, wt, b, x1, res, flags)
     _report(got, exp, F32_OP_TOL, f"conv {shape}")
+
+
+@pytest.mark.parametrize("shape", [
+    (1, 8, 32, 16, 0, 64, 0, False),
+    (1, 16, 64, 32, 0, 64, 3, True),            # relu in/out + residual (split residual read / write)
+    (2, 24, 24, 64, 0, 128, 1, False),
+    (1, 17, 45, 48, 0, 64, 0, False),
+    (1, 16, 40, 64, 64, 64, 0, False),          # concat
+    (1, 10, 33, 64, 0, 256, 7, False),          # relu + depth_to_space store in split layout
+    (1, 16, 64, 64, 0, 6, 0, False),            # fp32-output head
+    (1, 8, 8, 512, 0, 512, 2, True),
+])
+def test_conv3x3_bf16x3_vs_oracle(dev, shape):
+    """Split-bf16 (3 MFMA per product) conv: inputs/weights are rounded to hi+lo (2^-18), products
+    drop lo*lo (2^-16 rel.), accumulation fp32 -> error ~1e-5 of the operand scale."""
+    n, h, w, c0, c1, cout, flags, use_res = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31) + 1)
+    x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+    wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+    got = hip_conv(x0, wt, b, x1, res, flags, prec="bf16x3", out_f32=(cout % 8 != 0))
+    exp = ref_conv(x0, wt, b, x1, res, flags)
+    _report(got, exp, 6e-5, f"bf16x3 conv {shape}")
+    # relu must zero hi and lo together: no negative values may survive
+    if flags & flib.CONV_RELU_OUT:
+        assert got.min() >= 0
 
 
 def test_conv3x3_transpose_detecting(dev):
@@ -210,6 +273,16 @@ def test_pool_upsample_bit_exact(dev):
     xr = xh.float().cpu().numpy()
     assert np.array_equal(poh.float().cpu().numpy(), O.max_pool2(xr))
     assert np.abs(uph.float().cpu().numpy() - O.resize_bilinear_x2(xr)).max() < 2e-3
+    # split-bf16 storage: pool is value-exact, upsample is fp32 maths re-split (2^-18 relative)
+    xs = to_dev(x, "bf16x3")
+    xsr = splitfmt.split_round(x)
+    pos = empty_dev((2, 3, 5, 64), "bf16x3")
+    ups = empty_dev((2, 12, 20, 64), "bf16x3")
+    flib.check(L.fisr_op_maxpool2(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(pos.data_ptr()), 2, 6, 10, 64, 2, _stream()))
+    flib.check(L.fisr_op_upsample2(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(ups.data_ptr()), 2, 6, 10, 64, 2, _stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(pos, "bf16x3", (2, 3, 5, 64)), O.max_pool2(xsr))
+    assert np.abs(from_dev(ups, "bf16x3", (2, 12, 20, 64)) - O.resize_bilinear_x2(xsr)).max() < 2e-5
 
 
 # ----------------------------------------------------------------------------- whole forward
@@ -251,6 +324,26 @@ def _psnr_protocol(hip, oracle, rng):
         gt = o + rng.standard_normal(o.shape) * sigma
         out.append(abs(O.compute_psnr(gt, np.clip(hip[..., sl], 0, 1)) - O.compute_psnr(gt, o)))
     return out
+
+
+def test_forward_bf16x3_vs_golden(netx3, gold_dir):
+    """Whole forward in split-bf16: must sit far inside the reference tolerance (it is the
+    fp32-grade fast path) -- max error ~1e-4 on O(1) outputs, dPSNR << 0.02 dB."""
+    g = np.load(os.path.join(gold_dir, "model_32x64.npz"))
+    l1, l2, l3 = netx3.model(torch.from_numpy(g["x"]).cuda())
+    for name, got, exp in (("l1", l1, g["l1"]), ("l2", l2, g["l2"]), ("l3", l3, g["l3"])):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - exp)
+        print(f"bf16x3 {name}: max {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}")
+        assert err.max() < 5e-4 and np.sqrt((err ** 2).mean()) < 5e-5
+    g96 = np.load(os.path.join(gold_dir, "model_96.npz"))
+    rng = np.random.default_rng(8)
+    for s_ in range(3):
+        _, _, l3 = netx3.model(torch.from_numpy(g96["inp"][s_:s_ + 1]).cuda(), want_all=False)
+        hip = l3.cpu().numpy()[0].astype(np.float64)
+        ref = g96["l3"][s_].astype(np.float64)
+        d = _psnr_protocol(hip, ref, rng)
+        print(f"bf16x3 window {s_}: rms {np.sqrt(np.mean((hip - ref) ** 2)):.3e} max {np.abs(hip - ref).max():.3e} dPSNR {d}")
+        assert max(d) <= 0.002, d
 
 
 def test_forward_fp16_within_reference_tolerance(net16, gold_dir):
