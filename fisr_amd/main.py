@@ -1,0 +1,109 @@
+"""Command line of the MI355X-native FISR inference path -- same flags as the reference's
+`main.py` (main.py:23-106) for the phases this build implements.
+
+    python -m fisr_amd.main --phase test [--test_data_path ... --checkpoint_dir ...]
+    python -m fisr_amd.main --phase FISR_for_video --frame_folder_path DIR --flow_file X.flo
+
+Differences from the reference, all deliberate:
+  * `--test_patch`, `--test_input_size`, `--FISR_input_size`, `--FISR_test_patch` parse "2,2" /
+    "(2,2)" into integer tuples (the reference's `type=tuple` turns a CLI string into a tuple of
+    characters, main.py:89-103); `--scale_factor` is an int (main.py:29 makes 2.0).
+  * `--phase train` is out of scope (inference-only build) and exits with an error.
+  * `--phase FISR_for_video` needs a pre-computed flow file (`--flow_file`): the PWC-Net flow
+    estimator (main.py:210) is a "next" row; the frame warp (main.py:213) runs on the GPU.
+  * extra flags: `--precision {fp32,bf16x3,fp16}`, `--device`, `--synthetic_weights SEED`.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+
+def _tuple2(s):
+    if isinstance(s, (tuple, list)):
+        return tuple(int(v) for v in s)
+    vals = [v for v in str(s).replace("(", " ").replace(")", " ").replace(",", " ").split() if v]
+    if len(vals) != 2:
+        raise argparse.ArgumentTypeError(f"expected two integers like 2,2 -- got {s!r}")
+    return int(vals[0]), int(vals[1])
+
+
+def check_folder(d):
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def parse_args(argv=None):
+    desc = "FISR (MI355X-native inference path): joint frame interpolation and super-resolution"
+    p = argparse.ArgumentParser(description=desc)
+    p.add_argument("--net_type", type=str, default="FISRnet", choices=["FISRnet"])
+    p.add_argument("--fraction_gpu", type=float, default=1.0, help="accepted for compatibility; unused")
+    p.add_argument("--phase", type=str, default="FISR_for_video", choices=["train", "test", "FISR_for_video"])
+    p.add_argument("--scale_factor", type=int, default=2)
+    p.add_argument("--test_data_path", type=str, default="./data/test/LR_LFR")
+    p.add_argument("--test_flow_data_path", type=str, default="./data/test/flow/LR_Surfing_SlamDunk_test_ss1.flo")
+    p.add_argument("--test_warped_data_path", type=str, default="./data/test/warped/LR_Surfing_SlamDunk_test_ss1_warp.mat")
+    p.add_argument("--test_label_path", type=str, default="./data/test/HR_HFR")
+    p.add_argument("--test_img_dir", type=str, default="./test_img_dir")
+    p.add_argument("--text_dir", type=str, default="./text_dir")
+    p.add_argument("--checkpoint_dir", type=str, default="./checkpoint_dir")
+    p.add_argument("--log_dir", type=str, default="./logdir")
+    p.add_argument("--exp_num", type=int, default=1)
+    p.add_argument("--test_patch", type=_tuple2, default=(2, 2))
+    p.add_argument("--test_input_size", type=_tuple2, default=(1080, 1920))
+    p.add_argument("--frame_folder_path", type=str, default="./FISR_test_folder/scene1")
+    p.add_argument("--FISR_input_size", type=_tuple2, default=(1080, 1920))
+    p.add_argument("--frame_num", type=int, default=5)
+    p.add_argument("--FISR_test_patch", type=_tuple2, default=(2, 2))
+    # build-specific
+    p.add_argument("--precision", type=str, default="bf16x3", choices=["fp32", "bf16x3", "fp16"])
+    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--flow_file", type=str, default=None, help="pre-computed 5-D .flo for FISR_for_video")
+    p.add_argument("--warp_file", type=str, default=None, help="pre-computed warp (.mat/.npy); default: warp on the GPU")
+    p.add_argument("--synthetic_weights", type=int, default=None, metavar="SEED",
+                   help="use seeded stand-in weights instead of a checkpoint (no checkpoint ships with the reference)")
+    args = p.parse_args(argv)
+    return check_args(args)
+
+
+def check_args(args):
+    """main.py:108-121."""
+    for d in (args.checkpoint_dir, args.text_dir, args.log_dir, args.test_img_dir):
+        check_folder(d)
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.phase == "train":
+        print("--phase train is out of scope of the MI355X inference build (see DESIGN.md)", file=sys.stderr)
+        return 2
+    from . import io as fio
+    from . import harness, weights
+    from .fisrnet import FISRnet
+
+    net = FISRnet(args)
+    if args.synthetic_weights is not None:
+        net.set_weights(weights.synthetic_weights(args.synthetic_weights))
+    if args.phase == "test":
+        net.test()
+        print(" [*] Test finished!")
+        return 0
+    # FISR_for_video (main.py:207-235)
+    if not args.flow_file:
+        print("FISR_for_video needs --flow_file (the on-GPU PWC-Net flow estimator is a 'next' row)", file=sys.stderr)
+        return 2
+    warp_file = args.warp_file
+    if warp_file is None:
+        flow = fio.read_flo_file_5dim(args.flow_file)
+        frames = harness.sorted_pngs(args.frame_folder_path)
+        warp_file = harness.warp_img(net, frames, flow)          # ndarray, stays in memory
+        print("[*] Warp done on the GPU")
+    net.FISR_for_video(args.flow_file, warp_file)
+    print(" [*] FISR finished!")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
