@@ -10,7 +10,7 @@ CMD="python $REPO/bench.py --steps 1 --warmup 1 --precision $PREC --no-cpu-basel
 echo "== kernel trace + stats"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 1 (SQ / MFMA busy)"
-timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc1" -o pmc1 -- $CMD > "$OUT/pmc1.log" 2>&1; echo "rc=$?"
+timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc1" -o pmc1 -- $CMD > "$OUT/pmc1.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 2 (LDS / waits)"
 timeout 900 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace -d "$OUT/pmc2" -o pmc2 -- $CMD > "$OUT/pmc2.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 3 (HBM read)"
@@ -18,6 +18,6 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc3" -o pmc3 -- 
 echo "== pmc pass 4 (HBM write)"
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc4" -o pmc4 -- $CMD > "$OUT/pmc4.log" 2>&1; echo "rc=$?"
 cd "$OUT" && find . -type f | head -50 && du -sh .
-# keep only CSVs (drop big binary dbs if any)
-find "$OUT" -type f \( -name "*.db" -o -name "*.pftrace" -o -name "*.json" \) -size +8M -delete
-python "$REPO/scripts/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt" | head -60
+python "$REPO/scripts/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1; cat "$OUT/summary.txt" | head -90
+# the merged gpurun_out/ is capped at 64 MiB: drop the big per-dispatch databases after summarising
+find "$OUT" -type f \( -name "*.db" -o -name "*.pftrace" -o -name "*.json" \) -size +6M -delete

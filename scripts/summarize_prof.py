@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into a short per-kernel summary."""
-import csv
+"""Condense rocprofv3 output (rocpd sqlite .db of ROCm 7.2, or CSV) into a short per-kernel
+summary: kernel stats from the trace pass, counter totals / per-dispatch averages from PMC passes."""
 import glob
 import os
+import re
+import sqlite3
 import sys
 from collections import defaultdict
 
@@ -10,34 +12,37 @@ root = sys.argv[1]
 
 
 def short(name):
-    name = name.replace("void fisr::", "").replace("fisr::", "")
-    return name[:80]
+    name = re.sub(r"\bvoid\s+", "", name).replace("fisr::", "")
+    name = re.sub(r"\(.*", "", name)
+    return name[:70]
 
 
-def find(pattern):
-    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
-
-
-print("# rocprofv3 summary of", os.path.basename(root))
-for f in find("*kernel_stats.csv"):
-    print("\n## kernel stats (", os.path.relpath(f, root), ")")
-    with open(f) as fh:
-        rows = list(csv.DictReader(fh))
-    for r in rows[:14]:
-        print(f"{short(r['Name']):82s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:10.3f} "
-              f"avg_us {float(r['AverageNs'])/1e3:10.2f} pct {r['Percentage']:>6s}")
-
-for f in find("*counter_collection.csv"):
-    print("\n## counters (", os.path.relpath(f, root), ")")
-    agg = defaultdict(lambda: defaultdict(float))
-    cnt = defaultdict(set)
-    with open(f) as fh:
-        for r in csv.DictReader(fh):
-            k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[k].add(r["Dispatch_Id"])
-    for k, d in sorted(agg.items(), key=lambda kv: -sum(kv[1].values()))[:8]:
-        n = len(cnt[k])
-        print(f"{k:82s} dispatches {n}")
-        for c, v in sorted(d.items()):
-            print(f"    {c:32s} total {v:.6g}  per_dispatch {v / max(n, 1):.6g}")
+print("# rocprofv3 summary of", os.path.basename(os.path.abspath(root)))
+for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+    db = sqlite3.connect(f)
+    cur = db.cursor()
+    rel = os.path.relpath(f, root)
+    try:
+        rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                                "from kernels group by name order by sum(duration) desc"))
+    except sqlite3.Error as e:
+        print(rel, "no kernels view:", e)
+        continue
+    tot = sum(r[2] for r in rows) or 1
+    pmc = list(cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
+                           "group by name, counter_name"))
+    if not pmc:
+        print(f"\n## kernel trace stats ({rel}); durations from the GPU timestamps of each dispatch")
+        print(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+        for n, c, s, a, mn, mx in rows[:16]:
+            print(f"{short(n):72s} {c:6d} {s / 1e6:10.3f} {a / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * s / tot:6.2f}")
+    else:
+        print(f"\n## counters ({rel})")
+        agg = defaultdict(dict)
+        for n, cn, c, s in pmc:
+            agg[short(n)][cn] = (c, s)
+        dur = {short(r[0]): (r[1], r[2]) for r in rows}
+        for k in sorted(agg, key=lambda k: -dur.get(k, (0, 0))[1])[:6]:
+            print(f"{k}  dispatches {dur.get(k, (0, 0))[0]}  total_ms {dur.get(k, (0, 0))[1] / 1e6:.3f}")
+            for cn, (c, s) in sorted(agg[k].items()):
+                print(f"    {cn:30s} sum {s:.6g}   per_dispatch {s / max(c, 1):.6g}")
