@@ -40,6 +40,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef FISR_SCHED
+#define FISR_SCHED 0
+#endif
+#ifndef FISR_ABL
+#define FISR_ABL 0
+#endif
+#ifndef FISR_MMAORDER
+#define FISR_MMAORDER 1
+#endif
+#ifndef FISR_STAGGER
+#define FISR_STAGGER 0
+#endif
+#ifndef FISR_PKRELU
+#define FISR_PKRELU 0
+#endif
+#ifndef FISR_XCD
+#define FISR_XCD 0
+#endif
+
 namespace fisr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -82,6 +101,13 @@ template <> struct Prec<float> {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, acc, 0, 0, 0);
   }
+  template <int NT_>
+  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[2][NT_], const Frag (&a)[2][NF], const Frag (&b)[NT_][NF]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < NT_; ++j) mma(acc[m][j], a[m], b[j]);
+  }
   static __device__ __forceinline__ uint4 relu16(uint4 v) {
     f32x4 f = __builtin_bit_cast(f32x4, v);
     f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f); f.z = fmaxf(f.z, 0.f); f.w = fmaxf(f.w, 0.f);
@@ -98,6 +124,13 @@ template <> struct Prec<_Float16> {
   typedef f16x8 Frag;
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+  }
+  template <int NT_>
+  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[2][NT_], const Frag (&a)[2][NF], const Frag (&b)[NT_][NF]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < NT_; ++j) mma(acc[m][j], a[m], b[j]);
   }
   static __device__ __forceinline__ uint4 relu16(uint4 v) {
     f16x8 f = __builtin_bit_cast(f16x8, v);
@@ -119,9 +152,39 @@ template <> struct Prec<bsplit> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);  // hi * lo
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);  // hi * hi
   }
+  // Term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependency).
+  template <int NT_>
+  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[2][NT_], const Frag (&a)[2][NF], const Frag (&b)[NT_][NF]) {
+#if FISR_MMAORDER
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < NT_; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][term == 0 ? 1 : 0], b[j][term == 1 ? 1 : 0], acc[m][j], 0, 0, 0);
+#else
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < NT_; ++j) mma(acc[m][j], a[m], b[j]);
+#endif
+  }
   static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused (pair form below)
   // relu of 8 split values: a value is negative iff its hi part is (lo is a correction of hi)
   static __device__ __forceinline__ void relu_pair(uint4& hi, uint4& lo) {
+#if FISR_PKRELU
+    // bf16 bit patterns compared as packed int16: negative value <=> sign bit <=> negative int16
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    s16x2* h = reinterpret_cast<s16x2*>(&hi);
+    s16x2* l = reinterpret_cast<s16x2*>(&lo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const s16x2 neg = h[i] >> 15;          // 0xffff in negative halves (v_pk_ashrrev_i16)
+      h[i] = h[i] & ~neg;
+      l[i] = l[i] & ~neg;
+    }
+#else
     uint32_t* h = reinterpret_cast<uint32_t*>(&hi);
     uint32_t* l = reinterpret_cast<uint32_t*>(&lo);
 #pragma unroll
@@ -130,6 +193,7 @@ template <> struct Prec<bsplit> {
       h[i] &= m;
       l[i] &= m;
     }
+#endif
   }
 };
 
@@ -173,12 +237,30 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
 
   const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
   const int tiles_y = (p.H + TILE_H - 1) / TILE_H;
+  // XCD-aware mapping: workgroup b is observed to run on XCD b % 8 (speed only, never
+  // correctness).  Give every XCD a contiguous band of tiles so that neighbouring tiles (which
+  // share halo rows/columns) hit the same 4 MiB L2 instead of re-fetching across XCDs.
   int t = blockIdx.x;
+  if (FISR_XCD) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = t & 7, loc = t >> 3;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int nb = t / tiles_y;
   const int x0 = tx * TILE_W, y0 = ty * TILE_H;
   const int n0 = blockIdx.y * BN;
+
+#if FISR_STAGGER
+  // Two workgroups share a CU and, being identical, run in lockstep: their LDS-fill/barrier
+  // phases coincide (matrix pipe idle) and their MFMA phases contend.  Delaying the second
+  // workgroup of every CU once, in the first dispatch round, by about half a chunk period puts
+  // the pair in anti-phase for the rest of the launch (a finishing workgroup's successor inherits
+  // its phase).  Placement heuristic (block b -> XCD b%8, CUs filled round-robin, so blocks b and
+  // b+256 share a CU): speed only, never correctness.
+  if (blockIdx.y == 0 && blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(80);
+#endif
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -199,6 +281,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
   const int slot = P::PAIR_LOAD ? (tid & 1) : (tid & 3);
   const int pix_lo = P::PAIR_LOAD ? (tid >> 1) : (tid >> 2);
   const int wslot = tid & 3;
+  const int wrec_lo = tid >> 2;
   int in_pix[NPIX_IT];  // linear pixel index in the source image, -1 = zero padding / no unit
 #pragma unroll
   for (int i = 0; i < NPIX_IT; ++i) {
@@ -217,7 +300,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
   // global loads of chunk kc+1 (they stay in flight during the MFMAs), then computes chunk kc.
   // Iteration -1 only issues the first loads.
   for (int kc = -1; kc < nchunks; ++kc) {
-    if (kc >= 0) {
+    if (kc >= 0 && !((FISR_ABL & 1) && kc >= 1)) {
       __syncthreads();  // every wave is done reading the previous chunk from LDS
 #pragma unroll
       for (int i = 0; i < NPIX_IT; ++i) {
@@ -235,13 +318,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       }
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
-        const int r = (tid >> 2) + i * (CONV_THREADS / 4);
+        const int r = wrec_lo + i * (CONV_THREADS / 4);
         if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
           *reinterpret_cast<uint4*>(s_w + r * REC_BYTES + wslot * 16) = rwt[i];
       }
       __syncthreads();
     }
-    if (kc + 1 < nchunks) {  // global -> registers for the next chunk
+    if (kc + 1 < nchunks && !((FISR_ABL & 1) && kc >= 0)) {  // global -> registers for the next chunk
       const T* src;
       int csrc, coff;
       const int c0 = (kc + 1) * CC;
@@ -268,7 +351,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       const char* wsrc = (const char*)p.wpk + (size_t)(kc + 1) * 9 * p.CoutPad * CHUNK_BYTES;
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
-        const int r = (tid >> 2) + i * (CONV_THREADS / 4);  // r = tap*BN + n
+        const int r = wrec_lo + i * (CONV_THREADS / 4);  // r = tap*BN + n
         const int tap = r / BN, n = r - tap * BN;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
@@ -276,31 +359,91 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
         rwt[i] = v;
       }
     }
-    if (kc < 0) continue;
+    if (kc < 0 || (FISR_ABL & 8)) continue;
 
     // ---- 9 taps x KG k-groups of MFMA on the staged chunk ----
+    // Fragments are double-buffered in registers: the ds_reads of step s+1 are issued before the
+    // MFMAs of step s (FISR_SCHED 1: order pinned with sched_barrier; 2: reads interleaved one per
+    // MFMA with sched_group_barrier; 0: left to the compiler, which waits on every tap's reads).
+    constexpr int NS = P::KG * 9;
+    auto load_frags = [&](int s_, Frag (&fa)[2][P::NF], Frag (&fb)[NT][P::NF]) {
+      const int kg = s_ / 9, tap = s_ % 9;
+      const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-    for (int kg = 0; kg < P::KG; ++kg) {
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        Frag a[2][P::NF], b[NT][P::NF];
+        for (int f = 0; f < P::NF; ++f)
+          fa[m][f] = *reinterpret_cast<const Frag*>(a_base + ((m + dy) * HALO_W + dx) * REC_BYTES + kg * 32 + f * 32);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int f = 0; f < P::NF; ++f)
-            a[m][f] = *reinterpret_cast<const Frag*>(a_base + ((m + dy) * HALO_W + dx) * REC_BYTES + kg * 32 + f * 32);
+        for (int f = 0; f < P::NF; ++f)
+          fb[j][f] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
+    };
+#if (FISR_ABL & 2)   // ablation: one fragment read per chunk (no LDS read traffic in the tap loop)
+    {
+      Frag fa[2][P::NF], fb[NT][P::NF];
+      load_frags(0, fa, fb);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int f = 0; f < P::NF; ++f)
-            b[j][f] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) P::mma(acc[m][j], a[m], b[j]);
+      for (int s_ = 0; s_ < NS; ++s_) {
+        P::mma_tiles(acc, fa, fb);
+        asm volatile("" ::: "memory");
       }
     }
+#elif FISR_SCHED == 0
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      Frag fa[2][P::NF], fb[NT][P::NF];
+      load_frags(s_, fa, fb);
+      P::mma_tiles(acc, fa, fb);
+    }
+#else
+    Frag fa0[2][P::NF], fb0[NT][P::NF], fa1[2][P::NF], fb1[NT][P::NF];
+    load_frags(0, fa0, fb0);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_ += 2) {
+      if (s_ + 1 < NS) load_frags(s_ + 1, fa1, fb1);
+#if FISR_SCHED == 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) P::mma(acc[m][j], fa0[m], fb0[j]);
+#if FISR_SCHED == 1
+      __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+      for (int q = 0; q < (2 + NT) * P::NF; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);    // the remaining MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (s_ + 1 < NS) {
+        if (s_ + 2 < NS) load_frags(s_ + 2, fa0, fb0);
+#if FISR_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) P::mma(acc[m][j], fa1[m], fb1[j]);
+#if FISR_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+        for (int q = 0; q < (2 + NT) * P::NF; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    }
+#endif
   }
 
   // C/D layout of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -331,6 +474,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
         }
       }
     }
+  } else if (FISR_ABL & 4) {   // ablation: no epilogue (keep the accumulators alive)
+    float sacc = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[m][j][r];
+    if (sacc == 12345.678f) ((float*)p.out)[0] = sacc;
   } else {
     // ---- staged epilogue: acc + bias -> LDS [256 px][BN] fp32 -> per-lane 16-byte vectors ----
     float* s_o = reinterpret_cast<float*>(smem);

@@ -778,4 +778,65 @@ int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int
   return 0;
 }
 
+// Micro-benchmark of one conv shape (not part of the product path): allocates its own buffers,
+// runs `iters` launches back to back on the default stream and returns the mean microseconds per
+// launch (HIP events) in *out_us.  Weights/activations are pseudo-random bit patterns.
+int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters,
+                    double* out_us) {
+  if (!prec_ok(precision) || !out_us || iters < 1) return fail(nullptr, FISR_EINVAL, "fisr_bench_conv: bad argument");
+  const int cc = prec_chunk(precision);
+  if (cin % cc || cout % 8) return fail(nullptr, FISR_EINVAL, "fisr_bench_conv: channels must be whole chunks");
+  const size_t abytes = precision == FISR_PREC_F16 ? 2 : 4;
+  const size_t in_b = (size_t)n * h * w * cin * abytes, out_b = (size_t)n * h * w * cout * abytes;
+  ConvW cw;
+  cw.ci = cin; cw.co = cout;
+  cw.w.resize((size_t)9 * cin * cout);
+  cw.b.assign(cout, 0.01f);
+  uint32_t st = 12345u;
+  for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw); });
+  if (rc) return rc;
+  void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
+  HIP_OK(nullptr, hipMalloc(&d_in, in_b));
+  HIP_OK(nullptr, hipMalloc(&d_out, out_b));
+  if (with_res) HIP_OK(nullptr, hipMalloc(&d_res, out_b));
+  {
+    std::vector<uint16_t> hbuf(1 << 20);
+    for (auto& v : hbuf) { st = st * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((st >> 12) & 0x3ff)) ^ (uint16_t)((st >> 31) << 15); }
+    for (size_t o = 0; o < in_b; o += hbuf.size() * 2)
+      HIP_OK(nullptr, hipMemcpy((char*)d_in + o, hbuf.data(), std::min(hbuf.size() * 2, in_b - o), hipMemcpyHostToDevice));
+    if (d_res)
+      for (size_t o = 0; o < out_b; o += hbuf.size() * 2)
+        HIP_OK(nullptr, hipMemcpy((char*)d_res + o, hbuf.data(), std::min(hbuf.size() * 2, out_b - o), hipMemcpyHostToDevice));
+  }
+  ConvArgs a;
+  a.in0 = d_in; a.in1 = nullptr; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = d_res; a.out = d_out;
+  a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
+  a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
+  a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
+  a.d2s = (flags & FISR_CONV_D2S) != 0;
+  a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
+  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0;
+  hipEvent_t e0, e1;
+  HIP_OK(nullptr, hipEventCreate(&e0));
+  HIP_OK(nullptr, hipEventCreate(&e1));
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; ++i)
+    e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
+  HIP_OK(nullptr, hipDeviceSynchronize());
+  HIP_OK(nullptr, hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters && e == hipSuccess; ++i)
+    e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
+  HIP_OK(nullptr, hipEventRecord(e1, nullptr));
+  HIP_OK(nullptr, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_OK(nullptr, hipEventElapsedTime(&ms, e0, e1));
+  *out_us = (double)ms * 1e3 / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
+  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b);
+  if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
 }  // extern "C"

@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SO_PATH = os.path.join(_PKG, "libfisr_hip.so")
+SO_PATH = os.environ.get("FISR_HIP_SO") or os.path.join(_PKG, "libfisr_hip.so")   # override: A/B kernel builds
 CSRC = os.path.join(_PKG, "csrc")
 
 PREC_F32, PREC_F16, PREC_BF16X3 = 0, 1, 2
@@ -24,7 +24,7 @@ EXPORTS = [
     "fisr_finalize_weights", "fisr_num_variables_set", "fisr_workspace_bytes", "fisr_forward",
     "fisr_profile_enable", "fisr_profile_reset", "fisr_profile_read", "fisr_warp", "fisr_pack_input",
     "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_op_conv3x3", "fisr_op_maxpool2",
-    "fisr_op_upsample2",
+    "fisr_op_upsample2", "fisr_bench_conv",
 ]
 
 
@@ -100,6 +100,7 @@ def lib():
                                   c_int, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_op_maxpool2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_op_upsample2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_bench_conv.argtypes = [c_int] * 9 + [POINTER(c_double)]
     _lib = L
     return L
 

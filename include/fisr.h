@@ -146,6 +146,12 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
 int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
 int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
 
+/* Micro-benchmark of one conv shape (diagnostics; not on the product path): runs `iters`
+ * launches of the conv kernel on self-allocated buffers and returns the mean microseconds per
+ * launch in *out_us. */
+int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res,
+                    int iters, double* out_us);
+
 #ifdef __cplusplus
 }
 #endif
