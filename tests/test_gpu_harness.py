@@ -1,0 +1,117 @@
+"""GPU end-to-end tests of the reference's drivers (cfg1 of BASELINE.json: `main.py --phase test`
+on the 96x96 LR 5-frame crop of scene1) through the CLI mirror, against oracle-derived numbers."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import c_oracle as C          # noqa: E402
+import fisr_oracle as O       # noqa: E402
+from fisr_amd import io as fio  # noqa: E402
+from fisr_amd import main as fmain  # noqa: E402
+from fisr_amd import weights  # noqa: E402
+from fisr_amd.harness import ssim_pil  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def scene(tmp_path_factory, gold_dir, syn_weights, syn_blob):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = tmp_path_factory.mktemp("cfg1")
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    lr = root / "LR_LFR"; hr = root / "HR_HFR"; ck = root / "checkpoint_dir" / "FISRnet_exp1"
+    for d in (lr, hr, ck):
+        d.mkdir(parents=True)
+    for i in range(5):
+        fio.write_png(str(lr / f"LR_vid_1_fr_07171_seq_{2 * i + 1}.png"), g["frames"][i])
+    fio.write_flow(g["flows"], str(root / "flow.flo"))
+    fio.write_warp_file(str(root / "warp.npy"), g["warps"])
+    weights.save_npz(str(ck / "FISRnet-122000.npz"), syn_weights)
+    # expected predictions from the oracle (fp64), window by window, 1x1 patch
+    fl = O.merge_seq_dim(g["flows"])
+    wp = O.merge_seq_dim(g["warps"] / np.float32(255.))
+    preds = []
+    for s in range(3):
+        img9 = np.concatenate([g["frames"][s + k] for k in range(3)], axis=2)
+        inp = O.assemble_input(img9, fl[0, :, :, 4 * s:4 * s + 8], wp[0, :, :, 6 * s:6 * s + 12])
+        preds.append(O.tiled_forward(inp.astype(np.float32), None, (1, 1),
+                                     forward=lambda t: C.forward(t, syn_blob, True)[2]))
+    # pseudo ground truth: the 7 unique HR frames = oracle predictions + noise, quantised to uint8 PNGs
+    rng = np.random.default_rng(5)
+    gt = {}
+    for s in range(3):
+        for f in range(3):
+            k = 2 * s + f
+            if k not in gt:
+                gt[k] = np.clip(np.round((preds[s][..., 3 * f:3 * f + 3] + rng.normal(0, 0.01, (192, 192, 3))) * 255), 0, 255).astype(np.uint8)
+    for k in range(7):
+        fio.write_png(str(hr / f"HR_vid_1_fr_07171_seq_{k + 1:02d}.png"), gt[k])
+    return dict(root=root, preds=preds, gt=gt, g=g)
+
+
+def _args(scene, phase, extra=()):
+    r = scene["root"]
+    return ["--phase", phase, "--test_data_path", str(r / "LR_LFR"), "--test_label_path", str(r / "HR_HFR"),
+            "--test_flow_data_path", str(r / "flow.flo"), "--test_warped_data_path", str(r / "warp.npy"),
+            "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(r / "test_img_dir"),
+            "--text_dir", str(r / "text_dir"), "--log_dir", str(r / "logdir"),
+            "--test_patch", "(1,1)", "--test_input_size", "96,96", *extra]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_phase_test_cfg1(scene, prec, capsys):
+    from fisr_amd.fisrnet import FISRnet
+    args = fmain.parse_args(_args(scene, "test", ["--precision", prec]))
+    net = FISRnet(args)
+    res = net.test()
+    out = capsys.readouterr().out
+    assert "Success to read FISRnet-122000.npz" in out and "######### Test (average) test_PSNR" in out
+    # expected metrics from the oracle predictions, computed the reference's way (FISRnet.py:883-920)
+    fisr_psnr, sr_psnr, fisr_ssim, sr_ssim = [], [], [], []
+    for s in range(3):
+        p = scene["preds"][s]
+        ps, ss = [], []
+        for f in range(3):
+            gtf = scene["gt"][2 * s + f].astype(np.float64) / 255.
+            ps.append(O.compute_psnr(p[..., 3 * f:3 * f + 3], gtf, 1.0))
+            ss.append(ssim_pil(O.quantize_u8(p[..., 3 * f:3 * f + 3]), (gtf * 255).astype("uint8")))
+        fisr_psnr.append(ps[0]); sr_psnr.append(ps[1]); fisr_ssim.append(ss[0]); sr_ssim.append(ss[1])
+        if s == 2:
+            fisr_psnr.append(ps[2]); fisr_ssim.append(ss[2])
+    assert abs(res["FISR_PSNR"] - np.mean(fisr_psnr)) <= 0.02          # the reference tolerance
+    assert abs(res["SR_PSNR"] - np.mean(sr_psnr)) <= 0.02
+    assert abs(res["FISR_SSIM"] - np.mean(fisr_ssim)) <= 1e-3
+    assert abs(res["SR_SSIM"] - np.mean(sr_ssim)) <= 1e-3
+    # written PNGs: pred_<HR name minus 'HR_'> (FISRnet.py:906-910), later windows overwrite
+    out_dir = scene["root"] / "test_img_dir" / "FISRnet_exp1"
+    names = sorted(os.listdir(out_dir))
+    assert names == [f"pred_vid_1_fr_07171_seq_{k + 1:02d}.png" for k in range(7)]
+    last = fio.read_png(str(out_dir / "pred_vid_1_fr_07171_seq_07.png"))
+    exp = O.yuv_u8_to_rgb_u8(O.quantize_u8(scene["preds"][2][..., 6:9]))
+    assert (np.abs(last.astype(int) - exp.astype(int)) > 1).mean() < 1e-3   # +-1 LSB at truncation boundaries only
+    net.close()
+
+
+def test_phase_fisr_for_video(scene):
+    from fisr_amd.fisrnet import FISRnet
+    r = scene["root"]
+    # the video phase takes pair-wise flows [num_fr-1, 2, h, w, 2] and warps on the GPU
+    pair_flow = scene["g"]["flows"][0].reshape(4, 2, 96, 96, 2)
+    fio.write_flow(pair_flow, str(r / "pairs.flo"))
+    rc = fmain.main(["--phase", "FISR_for_video", "--frame_folder_path", str(r / "LR_LFR"), "--flow_file", str(r / "pairs.flo"),
+                     "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(r / "test_img_dir"),
+                     "--text_dir", str(r / "text_dir"), "--log_dir", str(r / "logdir"),
+                     "--FISR_test_patch", "1,1", "--FISR_input_size", "96,96", "--frame_num", "5", "--precision", "fp32"])
+    assert rc == 0
+    out_dir = r / "LR_LFR" / "FISR_frames"
+    names = sorted(os.listdir(out_dir))
+    assert names == sorted([f"pred_{k}.png" for k in range(7)] + [f"pred_YUV_{k}.png" for k in range(7)])
+    # same inputs as the test phase -> the YUV frame of the last window equals the oracle prediction (uint8)
+    yuv = fio.read_png(str(out_dir / "pred_YUV_6.png"))
+    exp = O.quantize_u8(scene["preds"][2][..., 6:9])
+    assert (np.abs(yuv.astype(int) - exp.astype(int)) > 1).mean() < 1e-3
+    assert (yuv != exp).mean() < 0.02
