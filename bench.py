@@ -123,8 +123,22 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     dom = max(convs, key=lambda p: p["ms"])
     tot_ms = sum(p["ms"] for p in prof)
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (scripts/gpu_profile.sh ->
+    # profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        tname = {"f32": "float", "f16": "_Float16", "bf16x3": "bsplit"}[dom["name"].split("<")[1].split(",")[0]]
+        nt = dom["name"].split("NT")[1][0]
+        key = f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in dom['name'] else 'false'}>"
+        if key in pmc:
+            traffic = round(pmc[key]["hbm_bytes_per_launch"] / 1e9, 4)
+    except (OSError, KeyError, IndexError, ValueError):
+        traffic = None
     return {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK[precision],
-            "unit": "TFLOP/s", "frac": round(ach / PEAK[precision], 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK[precision], 4), "traffic": traffic,
+            "traffic_unit": "GB of HBM per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
             "mfma_issue_frac": round(MFMA_PER_PRODUCT[precision] * ach / PEAK[precision], 4),
             "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": int(dom["launches"]),
             "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
@@ -228,7 +242,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle
-        ch, cw = 128, 192
+        ch, cw = 256, 384
         x = np.random.default_rng(3).random((1, ch, cw, 29)).astype(np.float32)
         blob = c_oracle.pack_blob(W)
         c_oracle.forward(x[:, :32, :32], blob, double=False)           # warm up threads

@@ -49,15 +49,6 @@
 #ifndef FISR_MMAORDER
 #define FISR_MMAORDER 1
 #endif
-#ifndef FISR_STAGGER
-#define FISR_STAGGER 0
-#endif
-#ifndef FISR_PKRELU
-#define FISR_PKRELU 0
-#endif
-#ifndef FISR_XCD
-#define FISR_XCD 0
-#endif
 
 namespace fisr {
 
@@ -173,18 +164,6 @@ template <> struct Prec<bsplit> {
   static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused (pair form below)
   // relu of 8 split values: a value is negative iff its hi part is (lo is a correction of hi)
   static __device__ __forceinline__ void relu_pair(uint4& hi, uint4& lo) {
-#if FISR_PKRELU
-    // bf16 bit patterns compared as packed int16: negative value <=> sign bit <=> negative int16
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    s16x2* h = reinterpret_cast<s16x2*>(&hi);
-    s16x2* l = reinterpret_cast<s16x2*>(&lo);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const s16x2 neg = h[i] >> 15;          // 0xffff in negative halves (v_pk_ashrrev_i16)
-      h[i] = h[i] & ~neg;
-      l[i] = l[i] & ~neg;
-    }
-#else
     uint32_t* h = reinterpret_cast<uint32_t*>(&hi);
     uint32_t* l = reinterpret_cast<uint32_t*>(&lo);
 #pragma unroll
@@ -193,7 +172,6 @@ template <> struct Prec<bsplit> {
       h[i] &= m;
       l[i] &= m;
     }
-#endif
   }
 };
 
@@ -237,30 +215,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
 
   const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
   const int tiles_y = (p.H + TILE_H - 1) / TILE_H;
-  // XCD-aware mapping: workgroup b is observed to run on XCD b % 8 (speed only, never
-  // correctness).  Give every XCD a contiguous band of tiles so that neighbouring tiles (which
-  // share halo rows/columns) hit the same 4 MiB L2 instead of re-fetching across XCDs.
   int t = blockIdx.x;
-  if (FISR_XCD) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-    const int xcd = t & 7, loc = t >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int nb = t / tiles_y;
   const int x0 = tx * TILE_W, y0 = ty * TILE_H;
   const int n0 = blockIdx.y * BN;
-
-#if FISR_STAGGER
-  // Two workgroups share a CU and, being identical, run in lockstep: their LDS-fill/barrier
-  // phases coincide (matrix pipe idle) and their MFMA phases contend.  Delaying the second
-  // workgroup of every CU once, in the first dispatch round, by about half a chunk period puts
-  // the pair in anti-phase for the rest of the launch (a finishing workgroup's successor inherits
-  // its phase).  Placement heuristic (block b -> XCD b%8, CUs filled round-robin, so blocks b and
-  // b+256 share a CU): speed only, never correctness.
-  if (blockIdx.y == 0 && blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(80);
-#endif
 
   f32x16 acc[2][NT];
 #pragma unroll

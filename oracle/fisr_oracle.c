@@ -72,11 +72,13 @@ static SUF(T) SUF(conv)(SUF(T) x, const float* wt, const float* bias, int co, in
   SUF(T) y = SUF(talloc)(x.n, H, W, co);
   REAL* wr = (REAL*)malloc(sizeof(REAL) * 9 * (size_t)ci * co);
   for (size_t i = 0; i < 9 * (size_t)ci * co; ++i) wr[i] = (REAL)wt[i];
-#pragma omp parallel for collapse(2) schedule(static)
+  const int nxb = (W + 3) / 4;
+#pragma omp parallel for collapse(3) schedule(static)
   for (int n = 0; n < x.n; ++n)
     for (int yy = 0; yy < H; ++yy) {
-      REAL acc[4][512];
-      for (int x0 = 0; x0 < W; x0 += 4) {
+      for (int xb = 0; xb < nxb; ++xb) {
+        REAL acc[4][512];
+        const int x0 = xb * 4;
         const int nb = (W - x0) < 4 ? (W - x0) : 4;
         for (int q = 0; q < nb; ++q)
           for (int o = 0; o < co; ++o) acc[q][o] = (REAL)bias[o];

@@ -46,3 +46,31 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
             print(f"{k}  dispatches {dur.get(k, (0, 0))[0]}  total_ms {dur.get(k, (0, 0))[1] / 1e6:.3f}")
             for cn, (c, s) in sorted(agg[k].items()):
                 print(f"    {cn:30s} sum {s:.6g}   per_dispatch {s / max(c, 1):.6g}")
+
+# ---- HBM traffic per launch of each kernel (for bench.py's roofline.traffic) ----
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide
+# coalesced streaming reads (MI355X_MICROARCH.md, HBM section) -> doubled here.
+import json
+
+traffic = {}
+for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+    cur = sqlite3.connect(f).cursor()
+    try:
+        rows = list(cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
+                                "where counter_name in ('FETCH_SIZE','WRITE_SIZE') group by name, counter_name"))
+    except sqlite3.Error:
+        continue
+    for n, cn, c, s in rows:
+        traffic.setdefault(short(n), {})[cn] = {"dispatches": c, "kib_per_dispatch": s / max(c, 1)}
+out = {}
+for k, d in traffic.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        out[k] = {"fetch_bytes_per_launch_raw": d["FETCH_SIZE"]["kib_per_dispatch"] * 1024,
+                  "fetch_bytes_per_launch_corrected_x2": d["FETCH_SIZE"]["kib_per_dispatch"] * 2048,
+                  "write_bytes_per_launch": d["WRITE_SIZE"]["kib_per_dispatch"] * 1024,
+                  "hbm_bytes_per_launch": d["FETCH_SIZE"]["kib_per_dispatch"] * 2048 + d["WRITE_SIZE"]["kib_per_dispatch"] * 1024,
+                  "dispatches": d["FETCH_SIZE"]["dispatches"]}
+if out:
+    with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("\n## pmc_traffic.json written:", ", ".join(out))
