@@ -10,9 +10,11 @@
 //   channel scatter into the 9-ch prediction (FISRnet.py:107-108 split/concat)
 //
 // GEMM view: M = output pixels, N = output channels, K = 9 taps x Cin.
-// Workgroup = 256 threads = 4 wave64; output tile = 8 rows x 32 cols x BN channels
-// (BN = 32*NT).  Each wave owns 2 image rows (2 M-subtiles of 32 pixels) x NT
-// N-subtiles of 32 channels = 2*NT accumulators of the 32x32 MFMA (16 VGPR each).
+// Output tile per workgroup = 8 rows x 32 cols x BN channels (BN = 32*NT).  A wave owns MR
+// image rows (MR M-subtiles of 32 pixels) x NT N-subtiles of 32 channels = MR*NT accumulators
+// of the 32x32 MFMA (16 VGPR each); the workgroup has 8/MR waves (MR = 1: 512 threads, two
+// waves of the SAME workgroup per SIMD hide each other's LDS/barrier latency in the K loop;
+// MR = 2: 256 threads, fewer LDS fragment reads per MFMA).
 // The K loop walks the input channels in 64-byte chunks: the (8+2)x(32+2) halo tile of
 // the chunk and the 9 x BN x chunk weights are staged in LDS once, then all 9 taps read
 // shifted windows of the same halo tile (9x LDS reuse of every input byte).  One
@@ -40,14 +42,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef FISR_SCHED
-#define FISR_SCHED 0
-#endif
+// FISR_ABL: performance-diagnosis ablations (WRONG results): bit 1 no global loads/LDS fills after
+// the first chunk, 2 no LDS fragment reads in the tap loop, 4 no epilogue, 8 no MFMAs.
 #ifndef FISR_ABL
 #define FISR_ABL 0
-#endif
-#ifndef FISR_MMAORDER
-#define FISR_MMAORDER 1
 #endif
 
 namespace fisr {
@@ -67,7 +65,6 @@ constexpr int HALO_W = TILE_W + 2;
 constexpr int HALO_PIX = (TILE_H + 2) * HALO_W;  // 340
 constexpr int CHUNK_BYTES = 64;                  // channel bytes staged per K chunk
 constexpr int REC_BYTES = CHUNK_BYTES + 16;      // LDS record stride (odd number of 16-B slots)
-constexpr int CONV_THREADS = 256;
 
 __device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
@@ -92,10 +89,10 @@ template <> struct Prec<float> {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, acc, 0, 0, 0);
   }
-  template <int NT_>
-  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[2][NT_], const Frag (&a)[2][NF], const Frag (&b)[NT_][NF]) {
+  template <int MR_, int NT_>
+  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[MR_][NT_], const Frag (&a)[MR_][NF], const Frag (&b)[NT_][NF]) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MR_; ++m)
 #pragma unroll
       for (int j = 0; j < NT_; ++j) mma(acc[m][j], a[m], b[j]);
   }
@@ -116,10 +113,10 @@ template <> struct Prec<_Float16> {
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
   }
-  template <int NT_>
-  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[2][NT_], const Frag (&a)[2][NF], const Frag (&b)[NT_][NF]) {
+  template <int MR_, int NT_>
+  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[MR_][NT_], const Frag (&a)[MR_][NF], const Frag (&b)[NT_][NF]) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MR_; ++m)
 #pragma unroll
       for (int j = 0; j < NT_; ++j) mma(acc[m][j], a[m], b[j]);
   }
@@ -144,22 +141,15 @@ template <> struct Prec<bsplit> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);  // hi * hi
   }
   // Term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependency).
-  template <int NT_>
-  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[2][NT_], const Frag (&a)[2][NF], const Frag (&b)[NT_][NF]) {
-#if FISR_MMAORDER
+  template <int MR_, int NT_>
+  static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[MR_][NT_], const Frag (&a)[MR_][NF], const Frag (&b)[NT_][NF]) {
 #pragma unroll
     for (int term = 0; term < 3; ++term)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MR_; ++m)
 #pragma unroll
         for (int j = 0; j < NT_; ++j)
           acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][term == 0 ? 1 : 0], b[j][term == 1 ? 1 : 0], acc[m][j], 0, 0, 0);
-#else
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int j = 0; j < NT_; ++j) mma(acc[m][j], a[m], b[j]);
-#endif
   }
   static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused (pair form below)
   // relu of 8 split values: a value is negative iff its hi part is (lo is a correction of hi)
@@ -189,19 +179,22 @@ struct ConvArgs {
   int d2s_shift;     // log2(Cout/4) when d2s (Cout/4 must be a power of two)
   // channel scatter of the direct store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
   int out_cstride, out_coff, out_split, out_gap;
+  // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
+  unsigned long long* trace;
 };
 
 template <typename T, int NT> constexpr size_t conv_lds_bytes() {
   return (size_t)HALO_PIX * REC_BYTES + (size_t)9 * 32 * NT * REC_BYTES;
 }
 
-template <typename T, int NT, bool OUT_F32>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const ConvArgs p) {
+template <typename T, int NT, bool OUT_F32, int MR>
+__global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_mfma_kernel(const ConvArgs p) {
   typedef Prec<T> P;
   typedef typename P::Frag Frag;
   constexpr int CC = P::CC;
   constexpr int BN = 32 * NT;
   constexpr int EPU = 16 / sizeof(T);  // T elements per 16-byte unit (bsplit counts as 4-byte slots)
+  constexpr int NTHR = 64 * (TILE_H / MR);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_in = smem;
@@ -222,9 +215,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
   const int x0 = tx * TILE_W, y0 = ty * TILE_H;
   const int n0 = blockIdx.y * BN;
 
-  f32x16 acc[2][NT];
+  unsigned long long t_start = 0, t_main = 0;
+  if (p.trace) t_start = __builtin_readcyclecounter();
+
+  f32x16 acc[MR][NT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -232,12 +228,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
 
   // ---- loader geometry (identical for every K chunk) ----
   // The halo tile of a chunk is HALO_PIX records of four 16-byte slots.  Normal types: unit
-  // u = tid + i*256 -> pixel u>>2, slot u&3.  bsplit: a thread loads the hi slot s (0/1) and
-  // the matching lo slot s+2 of one pixel (relu needs both): pixel (tid>>1) + i*128.
-  constexpr int NIN = (HALO_PIX * 4 + CONV_THREADS - 1) / CONV_THREADS;  // 6 x 16 B per thread
-  constexpr int NWT = (9 * BN * 4 + CONV_THREADS - 1) / CONV_THREADS;    // 9 (BN=64) / 5 (BN=32)
-  constexpr int NPIX_IT = P::PAIR_LOAD ? NIN / 2 : NIN;                  // pixel iterations
-  constexpr int PIX_STEP = P::PAIR_LOAD ? CONV_THREADS / 2 : CONV_THREADS / 4;
+  // u = tid + i*NTHR -> pixel u>>2, slot u&3.  bsplit: a thread loads the hi slot s (0/1) and
+  // the matching lo slot s+2 of one pixel (relu needs both): pixel (tid>>1) + i*NTHR/2.
+  constexpr int NPIX_IT = P::PAIR_LOAD ? (HALO_PIX * 2 + NTHR - 1) / NTHR : (HALO_PIX * 4 + NTHR - 1) / NTHR;
+  constexpr int NIN = P::PAIR_LOAD ? 2 * NPIX_IT : NPIX_IT;     // 16-byte registers for the halo tile
+  constexpr int NWT = (9 * BN * 4 + NTHR - 1) / NTHR;           // ... and for the weight slab
+  constexpr int PIX_STEP = P::PAIR_LOAD ? NTHR / 2 : NTHR / 4;
   const int slot = P::PAIR_LOAD ? (tid & 1) : (tid & 3);
   const int pix_lo = P::PAIR_LOAD ? (tid >> 1) : (tid >> 2);
   const int wslot = tid & 3;
@@ -252,7 +248,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
     in_pix[i] = ok ? (nb * p.H + gy) * p.W + gx : -1;
   }
   uint4 rin[NIN], rwt[NWT];
-  const char* a_base = s_in + ((wave * 2) * HALO_W + li) * REC_BYTES + kh * 16;
+  const char* a_base = s_in + ((wave * MR) * HALO_W + li) * REC_BYTES + kh * 16;
   const char* b_base = s_w + li * REC_BYTES + kh * 16;
   const int nchunks = (p.C0 + p.C1) / CC;
 
@@ -278,8 +274,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       }
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
-        const int r = wrec_lo + i * (CONV_THREADS / 4);
-        if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
+        const int r = wrec_lo + i * (NTHR / 4);
+        if (NWT * NTHR == 9 * BN * 4 || r < 9 * BN)
           *reinterpret_cast<uint4*>(s_w + r * REC_BYTES + wslot * 16) = rwt[i];
       }
       __syncthreads();
@@ -311,10 +307,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       const char* wsrc = (const char*)p.wpk + (size_t)(kc + 1) * 9 * p.CoutPad * CHUNK_BYTES;
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
-        const int r = wrec_lo + i * (CONV_THREADS / 4);  // r = tap*BN + n
+        const int r = wrec_lo + i * (NTHR / 4);  // r = tap*BN + n
         const int tap = r / BN, n = r - tap * BN;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (NWT * CONV_THREADS == 9 * BN * 4 || r < 9 * BN)
+        if (NWT * NTHR == 9 * BN * 4 || r < 9 * BN)
           v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)tap * p.CoutPad + n0 + n) * CHUNK_BYTES + wslot * 16);
         rwt[i] = v;
       }
@@ -322,15 +318,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
     if (kc < 0 || (FISR_ABL & 8)) continue;
 
     // ---- 9 taps x KG k-groups of MFMA on the staged chunk ----
-    // Fragments are double-buffered in registers: the ds_reads of step s+1 are issued before the
-    // MFMAs of step s (FISR_SCHED 1: order pinned with sched_barrier; 2: reads interleaved one per
-    // MFMA with sched_group_barrier; 0: left to the compiler, which waits on every tap's reads).
     constexpr int NS = P::KG * 9;
-    auto load_frags = [&](int s_, Frag (&fa)[2][P::NF], Frag (&fb)[NT][P::NF]) {
+    auto load_frags = [&](int s_, Frag (&fa)[MR][P::NF], Frag (&fb)[NT][P::NF]) {
       const int kg = s_ / 9, tap = s_ % 9;
       const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int f = 0; f < P::NF; ++f)
           fa[m][f] = *reinterpret_cast<const Frag*>(a_base + ((m + dy) * HALO_W + dx) * REC_BYTES + kg * 32 + f * 32);
@@ -340,9 +333,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
         for (int f = 0; f < P::NF; ++f)
           fb[j][f] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
     };
-#if (FISR_ABL & 2)   // ablation: one fragment read per chunk (no LDS read traffic in the tap loop)
+#if (FISR_ABL & 2)
     {
-      Frag fa[2][P::NF], fb[NT][P::NF];
+      Frag fa[MR][P::NF], fb[NT][P::NF];
       load_frags(0, fa, fb);
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_) {
@@ -350,62 +343,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
         asm volatile("" ::: "memory");
       }
     }
-#elif FISR_SCHED == 0
+#else
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
-      Frag fa[2][P::NF], fb[NT][P::NF];
+      Frag fa[MR][P::NF], fb[NT][P::NF];
       load_frags(s_, fa, fb);
       P::mma_tiles(acc, fa, fb);
-    }
-#else
-    Frag fa0[2][P::NF], fb0[NT][P::NF], fa1[2][P::NF], fb1[NT][P::NF];
-    load_frags(0, fa0, fb0);
-#pragma unroll
-    for (int s_ = 0; s_ < NS; s_ += 2) {
-      if (s_ + 1 < NS) load_frags(s_ + 1, fa1, fb1);
-#if FISR_SCHED == 1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) P::mma(acc[m][j], fa0[m], fb0[j]);
-#if FISR_SCHED == 1
-      __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-      for (int q = 0; q < (2 + NT) * P::NF; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);    // the remaining MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      if (s_ + 1 < NS) {
-        if (s_ + 2 < NS) load_frags(s_ + 2, fa0, fb0);
-#if FISR_SCHED == 1
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) P::mma(acc[m][j], fa1[m], fb1[j]);
-#if FISR_SCHED == 1
-        __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-        for (int q = 0; q < (2 + NT) * P::NF; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
     }
 #endif
   }
 
+  if (p.trace) t_main = __builtin_readcyclecounter();
   // C/D layout of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r&3) + 8*(r>>2) + 4*(lane>>5).
   if constexpr (OUT_F32) {
     // ---- direct epilogue (the 3/6-channel heads): bias, relu, channel-scatter fp32 store ----
@@ -419,8 +367,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       const int nmap = n + p.out_coff + (n >= p.out_split ? p.out_gap : 0);
       const int step = p.out_cstride;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const int y = y0 + wave * 2 + m;
+      for (int m = 0; m < MR; ++m) {
+        const int y = y0 + wave * MR + m;
         if (y >= p.H) continue;
         const size_t pix = (size_t)(nb * p.H + y) * p.W + xb;
         float* ob = (float*)p.out + pix * (size_t)step + nmap;
@@ -437,7 +385,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
   } else if (FISR_ABL & 4) {   // ablation: no epilogue (keep the accumulators alive)
     float sacc = 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -445,27 +393,53 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
     if (sacc == 12345.678f) ((float*)p.out)[0] = sacc;
   } else {
     // ---- staged epilogue: acc + bias -> LDS [256 px][BN] fp32 -> per-lane 16-byte vectors ----
+    // Every thread owns NU units of UC consecutive channels of one pixel.  The residual vectors
+    // of ALL its units are requested in one go right after the accumulators went to LDS (one
+    // exposed HBM/L2 latency instead of one per unit), then add / relu / convert / 16-byte stores.
+    constexpr int UC = P::UC;                 // channels per unit
+    constexpr int UPP = BN / UC;              // units per pixel
+    constexpr int NU = TILE_H * TILE_W * UPP / NTHR;
+    constexpr int RV = P::PAIR_LOAD ? 2 : 1;  // 16-byte residual vectors per unit
+    const int cq_shift = p.d2s_shift;
     float* s_o = reinterpret_cast<float*>(smem);
     __syncthreads();  // all waves are done with the last chunk's LDS reads
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const float bv = p.bias[n0 + j * 32 + li];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int col = (r & 3) + 8 * (r >> 2) + 4 * kh;
-          s_o[((wave * 2 + m) * TILE_W + col) * BN + j * 32 + li] = acc[m][j][r] + bv;
+          s_o[((wave * MR + m) * TILE_W + col) * BN + j * 32 + li] = acc[m][j][r] + bv;
         }
     }
+    uint4 rres[NU][RV];
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        const int u = tid + i * NTHR;
+        const int px = u / UPP, cu = u - px * UPP;
+        const int y = y0 + px / TILE_W, x = x0 + (px & (TILE_W - 1));
+        const int n = n0 + cu * UC;
+#pragma unroll
+        for (int k = 0; k < RV; ++k) rres[i][k] = make_uint4(0u, 0u, 0u, 0u);
+        if (y < p.H && x < p.W && n < p.Cout) {
+          const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
+          if constexpr (P::PAIR_LOAD) {
+            const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4 + ((n >> 3) & 1) * 16;
+            rres[i][0] = *reinterpret_cast<const uint4*>(rb);
+            rres[i][1] = *reinterpret_cast<const uint4*>(rb + 32);
+          } else {
+            rres[i][0] = *reinterpret_cast<const uint4*>((const T*)p.res + gp * p.Cout + n);
+          }
+        }
+      }
+    }
     __syncthreads();
-    constexpr int UC = P::UC;                 // channels per unit
-    constexpr int UPP = BN / UC;              // units per pixel
-    constexpr int NU = TILE_H * TILE_W * UPP / CONV_THREADS;
-    const int cq_shift = p.d2s_shift;
-#pragma unroll 4
+#pragma unroll
     for (int i = 0; i < NU; ++i) {
-      const int u = tid + i * CONV_THREADS;
+      const int u = tid + i * NTHR;
       const int px = u / UPP, cu = u - px * UPP;
       const int row = px / TILE_W, col = px - row * TILE_W;
       const int y = y0 + row, x = x0 + col;
@@ -490,7 +464,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       }
       if constexpr (sizeof(T) == 4 && !P::PAIR_LOAD) {  // float
         if (p.res) {
-          const f32x4 rv = *reinterpret_cast<const f32x4*>((const float*)p.res + gp * p.Cout + n);
+          const f32x4 rv = __builtin_bit_cast(f32x4, rres[i][0]);
           v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
         }
         if (p.relu_out) {
@@ -501,7 +475,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
         *reinterpret_cast<f32x4*>((float*)p.out + oel) = o;
       } else if constexpr (sizeof(T) == 2) {  // fp16
         if (p.res) {
-          const f16x8 rv = *reinterpret_cast<const f16x8*>((const _Float16*)p.res + gp * p.Cout + n);
+          const f16x8 rv = __builtin_bit_cast(f16x8, rres[i][0]);
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
         }
@@ -512,11 +486,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
       } else {  // bsplit: channel c of group g lives at byte (g*64 + (c&15)*2) [hi] and +32 [lo]
         const int half = (n >> 3) & 1;
         if (p.res) {
-          const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4 + half * 16;
-          const uint4 rh = *reinterpret_cast<const uint4*>(rb);
-          const uint4 rl = *reinterpret_cast<const uint4*>(rb + 32);
-          const uint16_t* h16 = reinterpret_cast<const uint16_t*>(&rh);
-          const uint16_t* l16 = reinterpret_cast<const uint16_t*>(&rl);
+          const uint16_t* h16 = reinterpret_cast<const uint16_t*>(&rres[i][0]);
+          const uint16_t* l16 = reinterpret_cast<const uint16_t*>(&rres[i][1]);
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32(h16[k]) + bf16_to_f32(l16[k]);
         }
@@ -530,6 +501,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_mfma_kernel(const Con
         *reinterpret_cast<uint4*>(ob + 32) = ol;
       }
     }
+  }
+  if (p.trace && tid == 0) {
+    unsigned long long* tr = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
+    tr[3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
   }
 }
 

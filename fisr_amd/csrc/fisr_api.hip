@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -211,11 +212,19 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw) {
 
 // ---- kernel launch helpers ----
 
-template <typename T, int NT, bool OUT_F32>
+// Rows per wave of the conv kernel: 1 = 512-thread workgroups, 2 = 256-thread.  Measured on
+// MI355X (r01): equal within 2 %; fp32 is marginally faster with 1, the 16-bit modes with 2.
+// FISR_CONV_MR=1|2 in the environment forces one build for A/B runs.
+template <typename T> inline int conv_mr() {
+  static int forced = [] { const char* e = getenv("FISR_CONV_MR"); return e ? (e[0] == '2' ? 2 : 1) : 0; }();
+  return forced ? forced : (std::is_same<T, float>::value ? 1 : 2);
+}
+
+template <typename T, int NT, bool OUT_F32, int MR>
 hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   static bool attr_done = false;
   constexpr size_t lds = conv_lds_bytes<T, NT>();
-  auto kern = conv3x3_mfma_kernel<T, NT, OUT_F32>;
+  auto kern = conv3x3_mfma_kernel<T, NT, OUT_F32, MR>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -224,14 +233,19 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles, a.CoutPad / (32 * NT));
-  hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (TILE_H / MR)), lds, st, a);
   return hipGetLastError();
 }
 
 template <typename T>
 hipError_t launch_conv(const ConvArgs& a, int nt, bool out_f32, hipStream_t st) {
-  if (nt == 1) return out_f32 ? launch_conv_variant<T, 1, true>(a, st) : launch_conv_variant<T, 1, false>(a, st);
-  return out_f32 ? launch_conv_variant<T, 2, true>(a, st) : launch_conv_variant<T, 2, false>(a, st);
+  const bool m1 = conv_mr<T>() == 1;
+  if (nt == 1) {
+    if (out_f32) return m1 ? launch_conv_variant<T, 1, true, 1>(a, st) : launch_conv_variant<T, 1, true, 2>(a, st);
+    return m1 ? launch_conv_variant<T, 1, false, 1>(a, st) : launch_conv_variant<T, 1, false, 2>(a, st);
+  }
+  if (out_f32) return m1 ? launch_conv_variant<T, 2, true, 1>(a, st) : launch_conv_variant<T, 2, true, 2>(a, st);
+  return m1 ? launch_conv_variant<T, 2, false, 1>(a, st) : launch_conv_variant<T, 2, false, 2>(a, st);
 }
 
 int prof_class(fisr_ctx* ctx, const std::string& name) {
@@ -360,7 +374,7 @@ struct Runner {
     a.d2s = (flags & FISR_CONV_D2S) != 0;
     a.d2s_shift = a.d2s ? ilog2(cw.co / 4) : 0;
     a.out_cstride = cstride ? cstride : cw.co;
-    a.out_coff = coff; a.out_split = split; a.out_gap = gap;
+    a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr;
     const double px = (double)n * h * w;
     char cls[96];
     snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
@@ -739,7 +753,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
-  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0;
+  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
   hipError_t e2 = hipStreamSynchronize(st);
@@ -816,7 +830,15 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
-  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0;
+  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr;
+  const char* trace_file = getenv("FISR_TRACE_FILE");
+  unsigned long long* d_trace = nullptr;
+  const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) * (cw.cout_pad / (32 * cw.nt));
+  if (trace_file) {
+    HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 32));
+    HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 32));
+    a.trace = d_trace;
+  }
   hipEvent_t e0, e1;
   HIP_OK(nullptr, hipEventCreate(&e0));
   HIP_OK(nullptr, hipEventCreate(&e1));
@@ -832,6 +854,12 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   float ms = 0.f;
   HIP_OK(nullptr, hipEventElapsedTime(&ms, e0, e1));
   *out_us = (double)ms * 1e3 / iters;
+  if (trace_file) {
+    std::vector<unsigned long long> tr(nblocks * 4);
+    HIP_OK(nullptr, hipMemcpy(tr.data(), d_trace, nblocks * 32, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_file, "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
+    (void)hipFree(d_trace);
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
   (void)hipFree(cw.d_w); (void)hipFree(cw.d_b);

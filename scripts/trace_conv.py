@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Record per-workgroup timestamps of one conv launch (diagnostics): python scripts/trace_conv.py out.bin n h w cin cout flags res [prec]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out, n, h, w, ci, co, fl, rs = sys.argv[1], *map(int, sys.argv[2:9])
+prec = {"fp32": 0, "fp16": 1, "bf16x3": 2}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
+os.environ["FISR_TRACE_FILE"] = out
+from fisr_amd import lib
+L = lib.lib()
+us = ctypes.c_double()
+rc = L.fisr_bench_conv(prec, n, h, w, ci, co, fl, rs, 3, ctypes.byref(us))
+print("rc", rc, "us", us.value, L.fisr_last_error(None) if rc else "")
