@@ -721,6 +721,24 @@ int fisr_sse_vs_u8(const float* pred, const uint8_t* gt, size_t count, double* o
   return 0;
 }
 
+int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, int coff, double* out_host, void* stream) {
+  if (!a || !b || !out_host || h < 7 || w < 7 || cstride < 3 || coff < 0 || coff + 3 > cstride)
+    return fail(nullptr, FISR_EINVAL, "fisr_ssim_u8: bad argument");
+  double* d = nullptr;
+  HIP_OK(nullptr, hipMalloc((void**)&d, sizeof(double)));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_OK(nullptr, hipMemsetAsync(d, 0, sizeof(double), st));
+  const size_t tiles = (size_t)(h / 7) * (w / 7) * 3;
+  hipLaunchKernelGGL(ssim_tiles_kernel, dim3(grid_for(tiles)), dim3(256), 0, st, a, b, h, w, cstride, coff, 7, d);
+  HIP_OK(nullptr, hipGetLastError());
+  double sum = 0;
+  HIP_OK(nullptr, hipMemcpyAsync(&sum, d, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_OK(nullptr, hipStreamSynchronize(st));
+  (void)hipFree(d);
+  *out_host = sum / (double)tiles;
+  return 0;
+}
+
 // ---- op-level entries ----
 
 int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
@@ -807,7 +825,8 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   cw.w.resize((size_t)9 * cin * cout);
   cw.b.assign(cout, 0.01f);
   uint32_t st = 12345u;
-  for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
+  const bool zero_fill = getenv("FISR_BENCH_ZERO") != nullptr;   // DVFS probe: zero operands draw less power
+  for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw); });
   if (rc) return rc;
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
@@ -816,7 +835,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   if (with_res) HIP_OK(nullptr, hipMalloc(&d_res, out_b));
   {
     std::vector<uint16_t> hbuf(1 << 20);
-    for (auto& v : hbuf) { st = st * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((st >> 12) & 0x3ff)) ^ (uint16_t)((st >> 31) << 15); }
+    for (auto& v : hbuf) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0 : ((uint16_t)(0x3c00 + ((st >> 12) & 0x3ff)) ^ (uint16_t)((st >> 31) << 15)); }
     for (size_t o = 0; o < in_b; o += hbuf.size() * 2)
       HIP_OK(nullptr, hipMemcpy((char*)d_in + o, hbuf.data(), std::min(hbuf.size() * 2, in_b - o), hipMemcpyHostToDevice));
     if (d_res)

@@ -314,4 +314,44 @@ __global__ void sse_u8_kernel(const float* __restrict__ pred, const uint8_t* __r
   }
 }
 
+// ---- SSIM as SSIM_PIL.compare_ssim computes it (call site FISRnet.py:890-891) ----
+// Non-overlapping tile x tile blocks (7x7) per channel of two uint8 images [H,W,3 of stride cstride]:
+// C1=(0.01*255)^2, C2=(0.03*255)^2, unbiased (N-1) variance/covariance; the mean over tiles and
+// channels is accumulated in double.  SSIM_PIL 1.0.10 is not in the reference tree: parity unpinned.
+__global__ void ssim_tiles_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int H, int W,
+                                  int cstride, int coff, int tile, double* __restrict__ acc) {
+#pragma clang fp contract(off)
+  const int th = H / tile, tw = W / tile;
+  const size_t total = (size_t)th * tw * 3;
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    const size_t t = i / 3;
+    const int tx = (int)(t % tw), ty = (int)(t / tw);
+    double sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+    for (int y = 0; y < tile; ++y)
+      for (int x = 0; x < tile; ++x) {
+        const size_t o = ((size_t)(ty * tile + y) * W + tx * tile + x) * cstride + coff + c;
+        const double va = (double)a[o], vb = (double)b[o];
+        sa += va; sb += vb; saa += va * va; sbb += vb * vb; sab += va * vb;
+      }
+    const double n = (double)(tile * tile);
+    const double ma = sa / n, mb = sb / n;
+    const double var_a = (saa - n * ma * ma) / (n - 1.0), var_b = (sbb - n * mb * mb) / (n - 1.0);
+    const double cov = (sab - n * ma * mb) / (n - 1.0);
+    const double c1 = (255 * 0.01) * (255 * 0.01), c2 = (255 * 0.03) * (255 * 0.03);
+    s += ((2.0 * ma * mb + c1) * (2.0 * cov + c2)) / ((ma * ma + mb * mb + c1) * (var_a + var_b + c2));
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ double part[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tsum = 0.0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tsum += part[k];
+    atomicAdd(acc, tsum);
+  }
+}
+
 }  // namespace fisr

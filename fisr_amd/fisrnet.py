@@ -214,6 +214,18 @@ class FISRnet:
         _lib.check(self._L.fisr_sse_vs_u8(_ptr(pred), _ptr(gt_u8), pred.numel(), ctypes.byref(out), _stream(self.device)))
         return out.value
 
+    def ssim_u8(self, a_u8, b_u8, coff: int = 0) -> float:
+        """SSIM_PIL-style SSIM (FISRnet.py:890-891) of the 3 channels starting at `coff` of two
+        uint8 device tensors [h,w,C]."""
+        a = a_u8.to(self.device).contiguous()
+        b = b_u8.to(self.device).contiguous()
+        if a.shape != b.shape or a.dim() != 3:
+            raise ValueError("ssim_u8: tensors must be [h,w,C] of equal shape")
+        out = ctypes.c_double()
+        _lib.check(self._L.fisr_ssim_u8(_ptr(a), _ptr(b), a.shape[0], a.shape[1], a.shape[2], coff,
+                                        ctypes.byref(out), _stream(self.device)))
+        return out.value
+
     # ------------------------------------------------------------------ tiled forward (FISRnet.py:845-883)
     def forward_tiled(self, inp, num_patch: Tuple[int, int] = (2, 2), tiles: Optional[Sequence[int]] = None,
                       full=None, timed: bool = False, batch_tiles: bool = True):

@@ -133,8 +133,10 @@ def run_test(net):
                     sse = net.sse_vs_u8(full[:, :, 3 * seq_i:3 * seq_i + 3].contiguous(), gt_d)
                     psnr[seq_i] = _psnr_from_sse(sse, gt.size)
                     # FISRnet.py:890-891: both sides as uint8(x*255) (GT: uint8 -> /255 -> *255 truncation)
+                    # (x/255*255 truncates to x-1 for some x: done on the host exactly like the reference)
                     gt_q = (np.clip(gt.astype(np.float64) / 255., 0, 1) * 255).astype("uint8")
-                    ssim[seq_i] = ssim_pil(yuv_host[:, :, 3 * seq_i:3 * seq_i + 3], gt_q)
+                    ssim[seq_i] = net.ssim_u8(yuv_u8[:, :, 3 * seq_i:3 * seq_i + 3],
+                                              torch.from_numpy(np.ascontiguousarray(gt_q)))
                 fio.write_png(os.path.join(test_img_dir, "pred_{}".format(name)), rgb_u8[seq_i].cpu().numpy())
             print(" <Test> [%4d/%4d]-th image, scene: %2d-%d, time: %4.4f(minutes), test_PSNR: fr1 (FI-SR) %.8f[dB], "
                   "fr2 (SR) %.8f[dB], fr3 (FI-SR) %.8f[dB]  " % (scene_i * 3 + sample_i, n_scenes * 3, scene_i, sample_i,

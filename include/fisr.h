@@ -132,6 +132,13 @@ int fisr_stitch(const float* tile, int th, int tw, int src_y, int src_x, int ch,
 int fisr_sse_vs_u8(const float* pred, const uint8_t* gt_u8, size_t count, double* out_host,
                    void* stream);
 
+/* SSIM the way the reference's SSIM_PIL.compare_ssim computes it on two uint8 images
+ * (FISRnet.py:890-891): non-overlapping 7x7 tiles per channel, C1=(0.01*255)^2, C2=(0.03*255)^2,
+ * unbiased variance, mean over tiles and the 3 channels.  a, b: [h,w,cstride] uint8, the frame's
+ * three channels start at channel `coff`.  Result in *out_host after synchronising the stream. */
+int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, int coff,
+                 double* out_host, void* stream);
+
 /* ---- op-level entry points (parity tests of the individual kernels) ---- */
 
 /* y = conv3x3_SAME(concat(in0,in1)) + b [+ res], ops.py:7-11.  Activations are float32

@@ -449,3 +449,17 @@ def test_full_size_tile_sparse_golden(net32, gold_dir):
     _, _, l3 = net32.model(torch.from_numpy(x).cuda(), want_all=False)
     got = l3[0, ::int(g["stride"]), ::int(g["stride"]), :].cpu().numpy()
     _report(got, g["l3_sparse"], F32_FWD_TOL, "544x992 tile sparse grid")
+
+
+def test_ssim_kernel_vs_oracle(net32):
+    """fisr_ssim_u8 (on-GPU SSIM_PIL restatement) vs the oracle's numpy restatement."""
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, 256, (45, 61, 9)).astype(np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    for coff in (0, 3, 6):
+        got = net32.ssim_u8(torch.from_numpy(a), torch.from_numpy(b), coff)
+        exp = O.ssim_pil(a[..., coff:coff + 3], b[..., coff:coff + 3])
+        assert abs(got - exp) < 1e-9, (coff, got, exp)
+    assert abs(net32.ssim_u8(torch.from_numpy(a), torch.from_numpy(a)) - 1.0) < 1e-12
+    flat = np.full((14, 14, 3), 7, np.uint8)                  # zero variance tiles
+    assert abs(net32.ssim_u8(torch.from_numpy(flat), torch.from_numpy(flat)) - 1.0) < 1e-12
