@@ -836,6 +836,10 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   {
     std::vector<uint16_t> hbuf(1 << 20);
     for (auto& v : hbuf) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0 : ((uint16_t)(0x3c00 + ((st >> 12) & 0x3ff)) ^ (uint16_t)((st >> 31) << 15)); }
+    if (const char* lm = getenv("FISR_BENCH_LOMASK")) {   // DVFS probe: fewer toggling bits in the lo planes
+      const uint16_t mask = (uint16_t)strtoul(lm, nullptr, 16);
+      for (size_t i = 0; i < hbuf.size(); ++i) if ((i >> 4) & 1) hbuf[i] &= mask;
+    }
     for (size_t o = 0; o < in_b; o += hbuf.size() * 2)
       HIP_OK(nullptr, hipMemcpy((char*)d_in + o, hbuf.data(), std::min(hbuf.size() * 2, in_b - o), hipMemcpyHostToDevice));
     if (d_res)
