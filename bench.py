@@ -12,7 +12,8 @@ inner loops of `FISRnet.test` / `FISR_for_video` (reference FISRnet.py:798-910),
 Default arithmetic is `bf16x3` (every value a hi+lo bf16 pair, 3 bf16 MFMAs per product, fp32
 accumulate: fp32-grade results, far inside the reference tolerance of +-0.02 dB); the exact-fp32
 MFMA path is timed next to it (`fp32_exact`) and the two outputs are compared at full size
-(`parity_vs_fp32`).  `--precision fp32` makes the exact path the headline.
+(`parity_vs_fp32`); `other_precisions` adds the fp16+fp8 split mode (`f16f8`, ~2^-15 per product,
+the fastest mode inside the reference tolerance).  `--precision fp32|f16f8` changes the headline.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank processes its own stack
 (frame-parallel, weights replicated, no data-path collective) -> weak scaling; timing is
@@ -34,10 +35,11 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 2 644 164 MAC)
-PEAK = {"fp32": 157.3, "fp16": 2500.0, "bf16x3": 2500.0}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
-MFMA_PER_PRODUCT = {"fp32": 1, "fp16": 1, "bf16x3": 3}
+PEAK = {"fp32": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+MFMA_PER_PRODUCT = {"fp32": 1, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
 DTYPE = {"fp32": "f32", "fp16": "f16 (f32 accumulate)",
-         "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)"}
+         "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
+         "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)"}
 UNIQUE_PER_STACK = 7                # 3 windows x 3 frames, overlaps counted once (FISRnet.py:913-920)
 
 
@@ -129,7 +131,7 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        tname = {"f32": "float", "f16": "_Float16", "bf16x3": "bsplit"}[dom["name"].split("<")[1].split(",")[0]]
+        tname = {"f32": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[dom["name"].split("<")[1].split(",")[0]]
         nt = dom["name"].split("NT")[1][0]
         key = f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in dom['name'] else 'false'}"
         hits = [v for k, v in pmc.items() if k.startswith(key)]
@@ -154,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "fp16"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16f8", "fp32", "fp16"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")
     ap.add_argument("--batch", default="stack", choices=["stack", "window", "tile"],
                     help="how many independent tiles go through one forward: the whole 5-frame stack "
@@ -215,29 +217,50 @@ def main():
                                  args.layer_profile if rank == 0 else None)
 
     fp32_exact = parity = None
-    if rank == 0 and world == 1 and args.precision != "fp32" and not args.no_fp32_ref:
+    other = {}
+    if rank == 0 and world == 1 and not args.no_fp32_ref:
         wl.step(net)
-        out_fast = wl.full.clone()
-        ref = FISRnet(device=f"cuda:{local_rank}", precision="fp32")
-        ref.set_weights(W)
-        wl.step(ref)                                      # warm-up + reference output
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        wl.step(ref)
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        rl = roofline_pass(ref, wl, "fp32", 1)
-        fp32_exact = {"value": round(UNIQUE_PER_STACK / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
-                      "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
-                      "roofline": {k: rl[k] for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us")} if rl else None}
-        a, b = out_fast.clamp(0, 1), wl.full.clamp(0, 1)
-        d = (a - b).double()
-        mse = float((d * d).mean())
-        parity = {"what": f"{args.precision} vs exact-fp32 output of the same step, all 3x2048x3840x9 values, clipped to [0,1]",
-                  "max_abs": float(d.abs().max()), "rms": mse ** 0.5,
-                  "psnr_db": round(10 * np.log10(1.0 / mse), 2) if mse > 0 else None,
-                  "uint8_mismatch_frac": float(((a * 255).to(torch.uint8) != (b * 255).to(torch.uint8)).double().mean())}
-        ref.close()
+        out_main = wl.full.clone()
+
+        def compare(a, b, what):
+            a, b = a.clamp(0, 1), b.clamp(0, 1)
+            d = (a - b).double()
+            mse = float((d * d).mean())
+            return {"what": what + ", all 3x%dx%dx9 values of the same step, clipped to [0,1]" % (wl.h * 2, wl.w * 2),
+                    "max_abs": float(d.abs().max()), "rms": mse ** 0.5,
+                    "psnr_db": round(10 * np.log10(1.0 / mse), 2) if mse > 0 else None,
+                    "uint8_mismatch_frac": float(((a * 255).to(torch.uint8) != (b * 255).to(torch.uint8)).double().mean())}
+
+        out_fp32 = out_main if args.precision == "fp32" else None
+        for alt in ("fp32", "f16f8", "bf16x3"):
+            if alt == args.precision:
+                continue
+            eng = FISRnet(device=f"cuda:{local_rank}", precision=alt)
+            eng.set_weights(W)
+            wl.step(eng)                                      # warm-up + this precision's output
+            torch.cuda.synchronize(dev)
+            out_alt = wl.full.clone()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                wl.step(eng)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / 2
+            rl = roofline_pass(eng, wl, alt, 1)
+            rec = {"value": round(UNIQUE_PER_STACK / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
+                   "dtype": DTYPE[alt],
+                   "roofline": {k: rl[k] for k in ("kernel", "achieved", "peak", "frac", "mfma_issue_frac", "avg_launch_us")} if rl else None}
+            if alt == "fp32":
+                out_fp32 = out_alt
+                fp32_exact = rec
+                parity = compare(out_main, out_fp32, f"{args.precision} vs exact fp32")
+            else:
+                if out_fp32 is not None:
+                    rec["parity_vs_fp32"] = compare(out_alt, out_fp32, f"{alt} vs exact fp32")
+                other[alt] = rec
+            eng.close()
+            del eng, out_alt
+            torch.cuda.empty_cache()
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -278,6 +301,7 @@ def main():
                        "forwards_per_s": round(world * 3 * args.steps / elapsed, 3),
                        "achieved_tflops_whole_step": round(world * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32_exact": fp32_exact, "parity_vs_fp32": parity,
+            "other_precisions": other or None,
         }
         print(json.dumps(line))
     if world > 1:

@@ -55,6 +55,54 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// Channel slot of the fp16 + fp8 split format ("f16f8").  Per pixel, per 16 channels, 64 bytes:
+//   [ 0..31] h   16 x fp16           h = fp16(x)
+//   [32..47] l8  16 x fp8 e4m3       l8 = fp8((x - h) * 2^14), clamped to +-448
+//   [48..63] h8  16 x fp8 e4m3       h8 = fp8(h), clamped to +-448 (operand of the cross terms only)
+// x ~ h + l8 * 2^-14 (>= 14 significant bits).  A product a*w is computed as
+//   a_h*w_h                       one v_mfma_f32_32x32x16_f16 per tap, and
+//   a_l*w_h + a_h*w_l             one v_mfma_scale_f32_32x32x64_f8f6f4 per PAIR of taps: K block 0 =
+//                                 {l8 | wh8}, K block 1 = {h8 | wl8}, each block carrying 16 channels of tap t
+//                                 (lanes 0-31) and 16 of tap t+1 (lanes 32-63); the 2^-14 / per-conv weight
+//                                 exponents ride on the block scales.  The cross terms are 2^-12 of the product, so 4-bit
+//                                 operands there cost ~2^-16 relative: 2.1 instead of 3 MFMA-units per product.
+struct fsplit { uint32_t raw; };
+constexpr int FS_LSHIFT = 14;
+
+__device__ __forceinline__ float fp8_clamp(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+// 8 floats -> 8 fp16 (16 B), 8 fp8 of the scaled remainder (8 B), 8 fp8 of h (8 B)
+__device__ __forceinline__ void fsplit_encode8(const float* v, uint4& h_out, uint2& l8_out, uint2& h8_out) {
+  _Float16 h[8];
+  float r[8], hf[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    h[k] = (_Float16)v[k];
+    hf[k] = (float)h[k];
+    r[k] = fp8_clamp((v[k] - hf[k]) * (float)(1 << FS_LSHIFT));
+    hf[k] = fp8_clamp(hf[k]);
+  }
+  h_out = __builtin_bit_cast(uint4, *reinterpret_cast<f16x8*>(h));
+  int t;
+  t = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false); t = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], t, true); l8_out.x = (uint32_t)t;
+  t = __builtin_amdgcn_cvt_pk_fp8_f32(r[4], r[5], 0, false); t = __builtin_amdgcn_cvt_pk_fp8_f32(r[6], r[7], t, true); l8_out.y = (uint32_t)t;
+  t = __builtin_amdgcn_cvt_pk_fp8_f32(hf[0], hf[1], 0, false); t = __builtin_amdgcn_cvt_pk_fp8_f32(hf[2], hf[3], t, true); h8_out.x = (uint32_t)t;
+  t = __builtin_amdgcn_cvt_pk_fp8_f32(hf[4], hf[5], 0, false); t = __builtin_amdgcn_cvt_pk_fp8_f32(hf[6], hf[7], t, true); h8_out.y = (uint32_t)t;
+}
+__device__ __forceinline__ void fsplit_decode8(uint4 h, uint2 l8, float* v) {
+  const f16x8 hv = __builtin_bit_cast(f16x8, h);
+  const float sc = 1.f / (float)(1 << FS_LSHIFT);
+  v[0] = (float)hv[0] + __builtin_amdgcn_cvt_f32_fp8((int)l8.x, 0) * sc;
+  v[1] = (float)hv[1] + __builtin_amdgcn_cvt_f32_fp8((int)l8.x, 1) * sc;
+  v[2] = (float)hv[2] + __builtin_amdgcn_cvt_f32_fp8((int)l8.x, 2) * sc;
+  v[3] = (float)hv[3] + __builtin_amdgcn_cvt_f32_fp8((int)l8.x, 3) * sc;
+  v[4] = (float)hv[4] + __builtin_amdgcn_cvt_f32_fp8((int)l8.y, 0) * sc;
+  v[5] = (float)hv[5] + __builtin_amdgcn_cvt_f32_fp8((int)l8.y, 1) * sc;
+  v[6] = (float)hv[6] + __builtin_amdgcn_cvt_f32_fp8((int)l8.y, 2) * sc;
+  v[7] = (float)hv[7] + __builtin_amdgcn_cvt_f32_fp8((int)l8.y, 3) * sc;
+}
+
 // One channel slot (hi or lo interleaved per 16 channels) of the split-bf16 format.  A tensor
 // [N,H,W,C] (C % 16 == 0) is stored per pixel as C/16 groups of {16 x bf16 hi, 16 x bf16 lo}.
 struct bsplit { uint32_t raw; };
@@ -165,6 +213,37 @@ template <> struct Prec<bsplit> {
   }
 };
 
+template <> struct Prec<fsplit> {
+  static constexpr int CC = 16;
+  static constexpr int KG = 1;
+  static constexpr int NF = 1;
+  static constexpr int UC = 8;
+  static constexpr bool PAIR_LOAD = false;
+  typedef f16x8 Frag;
+  // relu of one 64-byte record (16 channels): the sign of h decides for h, l8 and h8
+  static __device__ __forceinline__ void relu_record(uint4& h0, uint4& h1, uint4& l8, uint4& h8) {
+    uint32_t* a = reinterpret_cast<uint32_t*>(&h0);
+    uint32_t* b = reinterpret_cast<uint32_t*>(&h1);
+    uint32_t* l = reinterpret_cast<uint32_t*>(&l8);
+    uint32_t* g = reinterpret_cast<uint32_t*>(&h8);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {  // dword d of l8/h8 = channels 4d..4d+3 = fp16 dwords 2d, 2d+1 of h
+      const uint32_t w0 = d < 2 ? a[2 * d] : b[2 * d - 4], w1 = d < 2 ? a[2 * d + 1] : b[2 * d - 3];
+      const uint32_t keep16_0 = ((w0 & 0x8000u) ? 0u : 0xffffu) | ((w0 & 0x80000000u) ? 0u : 0xffff0000u);
+      const uint32_t keep16_1 = ((w1 & 0x8000u) ? 0u : 0xffffu) | ((w1 & 0x80000000u) ? 0u : 0xffff0000u);
+      const uint32_t keep8 = ((w0 & 0x8000u) ? 0u : 0xffu) | ((w0 & 0x80000000u) ? 0u : 0xff00u) |
+                             ((w1 & 0x8000u) ? 0u : 0xff0000u) | ((w1 & 0x80000000u) ? 0u : 0xff000000u);
+      if (d < 2) { a[2 * d] &= keep16_0; a[2 * d + 1] &= keep16_1; } else { b[2 * d - 4] &= keep16_0; b[2 * d - 3] &= keep16_1; }
+      l[d] &= keep8;
+      g[d] &= keep8;
+    }
+  }
+  static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused
+};
+
+template <typename T> struct IsFsplit { static constexpr bool value = false; };
+template <> struct IsFsplit<fsplit> { static constexpr bool value = true; };
+
 struct ConvArgs {
   const void* in0;   // [N,H,W,C0]
   const void* in1;   // [N,H,W,C1] second concat source (nullable)
@@ -179,6 +258,7 @@ struct ConvArgs {
   int d2s_shift;     // log2(Cout/4) when d2s (Cout/4 must be a power of two)
   // channel scatter of the direct store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
   int out_cstride, out_coff, out_split, out_gap;
+  int wexp;          // f16f8: wh8 = fp8(w_h * 2^wexp), wl8 = fp8(w_l * 2^(wexp+11)) (per conv, host-chosen)
   // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
   unsigned long long* trace;
 };
@@ -230,12 +310,15 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   // The halo tile of a chunk is HALO_PIX records of four 16-byte slots.  Normal types: unit
   // u = tid + i*NTHR -> pixel u>>2, slot u&3.  bsplit: a thread loads the hi slot s (0/1) and
   // the matching lo slot s+2 of one pixel (relu needs both): pixel (tid>>1) + i*NTHR/2.
-  constexpr int NPIX_IT = P::PAIR_LOAD ? (HALO_PIX * 2 + NTHR - 1) / NTHR : (HALO_PIX * 4 + NTHR - 1) / NTHR;
-  constexpr int NIN = P::PAIR_LOAD ? 2 * NPIX_IT : NPIX_IT;     // 16-byte registers for the halo tile
+  // f16f8: a thread loads the whole 64-byte record of one pixel (relu needs h for l8 and h8).
+  constexpr bool QUAD = IsFsplit<T>::value;
+  constexpr int NPIX_IT = QUAD ? (HALO_PIX + NTHR - 1) / NTHR
+                               : (P::PAIR_LOAD ? (HALO_PIX * 2 + NTHR - 1) / NTHR : (HALO_PIX * 4 + NTHR - 1) / NTHR);
+  constexpr int NIN = QUAD ? 4 * NPIX_IT : (P::PAIR_LOAD ? 2 * NPIX_IT : NPIX_IT);  // 16-byte registers, halo tile
   constexpr int NWT = (9 * BN * 4 + NTHR - 1) / NTHR;           // ... and for the weight slab
-  constexpr int PIX_STEP = P::PAIR_LOAD ? NTHR / 2 : NTHR / 4;
-  const int slot = P::PAIR_LOAD ? (tid & 1) : (tid & 3);
-  const int pix_lo = P::PAIR_LOAD ? (tid >> 1) : (tid >> 2);
+  constexpr int PIX_STEP = QUAD ? NTHR : (P::PAIR_LOAD ? NTHR / 2 : NTHR / 4);
+  const int slot = QUAD ? 0 : (P::PAIR_LOAD ? (tid & 1) : (tid & 3));
+  const int pix_lo = QUAD ? tid : (P::PAIR_LOAD ? (tid >> 1) : (tid >> 2));
   const int wslot = tid & 3;
   const int wrec_lo = tid >> 2;
   int in_pix[NPIX_IT];  // linear pixel index in the source image, -1 = zero padding / no unit
@@ -262,7 +345,12 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       for (int i = 0; i < NPIX_IT; ++i) {
         const int pix = pix_lo + i * PIX_STEP;
         if (i < NPIX_IT - 1 || pix < HALO_PIX) {
-          if constexpr (P::PAIR_LOAD) {
+          if constexpr (QUAD) {
+            uint4 q0 = rin[4 * i], q1 = rin[4 * i + 1], q2 = rin[4 * i + 2], q3 = rin[4 * i + 3];
+            if (p.relu_in) P::relu_record(q0, q1, q2, q3);
+            uint4* d = reinterpret_cast<uint4*>(s_in + pix * REC_BYTES);
+            d[0] = q0; d[1] = q1; d[2] = q2; d[3] = q3;
+          } else if constexpr (P::PAIR_LOAD) {
             uint4 hi = rin[2 * i], lo = rin[2 * i + 1];
             if (p.relu_in) P::relu_pair(hi, lo);
             *reinterpret_cast<uint4*>(s_in + pix * REC_BYTES + slot * 16) = hi;
@@ -288,7 +376,14 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       else           { src = (const T*)p.in1; csrc = p.C1; coff = c0 - p.C0; }
 #pragma unroll
       for (int i = 0; i < NPIX_IT; ++i) {
-        if constexpr (P::PAIR_LOAD) {
+        if constexpr (QUAD) {
+          const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+          rin[4 * i] = z; rin[4 * i + 1] = z; rin[4 * i + 2] = z; rin[4 * i + 3] = z;
+          if (in_pix[i] >= 0) {
+            const uint4* q = reinterpret_cast<const uint4*>(src + (size_t)in_pix[i] * csrc + coff);
+            rin[4 * i] = q[0]; rin[4 * i + 1] = q[1]; rin[4 * i + 2] = q[2]; rin[4 * i + 3] = q[3];
+          }
+        } else if constexpr (P::PAIR_LOAD) {
           uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
           if (in_pix[i] >= 0) {
             const T* q = src + (size_t)in_pix[i] * csrc + coff + slot * EPU;
@@ -333,6 +428,70 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         for (int f = 0; f < P::NF; ++f)
           fb[j][f] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
     };
+    if constexpr (IsFsplit<T>::value) {
+      // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-): per accumulator 2 fp16 MFMAs (main term, one per tap)
+      // + 1 block-scaled fp8 MFMA carrying both cross terms of both taps.
+      // Operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 (probed, scripts/probes/): lane (row, kh)
+      // holds bytes 0-15 = K block 0 elements kh*16.., bytes 16-31 = K block 1 elements kh*16..; the
+      // scale of block b is taken from the lanes with kh == b.  So lane half kh carries tap 2*tp+kh:
+      // bytes 0-15 = l8 | wh8 (block 0: a_l*w_h, scales 2^-14 | 2^-wexp), bytes 16-31 = h8 | wl8
+      // (block 1: a_h*w_l, scales 1 | 2^-(wexp+11)) = bytes 32..63 of that tap's 64-byte record.
+      const int sa = kh == 0 ? 127 - FS_LSHIFT : 127;
+      const int sb = kh == 0 ? 127 - p.wexp : 127 - p.wexp - 11;
+      const char* ax_base = s_in + ((wave * MR) * HALO_W + li) * REC_BYTES + 32;
+      const char* bx_base = s_w + li * REC_BYTES + 32;
+#pragma unroll
+      for (int tp = 0; tp < 5; ++tp) {
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;   // t1 clamped; its data is zeroed
+        const bool pair = 2 * tp + 1 < 9;
+        f16x8 ah[2][MR], bh[2][NT];
+        uint4 ax[MR][2], bx[NT][2];
+        // main-term fragments of both taps (all lanes)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int tap = q == 0 ? t0 : t1;
+          const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+            ah[q][m] = *reinterpret_cast<const f16x8*>(a_base + ((m + dy) * HALO_W + dx) * REC_BYTES);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bh[q][j] = *reinterpret_cast<const f16x8*>(b_base + (tap * BN + j * 32) * REC_BYTES);
+        }
+        // cross-term operands: this lane half's tap
+        {
+          const int offa0 = ((t0 / 3) * HALO_W + (t0 % 3)) * REC_BYTES, offa1 = ((t1 / 3) * HALO_W + (t1 % 3)) * REC_BYTES;
+          const int offa = kh ? offa1 : offa0;
+          const int offb = (kh ? t1 : t0) * BN * REC_BYTES;
+          const bool live = pair || kh == 0;
+#pragma unroll
+          for (int m = 0; m < MR; ++m) {
+            const uint4* q = reinterpret_cast<const uint4*>(ax_base + m * HALO_W * REC_BYTES + offa);
+            ax[m][0] = q[0]; ax[m][1] = q[1];
+            if (!live) { ax[m][0] = make_uint4(0u, 0u, 0u, 0u); ax[m][1] = make_uint4(0u, 0u, 0u, 0u); }
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const uint4* q = reinterpret_cast<const uint4*>(bx_base + offb + j * 32 * REC_BYTES);
+            bx[j][0] = q[0]; bx[j][1] = q[1];
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][m], bh[0][j], acc[m][j], 0, 0, 0);
+            if (pair) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][m], bh[1][j], acc[m][j], 0, 0, 0);
+            i32x8 fa, fb;
+            fa[0] = ax[m][0].x; fa[1] = ax[m][0].y; fa[2] = ax[m][0].z; fa[3] = ax[m][0].w;
+            fa[4] = ax[m][1].x; fa[5] = ax[m][1].y; fa[6] = ax[m][1].z; fa[7] = ax[m][1].w;
+            fb[0] = bx[j][0].x; fb[1] = bx[j][0].y; fb[2] = bx[j][0].z; fb[3] = bx[j][0].w;
+            fb[4] = bx[j][1].x; fb[5] = bx[j][1].y; fb[6] = bx[j][1].z; fb[7] = bx[j][1].w;
+            acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, acc[m][j], 0, 0, 0, sa, 0, sb);
+          }
+      }
+    } else {
 #if (FISR_ABL & 2)
     {
       Frag fa[MR][P::NF], fb[NT][P::NF];
@@ -351,6 +510,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       P::mma_tiles(acc, fa, fb);
     }
 #endif
+    }
   }
 
   if (p.trace) t_main = __builtin_readcyclecounter();
@@ -399,7 +559,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
     constexpr int UC = P::UC;                 // channels per unit
     constexpr int UPP = BN / UC;              // units per pixel
     constexpr int NU = TILE_H * TILE_W * UPP / NTHR;
-    constexpr int RV = P::PAIR_LOAD ? 2 : 1;  // 16-byte residual vectors per unit
+    constexpr int RV = (P::PAIR_LOAD || IsFsplit<T>::value) ? 2 : 1;  // 16-byte residual vectors per unit
     const int cq_shift = p.d2s_shift;
     float* s_o = reinterpret_cast<float*>(smem);
     __syncthreads();  // all waves are done with the last chunk's LDS reads
@@ -426,7 +586,13 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         for (int k = 0; k < RV; ++k) rres[i][k] = make_uint4(0u, 0u, 0u, 0u);
         if (y < p.H && x < p.W && n < p.Cout) {
           const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
-          if constexpr (P::PAIR_LOAD) {
+          if constexpr (IsFsplit<T>::value) {
+            const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4;
+            const int half = (n >> 3) & 1;
+            rres[i][0] = *reinterpret_cast<const uint4*>(rb + half * 16);
+            const uint2 l8 = *reinterpret_cast<const uint2*>(rb + 32 + half * 8);
+            rres[i][1] = make_uint4(l8.x, l8.y, 0u, 0u);
+          } else if constexpr (P::PAIR_LOAD) {
             const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4 + ((n >> 3) & 1) * 16;
             rres[i][0] = *reinterpret_cast<const uint4*>(rb);
             rres[i][1] = *reinterpret_cast<const uint4*>(rb + 32);
@@ -462,7 +628,25 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       } else {
         oel = gp * p.Cout + n;
       }
-      if constexpr (sizeof(T) == 4 && !P::PAIR_LOAD) {  // float
+      if constexpr (IsFsplit<T>::value) {  // f16f8: 8 channels = 16 B of h, 8 B of l8, 8 B of h8
+        const int half = (n >> 3) & 1;
+        if (p.res) {
+          float rv[8];
+          fsplit_decode8(rres[i][0], make_uint2(rres[i][1].x, rres[i][1].y), rv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += rv[k];
+        }
+        if (p.relu_out) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        uint4 oh; uint2 ol, og;
+        fsplit_encode8(v, oh, ol, og);
+        char* ob = (char*)p.out + (oel & ~(size_t)15) * 4;
+        *reinterpret_cast<uint4*>(ob + half * 16) = oh;
+        *reinterpret_cast<uint2*>(ob + 32 + half * 8) = ol;
+        *reinterpret_cast<uint2*>(ob + 48 + half * 8) = og;
+      } else if constexpr (sizeof(T) == 4 && !P::PAIR_LOAD) {  // float
         if (p.res) {
           const f32x4 rv = __builtin_bit_cast(f32x4, rres[i][0]);
           v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;

@@ -34,6 +34,7 @@ struct ConvW {
   void* d_w = nullptr;
   float* d_b = nullptr;
   int cin_pad = 0, cout_pad = 0, nt = 2;
+  int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
 };
 
 struct ProfEntry {
@@ -133,16 +134,36 @@ template <typename T> struct PrecName;
 template <> struct PrecName<float> { static const char* get() { return "f32"; } };
 template <> struct PrecName<_Float16> { static const char* get() { return "f16"; } };
 template <> struct PrecName<bsplit> { static const char* get() { return "bf16x3"; } };
+template <> struct PrecName<fsplit> { static const char* get() { return "f16f8"; } };
 
 // call f(T()) with the activation type of `precision`
 template <typename F>
 auto with_prec(int precision, F&& f) {
   if (precision == FISR_PREC_F32) return f(float());
   if (precision == FISR_PREC_F16) return f(_Float16());
+  if (precision == FISR_PREC_F16F8) return f(fsplit());
   return f(bsplit());
 }
 inline bool prec_ok(int precision) {
-  return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3;
+  return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
+         precision == FISR_PREC_F16F8;
+}
+inline bool prec_grouped16(int precision) { return precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8; }
+
+// host fp8 e4m3fn (OCP) encode, round-to-nearest-even, saturating at +-448
+inline uint8_t host_fp8_e4m3(float f) {
+  if (f != f) return 0x7f;
+  const uint8_t sign = f < 0 ? 0x80 : 0;
+  float a = std::fabs(f);
+  if (a >= 448.f) return sign | 0x7e;
+  if (a == 0.f) return sign;
+  int ex = std::max(std::ilogb(a), -6);          // exponent of the binade (subnormals share -6)
+  float q = std::ldexp(a, 3 - ex);               // [8,16) for normals, [0,8) for subnormals
+  float r = std::nearbyint(q);                   // RNE in the default rounding mode
+  if (r >= 16.f) { r = 8.f; ex += 1; }
+  if (r < 8.f) return sign | (uint8_t)r;         // subnormal (r == 8 would have been normal)
+  if (ex > 8) return sign | 0x7e;
+  return sign | (uint8_t)(((ex + 7) << 3) | ((int)r - 8));
 }
 inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 ? 32 : 16; }
 inline int prec_unit(int precision) { return precision == FISR_PREC_F32 ? 4 : 8; }
@@ -166,7 +187,7 @@ inline float host_bf16_to_f32(uint16_t h) {
 // Record = CC values of T (float / fp16), or 16 bf16 hi followed by 16 bf16 lo (bsplit).
 template <typename T>
 void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, int cout_pad,
-                  std::vector<char>& wp, std::vector<float>& bp) {
+                  std::vector<char>& wp, std::vector<float>& bp, int wexp) {
   constexpr int CC = Prec<T>::CC;
   wp.assign((size_t)(cin_pad / CC) * 9 * cout_pad * CHUNK_BYTES, 0);
   bp.assign(cout_pad, 0.f);
@@ -180,6 +201,13 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
           reinterpret_cast<float*>(rec)[cc] = v;
         } else if constexpr (std::is_same<T, _Float16>::value) {
           reinterpret_cast<_Float16*>(rec)[cc] = (_Float16)v;
+        } else if constexpr (std::is_same<T, fsplit>::value) {
+          // [ 0..31] w_h fp16 | [32..47] fp8(w_h * 2^wexp) | [48..63] fp8((w - w_h) * 2^(wexp+11))
+          const _Float16 h = (_Float16)v;
+          const float hf = (float)h;
+          reinterpret_cast<_Float16*>(rec)[cc] = h;
+          reinterpret_cast<uint8_t*>(rec)[32 + cc] = host_fp8_e4m3(std::ldexp(hf, wexp));
+          reinterpret_cast<uint8_t*>(rec)[48 + cc] = host_fp8_e4m3(std::ldexp(v - hf, wexp + 11));
         } else {
           const uint16_t hi = host_bf16(v);
           const uint16_t lo = host_bf16(v - host_bf16_to_f32(hi));
@@ -200,7 +228,14 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw) {
   cw.cout_pad = round_up(cw.co, 32 * cw.nt);
   std::vector<char> wp;
   std::vector<float> bp;
-  pack_weights<T>(cw.w.data(), cw.b.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad, wp, bp);
+  cw.wexp = 0;
+  if (std::is_same<T, fsplit>::value) {
+    float mx = 0.f;
+    for (float v : cw.w) mx = std::max(mx, std::fabs(v));
+    // largest power of two with max|w| * 2^wexp <= 448 (fp8 e4m3 max), kept inside the scale byte's range
+    cw.wexp = mx > 0.f ? std::min(30, std::max(-30, 8 - std::ilogb(mx) - 1)) : 0;
+  }
+  pack_weights<T>(cw.w.data(), cw.b.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad, wp, bp, cw.wexp);
   if (cw.d_w) { (void)hipFree(cw.d_w); cw.d_w = nullptr; }
   if (cw.d_b) { (void)hipFree(cw.d_b); cw.d_b = nullptr; }
   HIP_OK(ctx, hipMalloc(&cw.d_w, wp.size()));
@@ -374,7 +409,7 @@ struct Runner {
     a.d2s = (flags & FISR_CONV_D2S) != 0;
     a.d2s_shift = a.d2s ? ilog2(cw.co / 4) : 0;
     a.out_cstride = cstride ? cstride : cw.co;
-    a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr;
+    a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr; a.wexp = cw.wexp;
     const double px = (double)n * h * w;
     char cls[96];
     snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
@@ -771,7 +806,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
-  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr;
+  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
   hipError_t e2 = hipStreamSynchronize(st);
@@ -785,7 +820,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
 int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {
   if (!in || !out || h % 2 || w % 2 || !prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: bad argument");
   const int uc = prec_unit(precision);
-  if (c % (precision == FISR_PREC_BF16X3 ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: c must be a multiple of the channel unit");
+  if (c % (prec_grouped16(precision) ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: c must be a multiple of the channel unit");
   const size_t work = (size_t)n * (h / 2) * (w / 2) * c / uc;
   with_prec(precision, [&](auto tag) {
     typedef decltype(tag) T;
@@ -799,7 +834,7 @@ int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int 
 int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {
   if (!in || !out || !prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: bad argument");
   const int uc = prec_unit(precision);
-  if (c % (precision == FISR_PREC_BF16X3 ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of the channel unit");
+  if (c % (prec_grouped16(precision) ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of the channel unit");
   const size_t work = (size_t)n * h * w * 4 * c / uc;
   with_prec(precision, [&](auto tag) {
     typedef decltype(tag) T;
@@ -853,7 +888,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
-  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr;
+  a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   const char* trace_file = getenv("FISR_TRACE_FILE");
   unsigned long long* d_trace = nullptr;
   const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) * (cw.cout_pad / (32 * cw.nt));

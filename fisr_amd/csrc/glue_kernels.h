@@ -61,6 +61,24 @@ template <> struct Unit<bsplit> {
   }
 };
 
+template <> struct Unit<fsplit> {   // 8 channels = 16 B of h + 8 B of l8 (+ 8 B of h8 on store), see conv3x3.h
+  static constexpr int UC = 8;
+  static __device__ __forceinline__ void load(const fsplit* pix, int cu, float* v) {
+    const char* b = reinterpret_cast<const char*>(pix) + (cu >> 1) * 64;
+    const int half = cu & 1;
+    fsplit_decode8(*reinterpret_cast<const uint4*>(b + half * 16), *reinterpret_cast<const uint2*>(b + 32 + half * 8), v);
+  }
+  static __device__ __forceinline__ void store(fsplit* pix, int cu, const float* v) {
+    uint4 h; uint2 l8, h8;
+    fsplit_encode8(v, h, l8, h8);
+    char* b = reinterpret_cast<char*>(pix) + (cu >> 1) * 64;
+    const int half = cu & 1;
+    *reinterpret_cast<uint4*>(b + half * 16) = h;
+    *reinterpret_cast<uint2*>(b + 32 + half * 8) = l8;
+    *reinterpret_cast<uint2*>(b + 48 + half * 8) = h8;
+  }
+};
+
 // ---- level input: strided sub-sample + concat with the previous prediction + channel pad ----
 // FISRnet.py:81,112 (legacy BICUBIC resize at integer factor == x[:, ::s, ::s, :])
 // FISRnet.py:113,144 (tf.concat((img_lk, pred_l{k-1}), axis=3)).  Output has cpad >= 29(+9)
@@ -79,7 +97,15 @@ __global__ void prep_level_input_kernel(const float* __restrict__ img, const flo
     float v = 0.f;
     if (c < 29) v = img[(((size_t)n * H + (size_t)y * s) * W + (size_t)x * s) * 29 + c];
     else if (pred != nullptr && c < 38) v = pred[pix * 9 + (c - 29)];
-    if constexpr (sizeof(T) == 4 && Unit<T>::UC == 4) {
+    if constexpr (IsFsplit<T>::value) {
+      const _Float16 h = (_Float16)v;
+      const float hf = (float)h;
+      const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp((v - hf) * (float)(1 << FS_LSHIFT)), fp8_clamp(hf), 0, false);
+      char* rec = reinterpret_cast<char*>(out) + (pix * cpad + (c & ~15)) * 4;
+      reinterpret_cast<_Float16*>(rec)[c & 15] = h;
+      rec[32 + (c & 15)] = (char)(pk & 0xff);
+      rec[48 + (c & 15)] = (char)((pk >> 8) & 0xff);
+    } else if constexpr (sizeof(T) == 4 && Unit<T>::UC == 4) {
       out[i] = v;
     } else if constexpr (sizeof(T) == 2) {
       out[i] = (_Float16)v;

@@ -30,7 +30,7 @@ from .lib import FisrError
 
 _PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
-         "bf16x3": _lib.PREC_BF16X3}
+         "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8}
 
 
 def _torch():

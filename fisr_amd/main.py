@@ -57,7 +57,7 @@ def parse_args(argv=None):
     p.add_argument("--frame_num", type=int, default=5)
     p.add_argument("--FISR_test_patch", type=_tuple2, default=(2, 2))
     # build-specific
-    p.add_argument("--precision", type=str, default="bf16x3", choices=["fp32", "bf16x3", "fp16"])
+    p.add_argument("--precision", type=str, default="bf16x3", choices=["fp32", "bf16x3", "f16f8", "fp16"])
     p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--flow_file", type=str, default=None, help="pre-computed 5-D .flo for FISR_for_video")
     p.add_argument("--warp_file", type=str, default=None, help="pre-computed warp (.mat/.npy); default: warp on the GPU")

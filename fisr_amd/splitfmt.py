@@ -39,3 +39,56 @@ def from_split(s: np.ndarray) -> np.ndarray:
 def split_round(x: np.ndarray) -> np.ndarray:
     """x rounded to what the split format can hold (hi + lo)."""
     return from_split(to_split(x))
+
+
+# ----------------------------------------------------------------------------------------------
+# fp16 + fp8 split ("f16f8", FISR_PREC_F16F8): per 16 channels 16 x fp16 h | 16 x fp8 l8 | 16 x fp8 h8
+# ----------------------------------------------------------------------------------------------
+FS_LSHIFT = 14
+
+
+def fp8_e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """float -> OCP fp8 e4m3fn bits, round-to-nearest-even, saturating at +-448 (as the kernels do)."""
+    x = np.asarray(x, np.float64)
+    sign = (np.signbit(x)).astype(np.uint8) << 7
+    a = np.minimum(np.abs(x), 448.0)
+    with np.errstate(divide="ignore"):
+        ex = np.maximum(np.floor(np.log2(np.where(a > 0, a, 1.0))), -6).astype(np.int64)
+    q = a * np.exp2(3 - ex)
+    r = np.rint(q)
+    bump = r >= 16
+    r = np.where(bump, 8, r)
+    ex = np.where(bump, ex + 1, ex)
+    normal = r >= 8
+    bits = np.where(normal, ((ex + 7) << 3) | (r.astype(np.int64) - 8), r.astype(np.int64))
+    bits = np.where(a >= 448.0, 0x7E, bits)
+    return (sign | bits.astype(np.uint8)).astype(np.uint8)
+
+
+def fp8_e4m3_decode(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b, np.uint8).astype(np.int64)
+    e, m = (b >> 3) & 0xF, b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (8 + m) * np.exp2(e - 10.0))
+    return np.where(b & 0x80, -v, v).astype(np.float32)
+
+
+def to_fsplit(x: np.ndarray) -> np.ndarray:
+    """float32 [..., C] -> uint8 [..., C/16, 64] (byte-exact device layout of FISR_PREC_F16F8)."""
+    x = np.ascontiguousarray(x, np.float32)
+    c = x.shape[-1]
+    assert c % 16 == 0
+    g = x.reshape(x.shape[:-1] + (c // 16, 16))
+    h = g.astype(np.float16)
+    hf = h.astype(np.float32)
+    l8 = fp8_e4m3_encode(np.clip((g - hf) * np.float32(2 ** FS_LSHIFT), -448, 448))
+    h8 = fp8_e4m3_encode(np.clip(hf, -448, 448))
+    return np.ascontiguousarray(np.concatenate([h.view(np.uint8).reshape(g.shape[:-1] + (32,)), l8, h8], axis=-1))
+
+
+def from_fsplit(s: np.ndarray) -> np.ndarray:
+    """uint8 [..., C/16, 64] -> float32 [..., C]  (x = h + l8 * 2^-14)."""
+    s = np.ascontiguousarray(s, np.uint8)
+    h = s[..., :32].copy().view(np.float16).astype(np.float32)
+    l = fp8_e4m3_decode(s[..., 32:48]) * np.float32(2.0 ** -FS_LSHIFT)
+    v = h + l
+    return v.reshape(v.shape[:-2] + (v.shape[-2] * 16,))

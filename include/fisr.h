@@ -44,11 +44,16 @@ enum {
 enum {
   FISR_PREC_F32 = 0, /* fp32 activations/weights, v_mfma_f32_32x32x2_f32 (exact fp32, fmaf chain) */
   FISR_PREC_F16 = 1, /* fp16 activations/weights, v_mfma_f32_32x32x16_f16, fp32 accumulate */
-  FISR_PREC_BF16X3 = 2 /* split bf16: every value kept as hi+lo (2 x bf16, ~2^-18 relative), each
+  FISR_PREC_BF16X3 = 2, /* split bf16: every value kept as hi+lo (2 x bf16, ~2^-18 relative), each
                           product = 3 x v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi), fp32
                           accumulate: fp32-grade results at 16/3 x the fp32 MFMA rate.  Activation
                           tensors use the split layout: per pixel, per 16 channels, 16 bf16 hi
                           (32 B) then 16 bf16 lo (32 B). */
+  FISR_PREC_F16F8 = 3  /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels
+                          16 x fp16 h (32 B), 16 x fp8-e4m3 l8 (16 B), 16 x fp8-e4m3 copy of h (16 B).
+                          Product = a_h*w_h (v_mfma_f32_32x32x16_f16) + both cross terms in ONE
+                          block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per pair of taps: ~2^-15
+                          relative per product at 2.1 instead of 3 MFMA-units (fp32 accumulate). */
 };
 
 /* flags of fisr_op_conv3x3 */
@@ -142,8 +147,8 @@ int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, 
 /* ---- op-level entry points (parity tests of the individual kernels) ---- */
 
 /* y = conv3x3_SAME(concat(in0,in1)) + b [+ res], ops.py:7-11.  Activations are float32
- * (FISR_PREC_F32), float16 (FISR_PREC_F16) or split-bf16 (FISR_PREC_BF16X3) device tensors; in1/res may be NULL;
- * c0 (and c1) must be multiples of 16 (f32, bf16x3) / 32 (f16) channels; w_host [3,3,c0+c1,cout]
+ * (FISR_PREC_F32), float16 (FISR_PREC_F16), split-bf16 (FISR_PREC_BF16X3) or fp16+fp8 (FISR_PREC_F16F8) device tensors; in1/res may be NULL;
+ * c0 (and c1) must be multiples of 16 (f32, bf16x3, f16f8) / 32 (f16) channels; w_host [3,3,c0+c1,cout]
  * and b_host [cout] are HOST float32.  With FISR_CONV_D2S, cout % 4 == 0 and out is
  * [n,2h,2w,cout/4].  out_f32 != 0 stores float32 regardless of precision.
  * Synchronous (packs and uploads the weights on every call). */

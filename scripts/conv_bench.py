@@ -19,7 +19,7 @@ SHAPES = [  # n, h, w, cin, cout, flags, res
     (12, 136, 248, 64, 64, 3, 1),
     (1, 544, 992, 64, 64, 3, 1),
 ]
-PID = {"fp32": 0, "fp16": 1, "bf16x3": 2}
+PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}
 L = lib.lib()
 for prec in (sys.argv[1:] or ["bf16x3"]):
     for (n, h, w, ci, co, fl, rs) in SHAPES:

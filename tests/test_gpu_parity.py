@@ -49,6 +49,14 @@ def netx3(dev, syn_weights):
 
 
 @pytest.fixture(scope="module")
+def netf8(dev, syn_weights):
+    n = FISRnet(device="cuda:0", precision="f16f8")
+    n.set_weights(syn_weights)
+    yield n
+    n.close()
+
+
+@pytest.fixture(scope="module")
 def net16(dev, syn_weights):
     n = FISRnet(device="cuda:0", precision="fp16")
     n.set_weights(syn_weights)
@@ -64,7 +72,7 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
 
 
-PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2}
+PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}
 
 
 def to_dev(x, prec):
@@ -74,6 +82,8 @@ def to_dev(x, prec):
         return torch.from_numpy(x).cuda()
     if prec == "fp16":
         return torch.from_numpy(x).cuda().half().contiguous()
+    if prec == "f16f8":
+        return torch.from_numpy(splitfmt.to_fsplit(x)).cuda()
     return torch.from_numpy(splitfmt.to_split(x).view(np.int16)).cuda()
 
 
@@ -82,6 +92,8 @@ def from_dev(t, prec, shape):
         return t.cpu().numpy().reshape(shape)
     if prec == "fp16":
         return t.float().cpu().numpy().reshape(shape)
+    if prec == "f16f8":
+        return splitfmt.from_fsplit(t.cpu().numpy().reshape(shape[:-1] + (shape[-1] // 16, 64)))
     s = t.cpu().numpy().view(np.uint16).reshape(shape[:-1] + (shape[-1] // 16, 2, 16))
     return splitfmt.from_split(s)
 
@@ -91,6 +103,8 @@ def empty_dev(shape, prec):
         return torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
     if prec == "fp16":
         return torch.full(shape, float("nan"), dtype=torch.float16, device="cuda")
+    if prec == "f16f8":
+        return torch.full(shape[:-1] + (shape[-1] // 16, 64), 0x7e, dtype=torch.uint8, device="cuda")  # fp16 NaN-ish pattern
     return torch.full(shape[:-1] + (shape[-1] // 16, 2, 16), 0x7fc0, dtype=torch.int16, device="cuda")  # bf16 NaN
 
 
@@ -199,6 +213,36 @@ def test_conv3x3_bf16x3_vs_oracle(dev, shape):
         assert got.min() >= 0
 
 
+@pytest.mark.parametrize("shape", [
+    (1, 8, 32, 16, 0, 64, 0, False),
+    (1, 16, 64, 32, 0, 64, 3, True),            # relu in/out + residual in the f16f8 layout
+    (2, 24, 24, 64, 0, 128, 1, False),
+    (1, 17, 45, 48, 0, 64, 0, False),
+    (1, 16, 40, 64, 64, 64, 0, False),          # concat
+    (1, 10, 33, 64, 0, 256, 7, False),          # relu + depth_to_space store
+    (1, 16, 64, 64, 0, 6, 0, False),            # fp32-output head
+    (1, 8, 8, 512, 0, 512, 2, True),
+])
+def test_conv3x3_f16f8_vs_oracle(dev, shape):
+    """fp16 main term + block-scaled fp8 cross terms: operands hold >= 14 bits (h + l8*2^-14), cross
+    terms are computed from 4-bit operands (2^-4 of a 2^-12 term) -> ~2^-15 relative per product."""
+    n, h, w, c0, c1, cout, flags, use_res = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31) + 2)
+    x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+    wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+    got = hip_conv(x0, wt, b, x1, res, flags, prec="f16f8", out_f32=(cout % 8 != 0))
+    exp = ref_conv(x0, wt, b, x1, res, flags)
+    err = np.abs(got.astype(np.float64) - exp)
+    print(f"f16f8 conv {shape}: max {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}")
+    _report(got, exp, 6e-4, f"f16f8 conv {shape}")
+    assert np.sqrt((err ** 2).mean()) < 1e-4
+    if flags & flib.CONV_RELU_OUT:
+        assert got.min() >= 0
+
+
 def test_conv3x3_transpose_detecting(dev):
     """A = delta input, asymmetric weights: catches swapped rows/cols, taps or channel order."""
     x = np.zeros((1, 8, 32, 16), np.float32)
@@ -283,6 +327,16 @@ def test_pool_upsample_bit_exact(dev):
     torch.cuda.synchronize()
     assert np.array_equal(from_dev(pos, "bf16x3", (2, 3, 5, 64)), O.max_pool2(xsr))
     assert np.abs(from_dev(ups, "bf16x3", (2, 12, 20, 64)) - O.resize_bilinear_x2(xsr)).max() < 2e-5
+    # fp16+fp8 storage
+    xf = to_dev(x, "f16f8")
+    xfr = from_dev(xf, "f16f8", x.shape)
+    pof = empty_dev((2, 3, 5, 64), "f16f8")
+    upf = empty_dev((2, 12, 20, 64), "f16f8")
+    flib.check(L.fisr_op_maxpool2(ctypes.c_void_p(xf.data_ptr()), ctypes.c_void_p(pof.data_ptr()), 2, 6, 10, 64, 3, _stream()))
+    flib.check(L.fisr_op_upsample2(ctypes.c_void_p(xf.data_ptr()), ctypes.c_void_p(upf.data_ptr()), 2, 6, 10, 64, 3, _stream()))
+    torch.cuda.synchronize()
+    assert np.abs(from_dev(pof, "f16f8", (2, 3, 5, 64)) - O.max_pool2(xfr)).max() < 2e-4
+    assert np.abs(from_dev(upf, "f16f8", (2, 12, 20, 64)) - O.resize_bilinear_x2(xfr)).max() < 2e-4
 
 
 # ----------------------------------------------------------------------------- whole forward
@@ -344,6 +398,25 @@ def test_forward_bf16x3_vs_golden(netx3, gold_dir):
         d = _psnr_protocol(hip, ref, rng)
         print(f"bf16x3 window {s_}: rms {np.sqrt(np.mean((hip - ref) ** 2)):.3e} max {np.abs(hip - ref).max():.3e} dPSNR {d}")
         assert max(d) <= 0.002, d
+
+
+def test_forward_f16f8_vs_golden(netf8, gold_dir):
+    """Whole forward in fp16+fp8 split arithmetic: ~2^-15 per product -> far inside +-0.02 dB."""
+    g = np.load(os.path.join(gold_dir, "model_32x64.npz"))
+    l1, l2, l3 = netf8.model(torch.from_numpy(g["x"]).cuda())
+    for name, got, exp in (("l1", l1, g["l1"]), ("l2", l2, g["l2"]), ("l3", l3, g["l3"])):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - exp)
+        print(f"f16f8 {name}: max {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}")
+        assert err.max() < 2e-3 and np.sqrt((err ** 2).mean()) < 2e-4
+    g96 = np.load(os.path.join(gold_dir, "model_96.npz"))
+    rng = np.random.default_rng(8)
+    for s_ in range(3):
+        _, _, l3 = netf8.model(torch.from_numpy(g96["inp"][s_:s_ + 1]).cuda(), want_all=False)
+        hip = l3.cpu().numpy()[0].astype(np.float64)
+        ref = g96["l3"][s_].astype(np.float64)
+        d = _psnr_protocol(hip, ref, rng)
+        print(f"f16f8 window {s_}: rms {np.sqrt(np.mean((hip - ref) ** 2)):.3e} max {np.abs(hip - ref).max():.3e} dPSNR {d}")
+        assert max(d) <= 0.004, d
 
 
 def test_forward_fp16_error_is_bounded(net16, gold_dir):
