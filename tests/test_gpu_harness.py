@@ -115,3 +115,57 @@ def test_phase_fisr_for_video(scene):
     exp = O.quantize_u8(scene["preds"][2][..., 6:9])
     assert (np.abs(yuv.astype(int) - exp.astype(int)) > 1).mean() < 1e-3
     assert (yuv != exp).mean() < 0.02
+
+
+def test_phase_test_full_size_precisions_agree(tmp_path_factory, syn_weights):
+    """cfg2/cfg3 plumbing at full size: `--phase test` on one synthetic 1080x1920 5-frame scene with the
+    reference's default 2x2 tiling (crop to 1024x1920, four 544x992 tiles, 2048x3840 outputs).  The exact
+    fp32 engine and the fast engines must agree within the reference tolerance (+-0.02 dB PSNR, 1e-3 SSIM)
+    against the same ground truth, and write the same set of files."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fisr_amd.fisrnet import FISRnet
+    root = tmp_path_factory.mktemp("cfg2")
+    lr = root / "LR_LFR"; hr = root / "HR_HFR"; ck = root / "checkpoint_dir" / "FISRnet_exp1"
+    for d in (lr, hr, ck):
+        d.mkdir(parents=True)
+    rng = np.random.default_rng(77)
+    coarse = rng.integers(0, 256, (5, 1080 // 8, 1920 // 8, 3)).astype(np.float32)
+    frames = np.clip(np.repeat(np.repeat(coarse, 8, 1), 8, 2) + rng.normal(0, 5, (5, 1080, 1920, 3)), 0, 255).astype(np.uint8)
+    fc = rng.normal(0, 4, (8, 1080 // 32 + 1, 1920 // 32 + 1, 2)).astype(np.float32)
+    flows = np.repeat(np.repeat(fc, 32, 1), 32, 2)[:, :1080, :1920].copy()[None]       # [1,8,H,W,2]
+    for i in range(5):
+        fio.write_png(str(lr / f"LR_s1_seq_{i}.png"), frames[i])
+    fio.write_flow(flows, str(root / "flow.flo"))
+    weights.save_npz(str(ck / "FISRnet-1.npz"), syn_weights)
+    args = lambda prec: fmain.parse_args([
+        "--phase", "test", "--test_data_path", str(lr), "--test_label_path", str(hr),
+        "--test_flow_data_path", str(root / "flow.flo"), "--test_warped_data_path", str(root / "warp.npy"),
+        "--checkpoint_dir", str(root / "checkpoint_dir"), "--test_img_dir", str(root / f"out_{prec}"),
+        "--text_dir", str(root / "text"), "--log_dir", str(root / "log"), "--precision", prec])
+    # warped frames from the GPU warp kernel, ground truth = fp32 prediction + noise (written once)
+    net = FISRnet(args("fp32"))
+    from fisr_amd.harness import warp_img, sorted_pngs
+    warp = warp_img(net, sorted_pngs(str(lr)), flows[0].reshape(4, 2, 1080, 1920, 2))
+    fio.write_warp_file(str(root / "warp.npy"), warp.reshape(1, 8, 1080, 1920, 3))
+    res0 = net.test()                       # no ground truth yet: PSNR nan, files written
+    assert np.isnan(res0["SR_PSNR"])
+    out0 = root / "out_fp32" / "FISRnet_exp1"
+    names = sorted(os.listdir(out0))
+    assert len(names) == 9                  # s0_w{0,1,2}_f{0,1,2}.png when no labels exist
+    gt_rng = np.random.default_rng(5)
+    for k in range(7):
+        src = fio.read_png(str(out0 / f"pred_s0_w{min(k // 2, 2)}_f{k - 2 * min(k // 2, 2)}.png"))
+        assert src.shape == (2048, 3840, 3)
+        fio.write_png(str(hr / f"HR_s1_seq_{k}.png"), np.clip(src.astype(int) + gt_rng.integers(-3, 4, src.shape), 0, 255).astype(np.uint8))
+    res = {}
+    for prec in ("fp32", "bf16x3", "f16f8"):
+        n2 = FISRnet(args(prec))
+        res[prec] = n2.test()
+        assert sorted(os.listdir(root / f"out_{prec}" / "FISRnet_exp1"))[-7:] == [f"pred_s1_seq_{k}.png" for k in range(7)]
+        assert abs(res[prec]["inference_time_per_frame"]) > 0
+        n2.close()
+    for prec in ("bf16x3", "f16f8"):
+        for key, tol in (("FISR_PSNR", 0.02), ("SR_PSNR", 0.02), ("FISR_SSIM", 1e-3), ("SR_SSIM", 1e-3)):
+            assert abs(res[prec][key] - res["fp32"][key]) <= tol, (prec, key, res[prec][key], res["fp32"][key])
+    net.close()

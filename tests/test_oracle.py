@@ -170,3 +170,34 @@ def test_ssim_identity():
     a = rng.integers(0, 256, (21, 28, 3)).astype(np.uint8)
     assert abs(O.ssim_pil(a, a) - 1.0) < 1e-12
     assert O.ssim_pil(a, 255 - a) < 0.5
+
+
+def test_depth_to_space_vs_torch_pixel_shuffle():
+    """tf.depth_to_space is 'DCR' (block index major), torch.pixel_shuffle is 'CRD' (channel major):
+    permuting channels c*4+(2i+j) <- (2i+j)*C+c must make them agree (independent index-math check)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(5)
+    C = 6
+    x = rng.standard_normal((2, 3, 5, 4 * C))
+    mine = O.depth_to_space2(x)
+    perm = np.array([(b * C + c) for c in range(C) for b in range(4)])          # CRD position -> DCR source
+    t = torch.from_numpy(x[..., perm]).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.pixel_shuffle(t, 2).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(mine, ref)
+
+
+def test_bilinear_x2_vs_torch_align_corners_grid():
+    """The TF-1.x legacy kernel samples in = out*0.5 (no half-pixel offset).  torch's grid_sample with an
+    explicit grid at those coordinates (border-clamped) is an independent bilinear implementation."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((1, 5, 7, 3))
+    mine = O.resize_bilinear_x2(x)
+    h, w = 5, 7
+    ys = np.minimum(np.arange(2 * h) * 0.5, h - 1)
+    xs = np.minimum(np.arange(2 * w) * 0.5, w - 1)
+    gy, gx = np.meshgrid(ys, xs, indexing="ij")
+    grid = np.stack([gx / (w - 1) * 2 - 1, gy / (h - 1) * 2 - 1], -1)[None]
+    ref = torch.nn.functional.grid_sample(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(grid),
+                                          mode="bilinear", padding_mode="border", align_corners=True)
+    assert np.abs(mine - ref.permute(0, 2, 3, 1).numpy()).max() < 1e-12
