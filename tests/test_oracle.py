@@ -201,3 +201,20 @@ def test_bilinear_x2_vs_torch_align_corners_grid():
     ref = torch.nn.functional.grid_sample(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(grid),
                                           mode="bilinear", padding_mode="border", align_corners=True)
     assert np.abs(mine - ref.permute(0, 2, 3, 1).numpy()).max() < 1e-12
+
+
+def test_remap_exact_mode_vs_scipy_map_coordinates():
+    """Exact-coordinate mode of the remap restatement vs scipy's independent bilinear sampler with
+    edge replication; the default (cv2) mode differs only by the 1/32-px coordinate quantisation."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(9)
+    src = rng.random((11, 13, 3)) * 255
+    mapx = (rng.random((11, 13)) * 16 - 2).astype(np.float32)
+    mapy = (rng.random((11, 13)) * 14 - 2).astype(np.float32)
+    mine = O.remap_linear_replicate(src, mapx, mapy, quantized=False)
+    ref = np.stack([ndi.map_coordinates(src[..., c], [mapy.astype(np.float64), mapx.astype(np.float64)], order=1, mode="nearest")
+                    for c in range(3)], -1)
+    assert np.abs(mine - ref).max() < 1e-4      # float32 bilinear weights (as cv2) vs scipy's float64
+    q = O.remap_linear_replicate(src, mapx, mapy, quantized=True)
+    # quantising coordinates to 1/32 px moves a sample by at most 1/64 px in x and y
+    assert np.abs(q - mine).max() <= 255 * (1 / 64) * 2 + 1e-9
