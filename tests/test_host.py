@@ -105,3 +105,16 @@ def test_no_gpu_fails_loudly():
     from fisr_amd.fisrnet import FISRnet, FisrError
     with pytest.raises(FisrError):
         FISRnet()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fisr.h must be consumable by a C compiler (the drop-in boundary is a C ABI)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "fisr.h"\nint main(void) { fisr_ctx* c = 0; (void)c; return FISR_OK; }\n')
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
