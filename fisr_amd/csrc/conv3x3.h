@@ -503,11 +503,33 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       }
     }
 #else
+    // Column-major tap order with halo-row reuse: for a fixed dx the MR+2 halo rows of this wave are
+    // read from LDS once and serve all (m, dy) pairs with m + dy = row (6 -> 4 A reads per dx for MR=2).
 #pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) {
-      Frag fa[MR][P::NF], fb[NT][P::NF];
-      load_frags(s_, fa, fb);
-      P::mma_tiles(acc, fa, fb);
+    for (int kg = 0; kg < P::KG; ++kg) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        Frag rows[MR + 2][P::NF];
+#pragma unroll
+        for (int r = 0; r < MR + 2; ++r)
+#pragma unroll
+          for (int f = 0; f < P::NF; ++f)
+            rows[r][f] = *reinterpret_cast<const Frag*>(a_base + (r * HALO_W + dx) * REC_BYTES + kg * 32 + f * 32);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          Frag fa[MR][P::NF], fb[NT][P::NF];
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int f = 0; f < P::NF; ++f) fa[m][f] = rows[m + dy][f];
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int f = 0; f < P::NF; ++f)
+              fb[j][f] = *reinterpret_cast<const Frag*>(b_base + ((dy * 3 + dx) * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
+          P::mma_tiles(acc, fa, fb);
+        }
+      }
     }
 #endif
     }
