@@ -288,12 +288,23 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 
   const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
   const int tiles_y = (p.H + TILE_H - 1) / TILE_H;
-  int t = blockIdx.x;
+  // Work-item order (1-D grid of tiles x N-blocks).  Workgroup b is observed to run on XCD b % 8
+  // (speed only, never correctness): each XCD gets a contiguous range of virtual ids, and within
+  // it the N-blocks of one tile are consecutive, so the (Cout/BN) re-reads of an input halo tile
+  // and the halo overlap of neighbouring tiles are served by that XCD's L2 instead of HBM.
+  int v = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = v & 7, loc = v >> 3;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int nblocks = p.CoutPad / BN;
+  int t = v / nblocks;
+  const int n0 = (v - t * nblocks) * BN;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
   const int nb = t / tiles_y;
   const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-  const int n0 = blockIdx.y * BN;
 
   unsigned long long t_start = 0, t_main = 0;
   if (p.trace) t_start = __builtin_readcyclecounter();
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
     }
   }
   if (p.trace && tid == 0) {
-    unsigned long long* tr = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    unsigned long long* tr = p.trace + (size_t)blockIdx.x * 4;
     tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
     tr[3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
   }

@@ -267,7 +267,7 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
-  dim3 grid(tiles, a.CoutPad / (32 * NT));
+  dim3 grid(tiles * (a.CoutPad / (32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
   hipLaunchKernelGGL(kern, grid, dim3(64 * (TILE_H / MR)), lds, st, a);
   return hipGetLastError();
 }
