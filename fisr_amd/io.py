@@ -3,9 +3,10 @@
   .flo   FISR's 5-D flow container: reader utils.py:57-74 (`read_flo_file_5dim`), writer
          FISR_tfoptflow/FISR_for_video_pwcnet_predict_from_img_test.py:57-81 (`write_flow`).
   warp   the reference stores warped frames in a MATLAB v7.3 (HDF5) `.mat` written by
-         hdf5storage (warp script :131-136) and reads it with h5py (utils.py:45-54).  h5py is an
-         optional dependency here; a `.npy` holding the same [N,N_seq,H,W,3] float32 0..255
-         array is accepted everywhere a `.mat` is.
+         hdf5storage (warp script :131-136) and reads it with h5py (utils.py:45-54).  h5py is used
+         when importable, otherwise fisr_amd/hdf5_min.py (the subset of the HDF5 file format those
+         files use); a `.npy` holding the same [N,N_seq,H,W,3] float32 0..255 array is accepted
+         everywhere a `.mat` is.
   PNG    frames are YUV packed in 8-bit RGB PNGs (README.md:38-55), read with PIL.
 """
 from __future__ import annotations
@@ -55,11 +56,12 @@ def read_warp_file(filename: str, key: str = "pred") -> np.ndarray:
     else:
         try:
             import h5py
-        except ImportError as e:
-            raise ImportError(f"{filename}: reading HDF5 .mat needs h5py (not installed); "
-                              "save the array as .npy instead") from e
-        with h5py.File(filename, "r") as f:
-            a = np.array(f[key], dtype=np.float32)
+        except ImportError:
+            from . import hdf5_min                  # the subset of HDF5 those files use, restated
+            a = hdf5_min.read_dataset(filename, key)
+        else:
+            with h5py.File(filename, "r") as f:
+                a = np.array(f[key], dtype=np.float32)
         a = np.transpose(a, (4, 3, 2, 1, 0))            # utils.py:52 (MATLAB dims are reversed on disk)
     a = np.asarray(a, np.float32)
     if a.ndim != 5 or a.shape[4] != 3:
@@ -73,12 +75,16 @@ def write_warp_file(filename: str, pred: np.ndarray) -> None:
     if ext == ".npy":
         np.save(filename, pred)
         return
+    disk = np.ascontiguousarray(np.transpose(pred, (4, 3, 2, 1, 0)))     # hdf5storage reverses the dimension order
     try:
         import h5py
-    except ImportError as e:
-        raise ImportError("writing .mat needs h5py; use a .npy path") from e
+    except ImportError:
+        from . import hdf5_min
+        hdf5_min.write_dataset(filename, "pred", disk, chunks=hdf5_min.auto_chunks(disk.shape, 4),
+                               compress=7, shuffle=True, checksum=True, matlab=True)
+        return
     with h5py.File(filename, "w") as f:
-        f.create_dataset("pred", data=np.transpose(pred, (4, 3, 2, 1, 0)))
+        f.create_dataset("pred", data=disk)
 
 
 def read_png(path: str) -> np.ndarray:

@@ -41,13 +41,13 @@ def scene(tmp_path_factory, gold_dir, syn_weights, syn_blob):
         preds.append(O.tiled_forward(inp.astype(np.float32), None, (1, 1),
                                      forward=lambda t: C.forward(t, syn_blob, True)[2]))
     # pseudo ground truth: the 7 unique HR frames = oracle predictions + noise, quantised to uint8 PNGs
+    # (frame k is scored once, from window min(k//2, 2): FISRnet.py:913-920)
     rng = np.random.default_rng(5)
     gt = {}
-    for s in range(3):
-        for f in range(3):
-            k = 2 * s + f
-            if k not in gt:
-                gt[k] = np.clip(np.round((preds[s][..., 3 * f:3 * f + 3] + rng.normal(0, 0.01, (192, 192, 3))) * 255), 0, 255).astype(np.uint8)
+    for k in range(7):
+        s = min(k // 2, 2)
+        f = k - 2 * s
+        gt[k] = np.clip(np.round((preds[s][..., 3 * f:3 * f + 3] + rng.normal(0, 0.01, (192, 192, 3))) * 255), 0, 255).astype(np.uint8)
     for k in range(7):
         fio.write_png(str(hr / f"HR_vid_1_fr_07171_seq_{k + 1:02d}.png"), gt[k])
     return dict(root=root, preds=preds, gt=gt, g=g)
@@ -168,4 +168,101 @@ def test_phase_test_full_size_precisions_agree(tmp_path_factory, syn_weights):
     for prec in ("bf16x3", "f16f8"):
         for key, tol in (("FISR_PSNR", 0.02), ("SR_PSNR", 0.02), ("FISR_SSIM", 1e-3), ("SR_SSIM", 1e-3)):
             assert abs(res[prec][key] - res["fp32"][key]) <= tol, (prec, key, res[prec][key], res["fp32"][key])
+    net.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# cfg3 of BASELINE.json ("full 4K test set (10 scenes), tiled inference, PSNR/SSIM match vs HR_HFR"),
+# emulated as SURVEY.md 8(d) prescribes: the data set is absent, so 10 synthetic scenes are made from
+# the scene1 crop by seeded circular shifts; pseudo HR_HFR = oracle prediction + Gaussian noise at the
+# published 37.86 dB (FI-SR frames) / 48.07 dB (SR frames).  Reduced to 128x128 LR so the fp64 oracle
+# finishes in seconds; the tiling is the reference's default 2x2 with the 32-px halo (96x96 tiles).
+# ------------------------------------------------------------------------------------------------
+N_SCENES, S3 = 10, 128
+
+
+@pytest.fixture(scope="module")
+def scenes10(tmp_path_factory, gold_dir, syn_weights, syn_blob):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scipy.ndimage import gaussian_filter
+    root = tmp_path_factory.mktemp("cfg3")
+    lr = root / "LR_LFR"; hr = root / "HR_HFR"; ck = root / "checkpoint_dir" / "FISRnet_exp1"
+    for d in (lr, hr, ck):
+        d.mkdir(parents=True)
+    weights.save_npz(str(ck / "FISRnet-122000.npz"), syn_weights)
+    base = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))["frames"]           # [5,96,96,3] uint8 YUV
+    base = np.pad(base, ((0, 0), (0, S3 - 96), (0, S3 - 96), (0, 0)), mode="wrap")
+    rng = np.random.default_rng(1234)
+    flows = np.zeros((N_SCENES, 8, S3, S3, 2), np.float32)
+    warps = np.zeros((N_SCENES, 8, S3, S3, 3), np.float32)
+    preds, gts = [], []
+    sig = {0: 10 ** (-37.86 / 20), 1: 10 ** (-48.07 / 20), 2: 10 ** (-37.86 / 20)}
+    for sc in range(N_SCENES):
+        dy, dx = rng.integers(0, S3, 2)
+        frames = np.roll(base, (int(dy), int(dx)), axis=(1, 2))
+        for i in range(5):
+            fio.write_png(str(lr / f"LR_vid_{sc:02d}_seq_{2 * i + 1}.png"), frames[i])
+        f = gaussian_filter(rng.normal(0, 4, (8, S3, S3, 2)), sigma=(0, 8, 8, 0)) * 8
+        flows[sc] = f.astype(np.float32)
+        for k in range(4):
+            warps[sc, 2 * k] = O.warp_frame(frames[k + 1], flows[sc, 2 * k])
+            warps[sc, 2 * k + 1] = O.warp_frame(frames[k], flows[sc, 2 * k + 1])
+        fl = O.merge_seq_dim(flows[sc:sc + 1])
+        wp = O.merge_seq_dim(warps[sc:sc + 1] / np.float32(255.))
+        sp, gt = [], {}
+        for s in range(3):
+            img9 = np.concatenate([frames[s + k] for k in range(3)], axis=2)
+            inp = O.assemble_input(img9, fl[0, :, :, 4 * s:4 * s + 8], wp[0, :, :, 6 * s:6 * s + 12])
+            sp.append(O.tiled_forward(inp.astype(np.float32), None, (2, 2),
+                                      forward=lambda t: C.forward(t, syn_blob, True)[2]))
+        for k in range(7):                      # frame k is scored once, from window min(k//2, 2) (FISRnet.py:913-920)
+            s = min(k // 2, 2)
+            fr = k - 2 * s
+            noisy = sp[s][..., 3 * fr:3 * fr + 3] + rng.normal(0, sig[fr], (2 * S3, 2 * S3, 3))
+            gt[k] = np.clip(np.round(noisy * 255), 0, 255).astype(np.uint8)
+        for k in range(7):
+            fio.write_png(str(hr / f"HR_vid_{sc:02d}_seq_{k + 1:02d}.png"), gt[k])
+        preds.append(sp); gts.append(gt)
+    fio.write_flow(flows, str(root / "flow.flo"))
+    fio.write_warp_file(str(root / "warp.npy"), warps)
+    return dict(root=root, preds=preds, gts=gts)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "f16f8"])
+def test_phase_test_cfg3_ten_scenes(scenes10, prec, capsys):
+    from fisr_amd.fisrnet import FISRnet
+    r = scenes10["root"]
+    args = fmain.parse_args([
+        "--phase", "test", "--test_data_path", str(r / "LR_LFR"), "--test_label_path", str(r / "HR_HFR"),
+        "--test_flow_data_path", str(r / "flow.flo"), "--test_warped_data_path", str(r / "warp.npy"),
+        "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(r / f"out_{prec}"),
+        "--text_dir", str(r / "text"), "--log_dir", str(r / "log"),
+        "--test_patch", "2,2", "--test_input_size", f"{S3},{S3}", "--precision", prec])
+    net = FISRnet(args)
+    res = net.test()
+    out = capsys.readouterr().out
+    assert out.count(" <Test> [") == 3 * N_SCENES
+    fisr_psnr, sr_psnr, fisr_ssim, sr_ssim = [], [], [], []
+    for sc in range(N_SCENES):
+        for s in range(3):
+            p = scenes10["preds"][sc][s]
+            ps, ss = [], []
+            for f in range(3):
+                gt_u8 = scenes10["gts"][sc][2 * s + f]
+                ps.append(O.compute_psnr(p[..., 3 * f:3 * f + 3], gt_u8.astype(np.float64) / 255., 1.0))
+                ss.append(ssim_pil(O.quantize_u8(p[..., 3 * f:3 * f + 3]), (gt_u8.astype(np.float64) / 255. * 255).astype("uint8")))
+            fisr_psnr.append(ps[0]); sr_psnr.append(ps[1]); fisr_ssim.append(ss[0]); sr_ssim.append(ss[1])
+            if s == 2:
+                fisr_psnr.append(ps[2]); fisr_ssim.append(ss[2])
+    exp = dict(FISR_PSNR=np.mean(fisr_psnr), SR_PSNR=np.mean(sr_psnr), FISR_SSIM=np.mean(fisr_ssim), SR_SSIM=np.mean(sr_ssim))
+    print(prec, "hip", res, "oracle", exp)
+    # the pseudo ground truth sits at the published operating point (README.md:97), so the +-0.02 dB /
+    # 1e-3 tolerance is exercised where it is meant to apply
+    assert 36.5 < exp["FISR_PSNR"] < 39 and 46 < exp["SR_PSNR"] < 50
+    assert abs(res["FISR_PSNR"] - exp["FISR_PSNR"]) <= 0.02
+    assert abs(res["SR_PSNR"] - exp["SR_PSNR"]) <= 0.02
+    assert abs(res["FISR_SSIM"] - exp["FISR_SSIM"]) <= 1e-3
+    assert abs(res["SR_SSIM"] - exp["SR_SSIM"]) <= 1e-3
+    assert len(os.listdir(r / f"out_{prec}" / "FISRnet_exp1")) == 7 * N_SCENES
     net.close()

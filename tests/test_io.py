@@ -38,11 +38,118 @@ def test_warp_file_npy_and_merge(tmp_path, gold_dir):
     with pytest.raises(ValueError):
         np.save(p, a[..., :2]); fio.read_warp_file(p)
     assert np.array_equal(fio.merge_seq_dim(g["seq_in"]), g["merge_seq"])
+    # .mat (HDF5) goes through h5py when importable, else through the restated subset
+    pm = str(tmp_path / "w.mat")
+    fio.write_warp_file(pm, a)
+    assert np.array_equal(fio.read_warp_file(pm), a)
+    with pytest.raises((ValueError, OSError)):
+        open(pm, "wb").write(b"not hdf5" * 100); fio.read_warp_file(pm)
+
+
+HDF5_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hdf5")
+CONDA_PY = "/opt/conda/bin/python3.9"          # an unrelated anaconda tree in this image that has h5py
+
+
+def test_hdf5_reader_vs_files_written_by_h5py():
+    """tests/golden/hdf5/*.mat come from h5py 3.3.0 / libhdf5 1.10.6 (oracle/make_golden_hdf5.py)."""
+    from fisr_amd import hdf5_min as H
+    e = np.load(os.path.join(HDF5_DIR, "expect.npz"))
+    disk = np.transpose(e["warp"], (4, 3, 2, 1, 0))
+    for name, key, exp in (("contig", "pred", disk), ("chunked", "pred", disk), ("auto", "pred", disk),
+                           ("auto", "other", np.arange(10, dtype=np.int16)), ("auto", "grp/x", np.arange(6.).reshape(2, 3)),
+                           ("auto", "be", np.arange(5, dtype=np.uint32)), ("latest", "pred", disk), ("latest", "c", disk),
+                           ("manychunks", "pred", e["big"])):
+        got = H.read_dataset(os.path.join(HDF5_DIR, name + ".mat"), key)
+        assert got.dtype == exp.dtype and got.shape == exp.shape and np.array_equal(got, exp), (name, key)
+    assert H.list_names(os.path.join(HDF5_DIR, "auto.mat")) == ["be", "grp", "other", "pred"]
+    with pytest.raises(KeyError):
+        H.read_dataset(os.path.join(HDF5_DIR, "auto.mat"), "nope")
+    with pytest.raises(H.Hdf5Error):
+        H.read_dataset(os.path.join(HDF5_DIR, "auto.mat"), "grp")           # a group is not a dataset
+    # the reference's reader (utils.py:45-54) on the hdf5storage-style fixture, through the io layer
+    import fisr_amd.hdf5_min  # noqa: F401
+    got = H.read_dataset(os.path.join(HDF5_DIR, "chunked.mat"), "pred")
+    assert np.array_equal(np.transpose(got, (4, 3, 2, 1, 0)), e["warp"])
+    # a corrupted chunk is caught by the fletcher32 filter
+    raw = bytearray(open(os.path.join(HDF5_DIR, "chunked.mat"), "rb").read())
+    raw[-40] ^= 0x10
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".mat") as t:
+        t.write(bytes(raw)); t.flush()
+        with pytest.raises((H.Hdf5Error, Exception)):
+            H.read_dataset(t.name, "pred")
+
+
+def test_hdf5_reader_on_a_real_matlab_file():
+    """scipy ships a MATLAB-written v7.3 file in its test data."""
+    from fisr_amd import hdf5_min as H
+    scipy_io = pytest.importorskip("scipy.io")
+    p = os.path.join(os.path.dirname(scipy_io.__file__), "matlab", "tests", "data", "testhdf5_7.4_GLNX86.mat")
+    if not os.path.isfile(p):
+        pytest.skip("scipy test data not installed")
+    assert H.list_names(p) == ["testdouble"]
+    a = H.read_dataset(p, "testdouble")
+    assert a.dtype == np.float64 and a.ndim == 2 and a.size == 9          # MATLAB: 0:pi/4:2*pi
+    np.testing.assert_allclose(a.ravel(), np.arange(9) * np.pi / 4, rtol=0, atol=1e-15)
+
+
+def test_hdf5_writer_roundtrip_and_fletcher(tmp_path):
+    from fisr_amd import hdf5_min as H
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64, np.uint8, np.int16):
+        a = (rng.random((3, 17, 9, 4, 2)) * 255).astype(dt)
+        for kw in (dict(), dict(chunks=(1, 5, 9, 2, 2)), dict(chunks=(3, 4, 4, 3, 1), compress=7, shuffle=True, checksum=True),
+                   dict(chunks=(1, 1, 2, 1, 1), shuffle=True), dict(chunks=(2, 17, 9, 4, 2), compress=1, matlab=False)):
+            p = str(tmp_path / "t.mat")
+            H.write_dataset(p, "pred", a, **kw)
+            b = H.read_dataset(p, "pred")
+            assert b.dtype == a.dtype and np.array_equal(a, b), (dt, kw)
+    # H5_checksum_fletcher32 restated literally (16-bit big-endian words, 360-word folding) vs the vectorised one
+    def ref(data):
+        s1 = s2 = 0
+        i, ln = 0, len(data) // 2
+        while ln:
+            t = min(360, ln); ln -= t
+            for _ in range(t):
+                s1 += (data[i] << 8) | data[i + 1]; i += 2; s2 += s1
+            s1 = (s1 & 0xffff) + (s1 >> 16); s2 = (s2 & 0xffff) + (s2 >> 16)
+        if len(data) % 2:
+            s1 += data[-1] << 8; s2 += s1
+            s1 = (s1 & 0xffff) + (s1 >> 16); s2 = (s2 & 0xffff) + (s2 >> 16)
+        s1 = (s1 & 0xffff) + (s1 >> 16); s2 = (s2 & 0xffff) + (s2 >> 16)
+        return (s2 << 16) | s1
+    for n in (0, 1, 2, 3, 7, 720, 721, 5000, 9999):
+        x = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert H.fletcher32(x) == ref(x), n
+    assert H.fletcher32(b"\xff\xff" * 3) == ref(b"\xff\xff" * 3) == 0xFFFFFFFF and H.fletcher32(b"\0" * 10) == 0
+    assert H.auto_chunks((3, 1920, 1080, 8, 1), 4) and np.prod(H.auto_chunks((3, 1920, 1080, 8, 1), 4)) * 4 <= 1 << 20
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="no anaconda h5py in this image")
+def test_hdf5_writer_is_readable_by_libhdf5(tmp_path):
+    """Files from the restated writer are opened by the real library (h5py 3.3.0 in /opt/conda)."""
+    import subprocess
+    a = (np.random.default_rng(3).random((1, 4, 24, 40, 3)) * 255).astype(np.float32)
+    fio_h5py = None
     try:
-        import h5py  # noqa: F401
+        import h5py as fio_h5py  # noqa: F401
     except ImportError:
-        with pytest.raises(ImportError):
-            fio.read_warp_file(str(tmp_path / "x.mat"))
+        pass
+    if fio_h5py is not None:
+        pytest.skip("io layer already uses h5py here")
+    fio.write_warp_file(str(tmp_path / "w.mat"), a)
+    np.save(str(tmp_path / "a.npy"), a)
+    code = ("import h5py, numpy as np, sys\n"
+            "a = np.load(sys.argv[2])\n"
+            "with h5py.File(sys.argv[1], 'r') as f:\n"
+            "    d = f['pred']\n"
+            "    b = np.transpose(np.array(d, dtype=np.float32), (4, 3, 2, 1, 0))   # utils.py:45-54\n"
+            "    assert (a == b).all() and d.compression == 'gzip' and d.shuffle and d.fletcher32\n"
+            "    assert d.attrs['MATLAB_class'] == b'single' and f.userblock_size == 512\n"
+            "print('OK')\n")
+    r = subprocess.run([CONDA_PY, "-W", "ignore", "-c", code, str(tmp_path / "w.mat"), str(tmp_path / "a.npy")],
+                       capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
 def test_tf_bundle_roundtrip(tmp_path, syn_weights):
