@@ -524,6 +524,68 @@ def test_full_size_tile_sparse_golden(net32, gold_dir):
     _report(got, g["l3_sparse"], F32_FWD_TOL, "544x992 tile sparse grid")
 
 
+@pytest.mark.parametrize("engine", ["net32", "netx3"])
+def test_full_size_batch_of_twelve_equals_single_tiles(engine, request, gold_dir):
+    """The bench's schedule (all 12 tiles of a 5-frame 1080p stack in one forward: activations of up to
+    1.66e9 elements / 6.6e9 bytes) must give, tile for tile, exactly what the reference's one-tile-at-a-time
+    schedule gives -- the kernels' work order is batch-independent -- and tile 0 must match the oracle's
+    sparse golden grid.  Guards the 64-bit indexing at the largest sizes the path sees."""
+    net = request.getfixturevalue(engine)
+    from tests_support import make_full_size_input
+    g = np.load(os.path.join(gold_dir, "model_544x992_sparse.npz"))
+    x0 = torch.from_numpy(make_full_size_input(int(g["seed"]), 544, 992)).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.rand((12, 544, 992, 29), device="cuda", generator=gen)
+    x[:, :, :, 9:17] = (x[:, :, :, 9:17] - 0.5) * 0.4
+    x[0] = x0[0]
+    x[11] = x0[0]
+    l1, l2, l3 = net.model(x)
+    torch.cuda.synchronize()
+    for t in (0, 5, 11):
+        s1, s2, s3 = net.model(x[t:t + 1].contiguous())
+        assert torch.equal(s3[0], l3[t]) and torch.equal(s2[0], l2[t]) and torch.equal(s1[0], l1[t]), f"tile {t}"
+    st = int(g["stride"])
+    tol = F32_FWD_TOL if engine == "net32" else 5e-4
+    for t in (0, 11):
+        _report(l3[t, ::st, ::st, :].cpu().numpy(), g["l3_sparse"], tol, f"batched tile {t} sparse grid")
+    del l1, l2, l3, x
+    torch.cuda.empty_cache()
+
+
+def test_c_host_through_the_c_abi(tmp_path, gold_dir, syn_weights):
+    """examples/c_host.c: a host in plain C99 (gcc, HIP runtime C API, include/fisr.h -- no Python, no torch
+    in the process) loads the 276 variables, runs the forward and must reproduce the golden outputs."""
+    import shutil
+    import struct
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no gcc / ROCm headers")
+    from fisr_amd import lib as flib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so_dir = os.path.dirname(flib.SO_PATH)
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"),
+                           "-I", "/opt/rocm/include", os.path.join(root, "examples", "c_host.c"), "-o", exe,
+                           "-L", so_dir, "-lfisr_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{so_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    g = np.load(os.path.join(gold_dir, "model_32x64.npz"))
+    with open(tmp_path / "weights.bin", "wb") as f:
+        extra = {"FISRnet/level_1/enc/level_0/conv/0/w/Adam": np.zeros((3, 3, 29, 64), np.float32), "beta1_power": np.ones((1,), np.float32)}
+        for name, arr in list(syn_weights.items()) + list(extra.items()):      # a training checkpoint also holds optimizer slots
+            a = np.ascontiguousarray(arr, np.float32)
+            nb = name.encode()
+            f.write(struct.pack("<i", len(nb)) + nb + struct.pack("<i", a.ndim) + struct.pack(f"<{a.ndim}q", *a.shape) + a.tobytes())
+    with open(tmp_path / "input.bin", "wb") as f:
+        f.write(struct.pack("<3i", *g["x"].shape[:3]) + np.ascontiguousarray(g["x"], np.float32).tobytes())
+    for prec, tol in ((0, F32_FWD_TOL), (2, 5e-4), (3, 2e-3)):
+        r = subprocess.run([exe, str(tmp_path / "weights.bin"), str(tmp_path / "input.bin"), str(tmp_path / "out.bin"), str(prec)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "variables set: 276 (ignored 2)" in r.stdout, r.stdout
+        got = np.fromfile(tmp_path / "out.bin", np.float32).reshape(g["l3"].shape)
+        _report(got, g["l3"], tol, f"c_host precision {prec} pred_l3")
+
+
 def test_ssim_kernel_vs_oracle(net32):
     """fisr_ssim_u8 (on-GPU SSIM_PIL restatement) vs the oracle's numpy restatement."""
     rng = np.random.default_rng(31)
