@@ -152,6 +152,24 @@ class FISRnet:
                                         ws.numel(), _stream(self.device)), self._ctx)
         return l1, l2, l3
 
+    def capture(self, n: int, h: int, w: int, want_all: bool = True):
+        """One forward of a fixed shape captured into a HIP graph (the ~300 launches of a forward are
+        launch-bound below ~128x128 inputs): returns (graph, static_input, (pred_l1, pred_l2, pred_l3)).
+        Copy a new input into `static_input`, `graph.replay()`, read the static outputs.  fisr_forward is
+        capture-safe: no allocation, synchronisation or host read-back happens inside it."""
+        torch = _torch()
+        static_in = torch.zeros((n, h, w, 29), dtype=torch.float32, device=self.device)
+        self._workspace(n, h, w)                       # allocated outside the capture, kept by the ctx mirror
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                  # warm-up run (sets kernel attributes) on the side stream
+            self.model(static_in, want_all=want_all)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self.model(static_in, want_all=want_all)
+        return graph, static_in, outs
+
     # ------------------------------------------------------------------ profiling hooks
     def profile(self, on) -> None:
         """on: 0/False off, 1/True per kernel class, 2 per layer."""
