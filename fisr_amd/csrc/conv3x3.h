@@ -122,6 +122,90 @@ __device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) 
   lo = bf16_bits(v - bf16_to_f32(hi));
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair (one v_cvt_pk_bf16_f32, round-to-nearest-even); a in the low half
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  f32x2_t v; v.x = a; v.y = b;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// 16-channel record <-> 16 floats: what one lane of the conv kernel owns per accumulator tile.
+//   float   : 64 B = 16 fp32                 _Float16: 32 B = 16 fp16
+//   bsplit  : 32 B hi + 32 B lo              fsplit  : 32 B h + 16 B l8 + 16 B h8
+template <typename T> struct Rec16;
+template <> struct Rec16<float> {
+  static constexpr int NV = 4;   // 16-byte vectors per record
+  static __device__ __forceinline__ void decode(const uint4* q, float* v) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 f = __builtin_bit_cast(f32x4, q[k]);
+      v[4 * k] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w;
+    }
+  }
+  static __device__ __forceinline__ void encode(const float* v, uint4* q) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 f; f.x = v[4 * k]; f.y = v[4 * k + 1]; f.z = v[4 * k + 2]; f.w = v[4 * k + 3];
+      q[k] = __builtin_bit_cast(uint4, f);
+    }
+  }
+};
+template <> struct Rec16<_Float16> {
+  static constexpr int NV = 2;
+  static __device__ __forceinline__ void decode(const uint4* q, float* v) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const f16x8 f = __builtin_bit_cast(f16x8, q[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[8 * k + i] = (float)f[i];
+    }
+  }
+  static __device__ __forceinline__ void encode(const float* v, uint4* q) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      f16x8 f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = (_Float16)v[8 * k + i];
+      q[k] = __builtin_bit_cast(uint4, f);
+    }
+  }
+};
+template <> struct Rec16<bsplit> {
+  static constexpr int NV = 4;   // q[0..1] = hi (channels 0-7, 8-15), q[2..3] = lo
+  static __device__ __forceinline__ void decode(const uint4* q, float* v) {
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      v[2 * d] = __builtin_bit_cast(float, h[d] << 16) + __builtin_bit_cast(float, h[8 + d] << 16);
+      v[2 * d + 1] = __builtin_bit_cast(float, h[d] & 0xffff0000u) + __builtin_bit_cast(float, h[8 + d] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void encode(const float* v, uint4* q) {
+    uint32_t* h = reinterpret_cast<uint32_t*>(q);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const uint32_t hi = cvt_pk_bf16(v[2 * d], v[2 * d + 1]);
+      h[d] = hi;
+      h[8 + d] = cvt_pk_bf16(v[2 * d] - __builtin_bit_cast(float, hi << 16), v[2 * d + 1] - __builtin_bit_cast(float, hi & 0xffff0000u));
+    }
+  }
+};
+template <> struct Rec16<fsplit> {
+  static constexpr int NV = 4;   // q[0..1] = h, q[2] = l8, q[3] = h8
+  static __device__ __forceinline__ void decode(const uint4* q, float* v) {
+    fsplit_decode8(q[0], make_uint2(q[2].x, q[2].y), v);
+    fsplit_decode8(q[1], make_uint2(q[2].z, q[2].w), v + 8);
+  }
+  static __device__ __forceinline__ void encode(const float* v, uint4* q) {
+    uint2 l0, l1, g0, g1;
+    fsplit_encode8(v, q[0], l0, g0);
+    fsplit_encode8(v + 8, q[1], l1, g1);
+    q[2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    q[3] = make_uint4(g0.x, g0.y, g1.x, g1.y);
+  }
+};
+
 template <typename T> struct Prec;
 
 template <> struct Prec<float> {
@@ -132,10 +216,10 @@ template <> struct Prec<float> {
   static constexpr bool PAIR_LOAD = false;
   typedef f32x4 Frag;
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0].x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0].y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0].z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0].w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].x, a[0].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].y, a[0].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].z, a[0].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0].w, a[0].w, acc, 0, 0, 0);
   }
   template <int MR_, int NT_>
   static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[MR_][NT_], const Frag (&a)[MR_][NF], const Frag (&b)[NT_][NF]) {
@@ -159,7 +243,7 @@ template <> struct Prec<_Float16> {
   static constexpr bool PAIR_LOAD = false;
   typedef f16x8 Frag;
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0], a[0], acc, 0, 0, 0);
   }
   template <int MR_, int NT_>
   static __device__ __forceinline__ void mma_tiles(f32x16 (&acc)[MR_][NT_], const Frag (&a)[MR_][NF], const Frag (&b)[NT_][NF]) {
@@ -184,9 +268,9 @@ template <> struct Prec<bsplit> {
   static constexpr bool PAIR_LOAD = true;
   typedef bf16x8 Frag;
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);  // lo * hi
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);  // hi * lo
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);  // hi * hi
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], acc, 0, 0, 0);  // w_hi * a_lo
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1], a[0], acc, 0, 0, 0);  // w_lo * a_hi
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0], acc, 0, 0, 0);  // w_hi * a_hi
   }
   // Term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependency).
   template <int MR_, int NT_>
@@ -197,7 +281,7 @@ template <> struct Prec<bsplit> {
       for (int m = 0; m < MR_; ++m)
 #pragma unroll
         for (int j = 0; j < NT_; ++j)
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][term == 0 ? 1 : 0], b[j][term == 1 ? 1 : 0], acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][term == 1 ? 1 : 0], a[m][term == 0 ? 1 : 0], acc[m][j], 0, 0, 0);
   }
   static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused (pair form below)
   // relu of 8 split values: a value is negative iff its hi part is (lo is a correction of hi)
@@ -306,16 +390,51 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   const int nb = t / tiles_y;
   const int x0 = tx * TILE_W, y0 = ty * TILE_H;
 
-  unsigned long long t_start = 0, t_main = 0;
+  unsigned long long t_start = 0, t_main = 0, t_first = 0;
   if (p.trace) t_start = __builtin_readcyclecounter();
 
+  // Accumulator tile [m][j] of lane (li, kh): pixel (y0 + wave*MR + m, x0 + li), channels
+  // n0 + 32*j + 16*kh + r for register r (the weights are the MFMA row operand and the host packs
+  // the rows of every 32-channel group in that order) -- i.e. exactly one 16-channel record of the
+  // activation formats.  The accumulators START from bias (+ residual): both are fetched here, next to
+  // the first chunk's loads, so no residual latency is left for the epilogue (measured on the box: ~6 us
+  // under load, 20 % of a 64->64 workgroup's life when it was fetched there).
+  typedef Rec16<T> R16;
   f32x16 acc[MR][NT];
+  {
+    uint4 rres[MR][NT][R16::NV];
+    const bool use_res = !OUT_F32 && p.res != nullptr;
+    if (use_res) {
 #pragma unroll
-  for (int m = 0; m < MR; ++m)
+      for (int m = 0; m < MR; ++m) {
+        const int y = min(y0 + wave * MR + m, p.H - 1), x = min(x0 + li, p.W - 1);   // clamped: never stored when outside
+        const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+          const int c0 = min(n0 + 32 * j + 16 * kh, p.Cout - 16);
+          const uint4* q = reinterpret_cast<const uint4*>((const char*)p.res + (gp * p.Cout + c0) * sizeof(T));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+          for (int k = 0; k < R16::NV; ++k) rres[m][j][k] = q[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const f32x4* bq = reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * j + 16 * kh);
+      float bv[16];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const f32x4 f = bq[k]; bv[4 * k] = f.x; bv[4 * k + 1] = f.y; bv[4 * k + 2] = f.z; bv[4 * k + 3] = f.w; }
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        if (use_res) R16::decode(rres[m][j], rv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][j][r] = bv[r] + rv[r];
+      }
+    }
+  }
 
   // ---- loader geometry (identical for every K chunk) ----
   // The halo tile of a chunk is HALO_PIX records of four 16-byte slots.  Normal types: unit
@@ -422,6 +541,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       }
     }
     if (kc < 0 || (FISR_ABL & 8)) continue;
+    if (p.trace && kc == 0) t_first = __builtin_readcyclecounter();   // first chunk staged: prologue over
 
     // ---- 9 taps x KG k-groups of MFMA on the staged chunk ----
     constexpr int NS = P::KG * 9;
@@ -492,14 +612,14 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         for (int m = 0; m < MR; ++m)
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][m], bh[0][j], acc[m][j], 0, 0, 0);
-            if (pair) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][m], bh[1][j], acc[m][j], 0, 0, 0);
+            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0][j], ah[0][m], acc[m][j], 0, 0, 0);
+            if (pair) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1][j], ah[1][m], acc[m][j], 0, 0, 0);
             i32x8 fa, fb;
             fa[0] = ax[m][0].x; fa[1] = ax[m][0].y; fa[2] = ax[m][0].z; fa[3] = ax[m][0].w;
             fa[4] = ax[m][1].x; fa[5] = ax[m][1].y; fa[6] = ax[m][1].z; fa[7] = ax[m][1].w;
             fb[0] = bx[j][0].x; fb[1] = bx[j][0].y; fb[2] = bx[j][0].z; fb[3] = bx[j][0].w;
             fb[4] = bx[j][1].x; fb[5] = bx[j][1].y; fb[6] = bx[j][1].z; fb[7] = bx[j][1].w;
-            acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, acc[m][j], 0, 0, 0, sa, 0, sb);
+            acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, acc[m][j], 0, 0, 0, sb, 0, sa);
           }
       }
     } else {
@@ -547,31 +667,24 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   }
 
   if (p.trace) t_main = __builtin_readcyclecounter();
-  // C/D layout of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // C/D layout of the 32x32 MFMA: column (N = pixel) = lane & 31, row (M = packed channel row)
+  // = (r&3) + 8*(r>>2) + 4*(lane>>5); with the host's row order register r is channel c0 + r.
+  const float relu_floor = p.relu_out ? 0.f : -__builtin_huge_valf();
+  const int x = x0 + li;
   if constexpr (OUT_F32) {
-    // ---- direct epilogue (the 3/6-channel heads): bias, relu, channel-scatter fp32 store ----
-    const int xb = x0 + 4 * kh;        // first pixel column this lane holds
-    const int xlim = p.W - xb;         // columns xb + q are valid for q < xlim
+    // ---- fp32 store with channel scatter (the 3/6-channel heads and ragged Cout) ----
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 32 + li;
-      if (n >= p.Cout) continue;
-      const float bv = p.bias[n];
-      const int nmap = n + p.out_coff + (n >= p.out_split ? p.out_gap : 0);
-      const int step = p.out_cstride;
+    for (int m = 0; m < MR; ++m) {
+      const int y = y0 + wave * MR + m;
+      if (y >= p.H || x >= p.W) continue;
+      float* ob = (float*)p.out + ((size_t)(nb * p.H + y) * p.W + x) * (size_t)p.out_cstride;
 #pragma unroll
-      for (int m = 0; m < MR; ++m) {
-        const int y = y0 + wave * MR + m;
-        if (y >= p.H) continue;
-        const size_t pix = (size_t)(nb * p.H + y) * p.W + xb;
-        float* ob = (float*)p.out + pix * (size_t)step + nmap;
+      for (int j = 0; j < NT; ++j) {
+        const int c0 = n0 + 32 * j + 16 * kh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int q = (r & 3) + 8 * (r >> 2);
-          if (q >= xlim) continue;
-          float v = acc[m][j][r] + bv;
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          ob[q * step] = v;
+          const int n = c0 + r;
+          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = fmaxf(acc[m][j][r], relu_floor);
         }
       }
     }
@@ -585,144 +698,39 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         for (int r = 0; r < 16; ++r) sacc += acc[m][j][r];
     if (sacc == 12345.678f) ((float*)p.out)[0] = sacc;
   } else {
-    // ---- staged epilogue: acc + bias -> LDS [256 px][BN] fp32 -> per-lane 16-byte vectors ----
-    // Every thread owns NU units of UC consecutive channels of one pixel.  The residual vectors
-    // of ALL its units are requested in one go right after the accumulators went to LDS (one
-    // exposed HBM/L2 latency instead of one per unit), then add / relu / convert / 16-byte stores.
-    constexpr int UC = P::UC;                 // channels per unit
-    constexpr int UPP = BN / UC;              // units per pixel
-    constexpr int NU = TILE_H * TILE_W * UPP / NTHR;
-    constexpr int RV = (P::PAIR_LOAD || IsFsplit<T>::value) ? 2 : 1;  // 16-byte residual vectors per unit
+    // ---- record store straight from the accumulators: relu, convert, R16::NV 16-byte stores per tile ----
     const int cq_shift = p.d2s_shift;
-    float* s_o = reinterpret_cast<float*>(smem);
-    __syncthreads();  // all waves are done with the last chunk's LDS reads
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float bv = p.bias[n0 + j * 32 + li];
+    for (int m = 0; m < MR; ++m) {
+      const int y = y0 + wave * MR + m;
+      if (y >= p.H || x >= p.W) continue;
 #pragma unroll
-      for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int col = (r & 3) + 8 * (r >> 2) + 4 * kh;
-          s_o[((wave * MR + m) * TILE_W + col) * BN + j * 32 + li] = acc[m][j][r] + bv;
+      for (int j = 0; j < NT; ++j) {
+        const int c0 = n0 + 32 * j + 16 * kh;
+        if (c0 >= p.Cout) continue;
+        size_t oel;  // first output element (channel slot) of the record
+        if (p.d2s) {
+          const int sub = c0 >> cq_shift, c = c0 & ((1 << cq_shift) - 1);
+          oel = (((size_t)(nb * 2 * p.H + 2 * y + (sub >> 1))) * (2 * p.W) + 2 * x + (sub & 1)) * ((size_t)1 << cq_shift) + c;
+        } else {
+          oel = ((size_t)(nb * p.H + y) * p.W + x) * p.Cout + c0;
         }
-    }
-    uint4 rres[NU][RV];
-    if (p.res) {
+        float v[16];
 #pragma unroll
-      for (int i = 0; i < NU; ++i) {
-        const int u = tid + i * NTHR;
-        const int px = u / UPP, cu = u - px * UPP;
-        const int y = y0 + px / TILE_W, x = x0 + (px & (TILE_W - 1));
-        const int n = n0 + cu * UC;
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[m][j][r], relu_floor);
+        uint4 q[R16::NV];
+        R16::encode(v, q);
+        uint4* ob = reinterpret_cast<uint4*>((char*)p.out + oel * sizeof(T));
 #pragma unroll
-        for (int k = 0; k < RV; ++k) rres[i][k] = make_uint4(0u, 0u, 0u, 0u);
-        if (y < p.H && x < p.W && n < p.Cout) {
-          const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
-          if constexpr (IsFsplit<T>::value) {
-            const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4;
-            const int half = (n >> 3) & 1;
-            rres[i][0] = *reinterpret_cast<const uint4*>(rb + half * 16);
-            const uint2 l8 = *reinterpret_cast<const uint2*>(rb + 32 + half * 8);
-            rres[i][1] = make_uint4(l8.x, l8.y, 0u, 0u);
-          } else if constexpr (P::PAIR_LOAD) {
-            const char* rb = (const char*)p.res + (gp * p.Cout + (n & ~15)) * 4 + ((n >> 3) & 1) * 16;
-            rres[i][0] = *reinterpret_cast<const uint4*>(rb);
-            rres[i][1] = *reinterpret_cast<const uint4*>(rb + 32);
-          } else {
-            rres[i][0] = *reinterpret_cast<const uint4*>((const T*)p.res + gp * p.Cout + n);
-          }
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NU; ++i) {
-      const int u = tid + i * NTHR;
-      const int px = u / UPP, cu = u - px * UPP;
-      const int row = px / TILE_W, col = px - row * TILE_W;
-      const int y = y0 + row, x = x0 + col;
-      const int n = n0 + cu * UC;
-      if (y >= p.H || x >= p.W || n >= p.Cout) continue;
-      float v[UC];
-      {
-        const f32x4* sp = reinterpret_cast<const f32x4*>(s_o + px * BN + cu * UC);
-#pragma unroll
-        for (int k = 0; k < UC / 4; ++k) {
-          const f32x4 q = sp[k];
-          v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-        }
-      }
-      const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
-      size_t oel;  // output element (channel) index
-      if (p.d2s) {
-        const int sub = n >> cq_shift, c = n & ((1 << cq_shift) - 1);
-        oel = (((size_t)(nb * 2 * p.H + 2 * y + (sub >> 1))) * (2 * p.W) + 2 * x + (sub & 1)) * ((size_t)1 << cq_shift) + c;
-      } else {
-        oel = gp * p.Cout + n;
-      }
-      if constexpr (IsFsplit<T>::value) {  // f16f8: 8 channels = 16 B of h, 8 B of l8, 8 B of h8
-        const int half = (n >> 3) & 1;
-        if (p.res) {
-          float rv[8];
-          fsplit_decode8(rres[i][0], make_uint2(rres[i][1].x, rres[i][1].y), rv);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += rv[k];
-        }
-        if (p.relu_out) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        uint4 oh; uint2 ol, og;
-        fsplit_encode8(v, oh, ol, og);
-        char* ob = (char*)p.out + (oel & ~(size_t)15) * 4;
-        *reinterpret_cast<uint4*>(ob + half * 16) = oh;
-        *reinterpret_cast<uint2*>(ob + 32 + half * 8) = ol;
-        *reinterpret_cast<uint2*>(ob + 48 + half * 8) = og;
-      } else if constexpr (sizeof(T) == 4 && !P::PAIR_LOAD) {  // float
-        if (p.res) {
-          const f32x4 rv = __builtin_bit_cast(f32x4, rres[i][0]);
-          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-        }
-        if (p.relu_out) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        *reinterpret_cast<f32x4*>((float*)p.out + oel) = o;
-      } else if constexpr (sizeof(T) == 2) {  // fp16
-        if (p.res) {
-          const f16x8 rv = __builtin_bit_cast(f16x8, rres[i][0]);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
-        }
-        f16x8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (_Float16)(p.relu_out ? fmaxf(v[k], 0.f) : v[k]);
-        *reinterpret_cast<f16x8*>((_Float16*)p.out + oel) = o;
-      } else {  // bsplit: channel c of group g lives at byte (g*64 + (c&15)*2) [hi] and +32 [lo]
-        const int half = (n >> 3) & 1;
-        if (p.res) {
-          const uint16_t* h16 = reinterpret_cast<const uint16_t*>(&rres[i][0]);
-          const uint16_t* l16 = reinterpret_cast<const uint16_t*>(&rres[i][1]);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32(h16[k]) + bf16_to_f32(l16[k]);
-        }
-        uint4 oh, ol;
-        uint16_t* h16 = reinterpret_cast<uint16_t*>(&oh);
-        uint16_t* l16 = reinterpret_cast<uint16_t*>(&ol);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) split_bf16(p.relu_out ? fmaxf(v[k], 0.f) : v[k], h16[k], l16[k]);
-        char* ob = (char*)p.out + (oel & ~(size_t)15) * 4 + half * 16;
-        *reinterpret_cast<uint4*>(ob) = oh;
-        *reinterpret_cast<uint4*>(ob + 32) = ol;
+        for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
       }
     }
   }
   if (p.trace && tid == 0) {
-    unsigned long long* tr = p.trace + (size_t)blockIdx.x * 4;
+    unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
     tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
     tr[3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+    tr[4] = t_first; tr[5] = 0; tr[6] = 0; tr[7] = 0;
   }
 }
 

@@ -166,7 +166,8 @@ inline uint8_t host_fp8_e4m3(float f) {
   return sign | (uint8_t)(((ex + 7) << 3) | ((int)r - 8));
 }
 inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 ? 32 : 16; }
-inline int prec_unit(int precision) { return precision == FISR_PREC_F32 ? 4 : 8; }
+inline int prec_unit(int precision) { return precision == FISR_PREC_F32 ? 4 : 8; }   // glue kernels: channels per 16 bytes
+constexpr int CONV_REC = 16;   // the conv kernel stores whole 16-channel records
 
 // host bf16 round-to-nearest-even (finite inputs)
 inline uint16_t host_bf16(float f) {
@@ -195,7 +196,12 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
     for (int c = 0; c < ci; ++c)
       for (int n = 0; n < co; ++n) {
         const int kc = c / CC, cc = c % CC;
-        char* rec = wp.data() + (((size_t)kc * 9 + tap) * cout_pad + n) * CHUNK_BYTES;
+        // The weights are the MFMA row operand: row m of a 32-channel group ends up in accumulator
+        // register r = (m&3) + 4*(m>>3) of lane half kh = (m>>2)&1.  Packing channel 16*kh + r into row m
+        // makes every lane own 16 CONSECUTIVE channels (one record of the activation formats).
+        const int wi = n & 31, wk = wi >> 4, wr = wi & 15;
+        const int row = (n & ~31) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+        char* rec = wp.data() + (((size_t)kc * 9 + tap) * cout_pad + row) * CHUNK_BYTES;
         const float v = w[((size_t)tap * ci + c) * co + n];
         if constexpr (std::is_same<T, float>::value) {
           reinterpret_cast<float*>(rec)[cc] = v;
@@ -783,13 +789,13 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: bad argument");
   if (!prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: unknown precision");
   const int cc = prec_chunk(precision);
-  if (cout % prec_unit(precision)) {
-    // partial channel units only exist on the fp32-output heads (direct epilogue, no residual)
+  if (cout % CONV_REC) {
+    // partial 16-channel records only exist on the fp32-output heads (channel-scatter store, no residual)
     if (precision == FISR_PREC_F32) out_f32 = 1;
-    if (!out_f32) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: cout must be a multiple of 8 unless out_f32");
+    if (!out_f32) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: cout must be a multiple of 16 unless out_f32");
   }
   if (out_f32 && (res || (flags & FISR_CONV_D2S)))
-    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: the fp32-output (direct) epilogue has no residual / d2s");
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: the fp32-output store has no residual / d2s");
   if (c0 % cc || c1 % cc || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
   if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4)))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two");
@@ -893,8 +899,8 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   unsigned long long* d_trace = nullptr;
   const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) * (cw.cout_pad / (32 * cw.nt));
   if (trace_file) {
-    HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 32));
-    HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 32));
+    HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 64));
+    HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 64));
     a.trace = d_trace;
   }
   hipEvent_t e0, e1;
@@ -913,8 +919,8 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   HIP_OK(nullptr, hipEventElapsedTime(&ms, e0, e1));
   *out_us = (double)ms * 1e3 / iters;
   if (trace_file) {
-    std::vector<unsigned long long> tr(nblocks * 4);
-    HIP_OK(nullptr, hipMemcpy(tr.data(), d_trace, nblocks * 32, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tr(nblocks * 8);
+    HIP_OK(nullptr, hipMemcpy(tr.data(), d_trace, nblocks * 64, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(trace_file, "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
     (void)hipFree(d_trace);
   }

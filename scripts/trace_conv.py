@@ -3,10 +3,17 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, n, h, w, ci, co, fl, rs = sys.argv[1], *map(int, sys.argv[2:9])
-prec = {"fp32": 0, "fp16": 1, "bf16x3": 2}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
+prec = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
 os.environ["FISR_TRACE_FILE"] = out
 from fisr_amd import lib
 L = lib.lib()
 us = ctypes.c_double()
 rc = L.fisr_bench_conv(prec, n, h, w, ci, co, fl, rs, 3, ctypes.byref(us))
 print("rc", rc, "us", us.value, L.fisr_last_error(None) if rc else "")
+
+import numpy as np
+a = np.fromfile(out, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+a = a[a[:, 2] > a[:, 0]]
+t0, tm, te, tf, e1, e2, e3 = a[:, 0], a[:, 1], a[:, 2], a[:, 4], a[:, 5], a[:, 6], a[:, 7]
+med = lambda x: float(np.median(x))
+print(f"blocks {len(a)}  life {med(te - t0):.0f}  prologue {med(tf - t0):.0f}  main(after prologue) {med(tm - tf):.0f}  epilogue {med(te - tm):.0f}")
