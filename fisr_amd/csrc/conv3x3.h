@@ -390,8 +390,8 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   const int nb = t / tiles_y;
   const int x0 = tx * TILE_W, y0 = ty * TILE_H;
 
-  unsigned long long t_start = 0, t_main = 0, t_first = 0;
-  if (p.trace) t_start = __builtin_readcyclecounter();
+  unsigned long long t_start = 0, t_main = 0, t_first = 0, t_real = 0;
+  if (p.trace) { t_start = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
 
   // Accumulator tile [m][j] of lane (li, kh): pixel (y0 + wave*MR + m, x0 + li), channels
   // n0 + 32*j + 16*kh + r for register r (the weights are the MFMA row operand and the host packs
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
     unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
     tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
     tr[3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
-    tr[4] = t_first; tr[5] = 0; tr[6] = 0; tr[7] = 0;
+    tr[4] = t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = 0;   // 100 MHz wall clock
   }
 }
 
