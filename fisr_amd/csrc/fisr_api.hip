@@ -263,14 +263,16 @@ template <typename T> inline int conv_mr() {
 
 template <typename T, int NT, bool OUT_F32, int MR>
 hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
-  static bool attr_done = false;
+  static bool attr_done[64] = {};   // per device: one process may drive several GPUs (one ctx each)
   constexpr size_t lds = conv_lds_bytes<T, NT>();
   auto kern = conv3x3_mfma_kernel<T, NT, OUT_F32, MR>;
-  if (!attr_done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles * (a.CoutPad / (32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
