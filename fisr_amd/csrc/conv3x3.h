@@ -43,7 +43,8 @@
 #include <stdint.h>
 
 // FISR_ABL: performance-diagnosis ablations (WRONG results): bit 1 no global loads/LDS fills after
-// the first chunk, 2 no LDS fragment reads in the tap loop, 4 no epilogue, 8 no MFMAs.
+// the first chunk, 2 no LDS fragment reads in the tap loop, 4 no epilogue, 8 no MFMAs, 16 epilogue without
+// its stores, 32 epilogue without its format conversion.
 #ifndef FISR_ABL
 #define FISR_ABL 0
 #endif
@@ -719,8 +720,16 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[m][j][r], relu_floor);
         uint4 q[R16::NV];
+#if (FISR_ABL & 32)   // ablation: no conversion, raw accumulator bits stored (same bytes)
+#pragma unroll
+        for (int k = 0; k < R16::NV; ++k) q[k] = make_uint4(__float_as_uint(v[4 * k]), __float_as_uint(v[4 * k + 1]), __float_as_uint(v[4 * k + 2]), __float_as_uint(v[4 * k + 3]));
+#else
         R16::encode(v, q);
+#endif
         uint4* ob = reinterpret_cast<uint4*>((char*)p.out + oel * sizeof(T));
+#if (FISR_ABL & 16)   // ablation: conversion kept alive, nothing stored
+        if ((q[0].x ^ q[1].y ^ q[R16::NV - 1].z) == 0x12345678u && p.wexp == 77)
+#endif
 #pragma unroll
         for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
       }
