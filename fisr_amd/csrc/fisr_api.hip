@@ -934,3 +934,5 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
 }
 
 }  // extern "C"
+
+#include "fisr_comm.h"

@@ -143,3 +143,65 @@ def tile_parallel_window(core_input, num_patch: Tuple[int, int], forward: Callab
     if postprocess is not None:
         pred = postprocess(pred)
     return gather_tiles(pred, num_patch, group)
+
+
+class FisrComm:
+    """The C-ABI's own RCCL communicator (include/fisr.h `fisr_comm_*`): the same two collectives for hosts
+    that do not run under torch.distributed.  `unique_id()` on rank 0, ship the 128 bytes to the other ranks
+    by any side channel (here: a torch.distributed broadcast if a group exists, else single rank), `init`."""
+
+    def __init__(self, comm_id: bytes, nranks: int, rank: int, device_index: int):
+        import ctypes
+        from . import lib as _lib
+        self._lib, self._L = _lib, _lib.lib()
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(comm_id), _lib.COMM_ID_BYTES)
+        _lib.check(self._L.fisr_comm_init(ctypes.byref(self._h), buf, nranks, rank, device_index))
+        self.nranks, self.rank = nranks, rank
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from . import lib as _lib
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().fisr_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, device_index: int, group=None):
+        """Bootstrap over an existing torch.distributed group of any backend (the id travels as a CPU tensor)."""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return cls(cls.unique_id(), 1, 0, device_index)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        obj = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        return cls(obj[0], world, rank, device_index)
+
+    def allgather(self, send, recv=None):
+        """send: contiguous device tensor; returns [nranks, *send.shape] (same dtype), async on the current stream."""
+        import ctypes
+        import torch
+        send = send.contiguous()
+        if recv is None:
+            recv = torch.empty((self.nranks,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        st = torch.cuda.current_stream(send.device).cuda_stream
+        self._lib.check(self._L.fisr_comm_allgather(self._h, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()),
+                                                    send.numel() * send.element_size(), ctypes.c_void_p(st)))
+        return recv
+
+    def sendrecv(self, send, peer: int):
+        import ctypes
+        import torch
+        send = send.contiguous()
+        recv = torch.empty_like(send)
+        st = torch.cuda.current_stream(send.device).cuda_stream
+        self._lib.check(self._L.fisr_comm_sendrecv(self._h, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()),
+                                                   send.numel() * send.element_size(), peer, ctypes.c_void_p(st)))
+        return recv
+
+    def close(self):
+        if self._h:
+            self._L.fisr_comm_destroy(self._h)
+            self._h = None

@@ -25,7 +25,10 @@ EXPORTS = [
     "fisr_profile_enable", "fisr_profile_reset", "fisr_profile_read", "fisr_warp", "fisr_pack_input",
     "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_ssim_u8", "fisr_op_conv3x3", "fisr_op_maxpool2",
     "fisr_op_upsample2", "fisr_bench_conv",
+    "fisr_comm_unique_id", "fisr_comm_init", "fisr_comm_rank", "fisr_comm_size", "fisr_comm_allgather",
+    "fisr_comm_sendrecv", "fisr_comm_destroy",
 ]
+COMM_ID_BYTES = 128
 
 
 class FisrError(RuntimeError):
@@ -102,6 +105,14 @@ def lib():
     L.fisr_op_upsample2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_ssim_u8.argtypes = [vp, vp, c_int, c_int, c_int, c_int, POINTER(c_double), vp]
     L.fisr_bench_conv.argtypes = [c_int] * 9 + [POINTER(c_double)]
+    L.fisr_comm_unique_id.argtypes = [vp]
+    L.fisr_comm_init.argtypes = [POINTER(vp), vp, c_int, c_int, c_int]
+    L.fisr_comm_rank.argtypes = [vp]
+    L.fisr_comm_size.argtypes = [vp]
+    L.fisr_comm_allgather.argtypes = [vp, vp, vp, c_size_t, vp]
+    L.fisr_comm_sendrecv.argtypes = [vp, vp, vp, c_size_t, c_int, vp]
+    L.fisr_comm_destroy.argtypes = [vp]
+    L.fisr_comm_destroy.restype = None
     _lib = L
     return L
 

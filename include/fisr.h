@@ -164,6 +164,25 @@ int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int
 int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res,
                     int iters, double* out_us);
 
+/* ---- multi-GPU exchange: thin RCCL wrappers (north_star: "2K->4K tiles shard across the 8 GPUs of one
+ * node with RCCL all-gather of border halos over xGMI"; the reference itself is single-GPU).
+ * One communicator per process / GPU.  librccl is opened lazily (dlopen) on the first call, so a
+ * single-GPU user of this library has no RCCL dependency.  Python hosts under torch.distributed use its
+ * "nccl" backend instead (fisr_amd/dist.py); these are for hosts without torch. ---- */
+typedef struct fisr_comm fisr_comm;
+#define FISR_COMM_ID_BYTES 128
+/* Rank 0 creates the id (host buffer of FISR_COMM_ID_BYTES) and hands it to the other ranks out of band. */
+int fisr_comm_unique_id(void* id_out);
+int fisr_comm_init(fisr_comm** out, const void* id, int nranks, int rank, int device_id);
+int fisr_comm_rank(const fisr_comm* comm);
+int fisr_comm_size(const fisr_comm* comm);
+/* recv[r * bytes_per_rank ...] = send of rank r (device buffers; asynchronous on stream): the gather of
+ * halo strips before a tile-parallel forward and of output tiles after it. */
+int fisr_comm_allgather(fisr_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+/* Exchange `bytes` with one neighbour (send and receive fused in one group; peer may be the own rank). */
+int fisr_comm_sendrecv(fisr_comm* comm, const void* send, void* recv, size_t bytes, int peer, void* stream);
+void fisr_comm_destroy(fisr_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

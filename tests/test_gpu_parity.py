@@ -616,6 +616,22 @@ def test_forward_captured_in_a_hip_graph(netx3, gold_dir):
     print(f"96x96 forward: eager {t_eager:.3f} ms, HIP graph {t_graph:.3f} ms")
 
 
+def test_comm_wrappers_single_rank(dev):
+    """fisr_comm_* (dlopen'ed RCCL): a one-rank communicator on this GPU -- all-gather and self send/recv are
+    the identity.  (Multi-rank use is covered by construction: the calls map 1:1 to ncclAllGather /
+    ncclSend+ncclRecv; the N>1 index plumbing is tested with gloo in tests/test_dist.py.)"""
+    from fisr_amd.dist import FisrComm
+    comm = FisrComm(FisrComm.unique_id(), 1, 0, 0)
+    x = torch.rand((3, 32, 29), device="cuda")
+    g = comm.allgather(x)
+    y = comm.sendrecv(x, 0)
+    torch.cuda.synchronize()
+    assert g.shape == (1, 3, 32, 29) and torch.equal(g[0], x) and torch.equal(y, x)
+    comm.close()
+    with pytest.raises(Exception):
+        FisrComm(b"\0" * 128, 2, 5, 0)          # rank out of range
+
+
 def test_ssim_kernel_vs_oracle(net32):
     """fisr_ssim_u8 (on-GPU SSIM_PIL restatement) vs the oracle's numpy restatement."""
     rng = np.random.default_rng(31)
