@@ -246,6 +246,35 @@ def test_conv3x3_f16f8_vs_oracle(dev, shape):
         assert got.min() >= 0
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16x3", 6e-5), ("f16f8", 6e-4), ("fp16", 2e-2)])
+def test_conv3x3_random_sweep(dev, prec, tol):
+    """Seeded random sweep over the conv op's argument space: ragged H/W (quad-transposed stores with masked
+    pixels), batch, channel counts that are not multiples of 32/64 (padded N-blocks), dual-source concat,
+    relu in/out, residual, depth_to_space, 16-channel-record and fp32-scatter epilogues."""
+    rng = np.random.default_rng({"fp32": 11, "bf16x3": 12, "f16f8": 13, "fp16": 14}[prec])
+    cc = 32 if prec == "fp16" else 16
+    for case in range(14):
+        n = int(rng.integers(1, 3))
+        h, w = int(rng.integers(1, 27)), int(rng.integers(1, 70))
+        c0 = cc * int(rng.integers(1, 5))
+        c1 = cc * int(rng.integers(0, 3)) if rng.random() < 0.4 else 0
+        kind = rng.integers(0, 4)
+        if kind == 0:                                   # fp32-scatter heads / ragged Cout
+            cout, flags, use_res, out_f32 = int(rng.choice([3, 6, 9, 5, 20])), int(rng.integers(0, 4)), False, True
+        elif kind == 1:                                 # depth_to_space store
+            cout, flags, use_res, out_f32 = int(rng.choice([64, 128, 256])), 4 | int(rng.integers(0, 4)), False, False
+        else:                                           # 16-channel records, optional residual
+            cout, flags, use_res, out_f32 = 16 * int(rng.integers(1, 10)), int(rng.integers(0, 4)), bool(rng.random() < 0.5), False
+        x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+        x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+        wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+        got = hip_conv(x0, wt, b, x1, res, flags, prec=prec, out_f32=out_f32)
+        exp = ref_conv(x0, wt, b, x1, res, flags)
+        _report(got, exp, tol, f"{prec} sweep case {case}: n{n} {h}x{w} {c0}+{c1}->{cout} flags {flags} res {use_res} f32out {out_f32}")
+
+
 def test_conv3x3_transpose_detecting(dev):
     """A = delta input, asymmetric weights: catches swapped rows/cols, taps or channel order."""
     x = np.zeros((1, 8, 32, 16), np.float32)
