@@ -176,11 +176,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # test hooks (a 1-GPU box cannot host two RCCL ranks): FISR_BENCH_BACKEND=gloo and FISR_BENCH_ONE_DEVICE=1
+    # run the N > 1 control flow -- rendezvous, barriers, max-over-ranks -- with every rank on cuda:0
+    backend = os.environ.get("FISR_BENCH_BACKEND", "nccl")
+    if os.environ.get("FISR_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from fisr_amd import weights
     from fisr_amd.fisrnet import FISRnet
@@ -206,7 +214,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * UNIQUE_PER_STACK * args.steps / elapsed
@@ -303,9 +311,13 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32_exact": fp32_exact, "parity_vs_fp32": parity,
             "other_precisions": other or None,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        # RCCL keeps an init banner in its C stdio buffer and flushes it at process exit, i.e. AFTER the
+        # JSON line; leave without running the C-level exit handlers so the JSON line stays the last line.
+        dist.barrier()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
