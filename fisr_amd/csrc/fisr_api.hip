@@ -447,15 +447,15 @@ struct Runner {
   }
   void up(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:69
     if (rc || ar.dry) return;
-    const size_t work = (size_t)n * h * w * 4 * c / Unit<T>::UC;
+    const size_t work = (size_t)n * h * w * c / Unit<T>::UC;   // one thread per input unit -> 2x2 output units
     ProfScope ps(ctx, st, "upsample2", 0, (double)n * h * w * c * sizeof(T) * 5.0);
     hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
     check(hipGetLastError(), "upsample2");
   }
   void prep(const float* img, const float* pred, T* out, int n, int H, int W, int s, int cpad) {
     if (rc || ar.dry) return;
-    const size_t work = (size_t)n * (H / s) * (W / s) * cpad;
-    ProfScope ps(ctx, st, "prep_level_input", 0, (double)work * (4 + sizeof(T)));
+    const size_t work = (size_t)n * (H / s) * (W / s) * (cpad / 16);   // one thread per 16-channel record
+    ProfScope ps(ctx, st, "prep_level_input", 0, (double)work * 16 * (4 + sizeof(T)));
     hipLaunchKernelGGL(prep_level_input_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, img, pred, out, n, H, W, s, cpad);
     check(hipGetLastError(), "prep_level_input");
   }
@@ -843,7 +843,7 @@ int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int
   if (!in || !out || !prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: bad argument");
   const int uc = prec_unit(precision);
   if (c % (prec_grouped16(precision) ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of the channel unit");
-  const size_t work = (size_t)n * h * w * 4 * c / uc;
+  const size_t work = (size_t)n * h * w * c / uc;
   with_prec(precision, [&](auto tag) {
     typedef decltype(tag) T;
     hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, n, h, w, c);

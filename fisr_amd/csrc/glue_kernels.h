@@ -86,36 +86,31 @@ template <> struct Unit<fsplit> {   // 8 channels = 16 B of h + 8 B of l8 (+ 8 B
 template <typename T>
 __global__ void prep_level_input_kernel(const float* __restrict__ img, const float* __restrict__ pred,
                                         T* __restrict__ out, int N, int H, int W, int s, int cpad) {
-  const int oh = H / s, ow = W / s;
-  const size_t total = (size_t)N * oh * ow * cpad;
+  // one thread = one 16-channel record of one output pixel (cpad is a multiple of 16; 32 for fp16)
+  typedef Rec16<T> R16;
+  const int oh = H / s, ow = W / s, groups = cpad / 16;
+  const size_t total = (size_t)N * oh * ow * groups;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cpad);
-    const size_t pix = i / cpad;
+    const int g = (int)(i % groups);
+    const size_t pix = i / groups;
     const int x = (int)(pix % ow);
     const int y = (int)((pix / ow) % oh);
     const int n = (int)(pix / ((size_t)ow * oh));
-    float v = 0.f;
-    if (c < 29) v = img[(((size_t)n * H + (size_t)y * s) * W + (size_t)x * s) * 29 + c];
-    else if (pred != nullptr && c < 38) v = pred[pix * 9 + (c - 29)];
-    if constexpr (IsFsplit<T>::value) {
-      const _Float16 h = (_Float16)v;
-      const float hf = (float)h;
-      const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp((v - hf) * (float)(1 << FS_LSHIFT)), fp8_clamp(hf), 0, false);
-      char* rec = reinterpret_cast<char*>(out) + (pix * cpad + (c & ~15)) * 4;
-      reinterpret_cast<_Float16*>(rec)[c & 15] = h;
-      rec[32 + (c & 15)] = (char)(pk & 0xff);
-      rec[48 + (c & 15)] = (char)((pk >> 8) & 0xff);
-    } else if constexpr (sizeof(T) == 4 && Unit<T>::UC == 4) {
-      out[i] = v;
-    } else if constexpr (sizeof(T) == 2) {
-      out[i] = (_Float16)v;
-    } else {
-      uint16_t hi, lo;
-      split_bf16(v, hi, lo);
-      uint16_t* o = reinterpret_cast<uint16_t*>(out) + (pix * cpad + (c & ~15)) * 2 + (c & 15);
-      o[0] = hi;
-      o[16] = lo;
+    const float* ip = img + (((size_t)n * H + (size_t)y * s) * W + (size_t)x * s) * 29;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = 16 * g + k;
+      float t = 0.f;
+      if (c < 29) t = ip[c];
+      else if (pred != nullptr && c < 38) t = pred[pix * 9 + (c - 29)];
+      v[k] = t;
     }
+    uint4 q[R16::NV];
+    R16::encode(v, q);
+    uint4* ob = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + (pix * cpad + 16 * g) * sizeof(T));
+#pragma unroll
+    for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
   }
 }
 
@@ -149,18 +144,18 @@ __global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, i
 template <typename T>
 __global__ void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
 #pragma clang fp contract(off)
+  // One thread = one channel unit of one INPUT pixel: the 2x2 output quad (2y..2y+1, 2x..2x+1) blends the
+  // same four taps (x, x+1 clamped; y, y+1 clamped) with tx, ty in {0, 0.5}: 4 loads -> 4 stores.
   constexpr int UC = Unit<T>::UC;
-  const int oh = H * 2, ow = W * 2, cv = C / UC;
-  const size_t total = (size_t)N * oh * ow * cv;
+  const int ow = W * 2, cv = C / UC;
+  const size_t total = (size_t)N * H * W * cv;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv);
     const size_t pix = i / cv;
-    const int ox = (int)(pix % ow);
-    const int oy = (int)((pix / ow) % oh);
-    const int n = (int)(pix / ((size_t)ow * oh));
-    const int y0 = oy >> 1, y1 = min(y0 + 1, H - 1);
-    const int x0 = ox >> 1, x1 = min(x0 + 1, W - 1);
-    const float ty = (oy & 1) ? 0.5f : 0.f, tx = (ox & 1) ? 0.5f : 0.f;
+    const int x0 = (int)(pix % W);
+    const int y0 = (int)((pix / W) % H);
+    const int n = (int)(pix / ((size_t)W * H));
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const size_t r0 = ((size_t)n * H + y0) * W, r1 = ((size_t)n * H + y1) * W;
     float tl[UC], tr[UC], bl[UC], br[UC], o[UC];
     Unit<T>::load(in + (r0 + x0) * C, c, tl);
@@ -168,12 +163,17 @@ __global__ void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, 
     Unit<T>::load(in + (r1 + x0) * C, c, bl);
     Unit<T>::load(in + (r1 + x1) * C, c, br);
 #pragma unroll
-    for (int k = 0; k < UC; ++k) {
-      const float top = tl[k] + (tr[k] - tl[k]) * tx;
-      const float bot = bl[k] + (br[k] - bl[k]) * tx;
-      o[k] = top + (bot - top) * ty;
+    for (int q = 0; q < 4; ++q) {
+      const float ty = (q & 2) ? 0.5f : 0.f, tx = (q & 1) ? 0.5f : 0.f;
+#pragma unroll
+      for (int k = 0; k < UC; ++k) {
+        const float top = tl[k] + (tr[k] - tl[k]) * tx;
+        const float bot = bl[k] + (br[k] - bl[k]) * tx;
+        o[k] = top + (bot - top) * ty;
+      }
+      const size_t opix = ((size_t)n * 2 * H + 2 * y0 + (q >> 1)) * ow + 2 * x0 + (q & 1);
+      Unit<T>::store(out + opix * C, c, o);
     }
-    Unit<T>::store(out + pix * C, c, o);
   }
 }
 
