@@ -49,6 +49,8 @@
 #define FISR_ABL 0
 #endif
 
+#include <type_traits>
+
 namespace fisr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -378,7 +380,7 @@ struct ConvArgs {
 };
 
 template <typename T, int NT> constexpr size_t conv_lds_bytes() {
-  return (size_t)HALO_PIX * REC_BYTES + (size_t)9 * 32 * NT * REC_BYTES;
+  return (size_t)HALO_PIX * REC_BYTES + (size_t)9 * (NT == 0 ? 16 : 32 * NT) * REC_BYTES;
 }
 
 template <typename T, int NT, bool OUT_F32, int MR>
@@ -386,7 +388,9 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   typedef Prec<T> P;
   typedef typename P::Frag Frag;
   constexpr int CC = P::CC;
-  constexpr int BN = 32 * NT;
+  constexpr int BN = NT == 0 ? 16 : 32 * NT;   // NT = 0: the 16-row heads variant (16x16 MFMAs, Cout <= 16)
+  constexpr int NTA = NT == 0 ? 1 : NT;
+  static_assert(NT != 0 || (OUT_F32 && !IsFsplit<T>::value), "the 16-row variant only has the fp32-scatter epilogue");
   constexpr int EPU = 16 / sizeof(T);  // T elements per 16-byte unit (bsplit counts as 4-byte slots)
   constexpr int NTHR = 64 * (TILE_H / MR);
 
@@ -430,9 +434,10 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   // the first chunk's loads, so no residual latency is left for the epilogue (measured on the box: ~6 us
   // under load, 20 % of a 64->64 workgroup's life when it was fetched there).
   typedef Rec16<T> R16;
-  f32x16 acc[MR][NT];
+  f32x16 acc[MR][NTA];
+  f32x4 acc4[MR][2];   // NT = 0: two 16-pixel column tiles per row, rows 4*(lane>>4)+r = channels
   {
-    uint4 rres[MR][NT][R16::NV];
+    uint4 rres[MR][NTA][R16::NV];
     const bool use_res = !OUT_F32 && p.res != nullptr;
     if (use_res) {
 #pragma unroll
@@ -463,6 +468,11 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][j][r] = bv[r] + rv[r];
       }
+    }
+    if constexpr (NT == 0) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 4 * (lane >> 4));
+#pragma unroll
+      for (int m = 0; m < MR; ++m) { acc4[m][0] = b4; acc4[m][1] = b4; }
     }
   }
 
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 
     // ---- 9 taps x KG k-groups of MFMA on the staged chunk ----
     constexpr int NS = P::KG * 9;
-    auto load_frags = [&](int s_, Frag (&fa)[MR][P::NF], Frag (&fb)[NT][P::NF]) {
+    auto load_frags = [&](int s_, Frag (&fa)[MR][P::NF], Frag (&fb)[NTA][P::NF]) {
       const int kg = s_ / 9, tap = s_ % 9;
       const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
@@ -589,7 +599,72 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         for (int f = 0; f < P::NF; ++f)
           fb[j][f] = *reinterpret_cast<const Frag*>(b_base + (tap * BN + j * 32) * REC_BYTES + kg * 32 + f * 32);
     };
-    if constexpr (IsFsplit<T>::value) {
+    if constexpr (NT == 0) {
+      // ---- 16-row variant for the 3/6-channel heads: v_mfma_f32_16x16x32 (16x16x4 for fp32) with the
+      // weights as the 16-row operand and 16 pixels as columns.  Operand layout (probed,
+      // scripts/probes/mfma16_layout_probe.hip): lane l = (index l&15, K group l>>4), element e <-> K = 8*(l>>4)+e;
+      // result: column l&15, rows 4*(l>>4)+r.  A 64-byte record is exactly one K=32 fragment:
+      //   bsplit  pixel record {hi0,hi1,lo0,lo1} x weight {whi0,whi1,whi0,whi1} = w_hi*a_hi + w_hi*a_lo in ONE
+      //           MFMA per tap; w_lo*a_hi pairs two taps per MFMA ({wlo(t) | wlo(t+1)} x {hi(t) | hi(t+1)}):
+      //           14 instead of 13.5 MFMAs per chunk, and a quarter of the 32x32 formulation's passes per pixel.
+      const int l16 = lane & 15, kg = lane >> 4;
+      const char* pa = s_in + ((wave * MR) * HALO_W + l16) * REC_BYTES;
+      const char* wa = s_w + l16 * REC_BYTES;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        if constexpr (std::is_same<T, float>::value) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(wa + tap * 16 * REC_BYTES + kg * 16);
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(pa + ((m + dy) * HALO_W + ct * 16 + dx) * REC_BYTES + kg * 16);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc4[m][ct], 0, 0, 0);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc4[m][ct], 0, 0, 0);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc4[m][ct], 0, 0, 0);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc4[m][ct], 0, 0, 0);
+            }
+        } else if constexpr (std::is_same<T, _Float16>::value) {
+          const f16x8 a = *reinterpret_cast<const f16x8*>(wa + tap * 16 * REC_BYTES + kg * 16);
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const f16x8 b = *reinterpret_cast<const f16x8*>(pa + ((m + dy) * HALO_W + ct * 16 + dx) * REC_BYTES + kg * 16);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc4[m][ct], 0, 0, 0);
+            }
+        } else {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(wa + tap * 16 * REC_BYTES + (kg & 1) * 16);   // {whi, whi}
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const bf16x8 b = *reinterpret_cast<const bf16x8*>(pa + ((m + dy) * HALO_W + ct * 16 + dx) * REC_BYTES + kg * 16);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4[m][ct], 0, 0, 0);
+            }
+        }
+      }
+      if constexpr (std::is_same<T, bsplit>::value) {
+#pragma unroll
+        for (int tp = 0; tp < 5; ++tp) {
+          const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
+          const bool live = (2 * tp + 1 < 9) || (kg >> 1) == 0;
+          const int offp0 = ((t0 / 3) * HALO_W + (t0 % 3)) * REC_BYTES, offp1 = ((t1 / 3) * HALO_W + (t1 % 3)) * REC_BYTES;
+          const int offp = (kg >> 1) ? offp1 : offp0;
+          const int offw = ((kg >> 1) ? t1 : t0) * 16 * REC_BYTES;
+          bf16x8 a = *reinterpret_cast<const bf16x8*>(wa + offw + 32 + (kg & 1) * 16);                 // w_lo of this lane group's tap
+          if (!live) a = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const bf16x8 b = *reinterpret_cast<const bf16x8*>(pa + (m * HALO_W + ct * 16) * REC_BYTES + offp + (kg & 1) * 16);   // a_hi
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4[m][ct], 0, 0, 0);
+            }
+        }
+      }
+    } else if constexpr (IsFsplit<T>::value) {
       // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-): per accumulator 2 fp16 MFMAs (main term, one per tap)
       // + 1 block-scaled fp8 MFMA carrying both cross terms of both taps.
       // Operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 (probed, scripts/probes/): lane (row, kh)
@@ -606,8 +681,8 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         constexpr int dummy_ = 0; (void)dummy_;
         const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;   // t1 clamped; its data is zeroed
         const bool pair = 2 * tp + 1 < 9;
-        f16x8 ah[2][MR], bh[2][NT];
-        uint4 ax[MR][2], bx[NT][2];
+        f16x8 ah[2][MR], bh[2][NTA];
+        uint4 ax[MR][2], bx[NTA][2];
         // main-term fragments of both taps (all lanes)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -655,7 +730,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
     } else {
 #if (FISR_ABL & 2)
     {
-      Frag fa[MR][P::NF], fb[NT][P::NF];
+      Frag fa[MR][P::NF], fb[NTA][P::NF];
       load_frags(0, fa, fb);
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_) {
@@ -678,7 +753,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
             rows[r][f] = *reinterpret_cast<const Frag*>(a_base + (r * HALO_W + dx) * REC_BYTES + kg * 32 + f * 32);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          Frag fa[MR][P::NF], fb[NT][P::NF];
+          Frag fa[MR][P::NF], fb[NTA][P::NF];
 #pragma unroll
           for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -701,7 +776,26 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   // = (r&3) + 8*(r>>2) + 4*(lane>>5); with the host's row order register r is channel c0 + r.
   const float relu_floor = p.relu_out ? 0.f : -__builtin_huge_valf();
   const int x = x0 + li;
-  if constexpr (OUT_F32) {
+  if constexpr (NT == 0) {
+    // ---- 16-row variant: lane (pixel l&15 of column tile ct, K group kg) holds channels 4*kg + r ----
+    const int l16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const int y = y0 + wave * MR + m;
+      if (y >= p.H) continue;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int xc = x0 + ct * 16 + l16;
+        if (xc >= p.W) continue;
+        float* ob = (float*)p.out + ((size_t)(nb * p.H + y) * p.W + xc) * (size_t)p.out_cstride;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 4 * kg + r;
+          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = fmaxf(acc4[m][ct][r], relu_floor);
+        }
+      }
+    }
+  } else if constexpr (OUT_F32) {
     // ---- fp32 store with channel scatter (the 3/6-channel heads and ragged Cout) ----
 #pragma unroll
     for (int m = 0; m < MR; ++m) {

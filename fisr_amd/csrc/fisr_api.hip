@@ -199,8 +199,9 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
         // The weights are the MFMA row operand: row m of a 32-channel group ends up in accumulator
         // register r = (m&3) + 4*(m>>3) of lane half kh = (m>>2)&1.  Packing channel 16*kh + r into row m
         // makes every lane own 16 CONSECUTIVE channels (one record of the activation formats).
+        // (The 16-row heads variant, cout_pad == 16, keeps the natural order: row = channel.)
         const int wi = n & 31, wk = wi >> 4, wr = wi & 15;
-        const int row = (n & ~31) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+        const int row = cout_pad == 16 ? n : (n & ~31) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
         char* rec = wp.data() + (((size_t)kc * 9 + tap) * cout_pad + row) * CHUNK_BYTES;
         const float v = w[((size_t)tap * ci + c) * co + n];
         if constexpr (std::is_same<T, float>::value) {
@@ -224,14 +225,20 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
   for (int n = 0; n < co; ++n) bp[n] = b[n];
 }
 
-inline int nt_for(int co) { return co <= 32 ? 1 : 2; }
+// N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16,
+// always fp32 output; FISR_CONV_HEAD16=0 turns it off for A/B runs; f16f8 has no 16-row path).
+template <typename T> inline int nt_for(int co) {
+  static const bool head16 = [] { const char* e = getenv("FISR_CONV_HEAD16"); return !(e && e[0] == '0'); }();
+  if (co < 16 && head16 && !std::is_same<T, fsplit>::value) return 0;
+  return co <= 32 ? 1 : 2;
+}
 
 template <typename T>
 int upload_conv(fisr_ctx* ctx, ConvW& cw) {
   constexpr int CC = Prec<T>::CC;
-  cw.nt = nt_for(cw.co);
+  cw.nt = nt_for<T>(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
-  cw.cout_pad = round_up(cw.co, 32 * cw.nt);
+  cw.cout_pad = cw.nt == 0 ? 16 : round_up(cw.co, 32 * cw.nt);
   std::vector<char> wp;
   std::vector<float> bp;
   cw.wexp = 0;
@@ -275,7 +282,7 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
-  dim3 grid(tiles * (a.CoutPad / (32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
+  dim3 grid(tiles * (a.CoutPad / (NT == 0 ? 16 : 32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
   hipLaunchKernelGGL(kern, grid, dim3(64 * (TILE_H / MR)), lds, st, a);
   return hipGetLastError();
 }
@@ -283,6 +290,10 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
 template <typename T>
 hipError_t launch_conv(const ConvArgs& a, int nt, bool out_f32, hipStream_t st) {
   const bool m1 = conv_mr<T>() == 1;
+  if (nt == 0) {
+    if constexpr (std::is_same<T, fsplit>::value) return hipErrorInvalidValue;
+    else return m1 ? launch_conv_variant<T, 0, true, 1>(a, st) : launch_conv_variant<T, 0, true, 2>(a, st);
+  }
   if (nt == 1) {
     if (out_f32) return m1 ? launch_conv_variant<T, 1, true, 1>(a, st) : launch_conv_variant<T, 1, true, 2>(a, st);
     return m1 ? launch_conv_variant<T, 1, false, 1>(a, st) : launch_conv_variant<T, 1, false, 2>(a, st);
@@ -899,7 +910,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   const char* trace_file = getenv("FISR_TRACE_FILE");
   unsigned long long* d_trace = nullptr;
-  const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) * (cw.cout_pad / (32 * cw.nt));
+  const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) * (cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
   if (trace_file) {
     HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 64));
     HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 64));
