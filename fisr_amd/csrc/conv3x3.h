@@ -297,7 +297,11 @@ template <> struct Prec<bsplit> {
   static constexpr int KG = 1;        // one K=16 step per chunk ...
   static constexpr int NF = 2;        // ... on two planes: [0] = hi (bytes 0..31), [1] = lo (bytes 32..63)
   static constexpr int UC = 8;
-  static constexpr bool PAIR_LOAD = true;
+#ifdef FISR_BSPLIT_PAIR_LOAD
+  static constexpr bool PAIR_LOAD = true;    // A/B: a thread loads a hi unit and its lo unit (32-byte pieces per lane pair)
+#else
+  static constexpr bool PAIR_LOAD = false;   // four lanes load the four 16-byte units of a pixel record (64 contiguous bytes)
+#endif
   typedef bf16x8 Frag;
   static __device__ __forceinline__ void mma(f32x16& acc, const Frag* a, const Frag* b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[1], acc, 0, 0, 0);  // w_hi * a_lo
@@ -315,8 +319,19 @@ template <> struct Prec<bsplit> {
         for (int j = 0; j < NT_; ++j)
           acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][term == 1 ? 1 : 0], a[m][term == 0 ? 1 : 0], acc[m][j], 0, 0, 0);
   }
-  static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused (pair form below)
-  // relu of 8 split values: a value is negative iff its hi part is (lo is a correction of hi)
+  // relu of one 16-byte unit in the quad layout: lanes 0,1 of a quad hold the hi units, lanes 2,3 the
+  // matching lo units; a value is negative iff its hi part is, so the lo lanes fetch the hi dwords of
+  // lane - 2 (DPP quad_perm [0,1,0,1]) and everybody masks with the signs found there.
+  static __device__ __forceinline__ uint4 relu16(uint4 v) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t h = (uint32_t)__builtin_amdgcn_mov_dpp((int)d[i], 0x44, 0xF, 0xF, true);
+      d[i] &= ((h & 0x8000u) ? 0u : 0xffffu) | ((h & 0x80000000u) ? 0u : 0xffff0000u);
+    }
+    return v;
+  }
+  // pair form (FISR_BSPLIT_PAIR_LOAD): relu of 8 split values held as (hi unit, lo unit) by one lane
   static __device__ __forceinline__ void relu_pair(uint4& hi, uint4& lo) {
     uint32_t* h = reinterpret_cast<uint32_t*>(&hi);
     uint32_t* l = reinterpret_cast<uint32_t*>(&lo);
