@@ -9,18 +9,19 @@
 //   depth_to_space(.,2)      (FISRnet.py:99, NHWC "DCR" order) folded into the store
 //   channel scatter into the 9-ch prediction (FISRnet.py:107-108 split/concat)
 //
-// GEMM view: M = output pixels, N = output channels, K = 9 taps x Cin.
-// Output tile per workgroup = 8 rows x 32 cols x BN channels (BN = 32*NT).  A wave owns MR
-// image rows (MR M-subtiles of 32 pixels) x NT N-subtiles of 32 channels = MR*NT accumulators
-// of the 32x32 MFMA (16 VGPR each); the workgroup has 8/MR waves (MR = 1: 512 threads, two
-// waves of the SAME workgroup per SIMD hide each other's LDS/barrier latency in the K loop;
-// MR = 2: 256 threads, fewer LDS fragment reads per MFMA).
+// GEMM view: rows = output channels (the weights are the MFMA row operand), columns = output pixels,
+// K = 9 taps x Cin.  Output tile per workgroup = 8 rows x 32 cols x BN channels (BN = 32*NT; NT = 0 is
+// the 16-row heads variant on 16x16 MFMAs).  A wave owns MR image rows (MR column tiles of 32 pixels) x NT
+// row tiles of 32 channels = MR*NT accumulators of the 32x32 MFMA (16 VGPR each); the workgroup has 8/MR
+// waves (MR = 1: 512 threads; MR = 2: 256 threads, fewer LDS fragment reads per MFMA).  The host packs the
+// weight rows of every 32-channel group so that accumulator register r of lane (pixel, kh) is channel
+// 16*kh + r: a lane owns one 16-channel record of the activation format.
 // The K loop walks the input channels in 64-byte chunks: the (8+2)x(32+2) halo tile of
 // the chunk and the 9 x BN x chunk weights are staged in LDS once, then all 9 taps read
 // shifted windows of the same halo tile (9x LDS reuse of every input byte).  One
 // ds_read_b128 per lane delivers a 16-byte k-slice.
 //
-// Three arithmetic modes share the structure (64-byte chunk records everywhere):
+// Four arithmetic modes share the structure (64-byte chunk records everywhere):
 //   float   : 16 fp32 channels / chunk, 4 x v_mfma_f32_32x32x2_f32 per 16-byte slice
 //             (exact fp32: bitwise an fmaf chain).
 //   _Float16: 32 fp16 channels / chunk, 1 x v_mfma_f32_32x32x16_f16 per slice, fp32 acc.
@@ -28,6 +29,7 @@
 //             relative); a chunk is 16 channels = 16 hi (32 B) + 16 lo (32 B).  A product is
 //             a_hi*b_hi + a_hi*b_lo + a_lo*b_hi = 3 x v_mfma_f32_32x32x16_bf16, fp32 acc:
 //             fp32-grade results (~2^-17 relative per product) at 16/3 x the fp32 MFMA rate.
+//   fsplit  : "f16f8", fp16 + fp8 remainder with block-scaled fp8 MFMAs for the cross terms (below).
 //
 // LDS records are 64 data bytes + 16 pad = 80 B (5 x 16-B slots, odd) so that the 16
 // lanes of every ds_read_b128 service group (which always cover all residues mod 16 of
@@ -36,8 +38,10 @@
 //
 // Software pipeline: the global loads of chunk k+1 are issued into registers before the
 // MFMAs of chunk k and written to LDS after them, so HBM/L2 latency hides under the MFMAs.
-// Epilogue: accumulators (+bias) go through LDS once so that every lane then handles 4-8
-// consecutive channels of one pixel: residual loads and stores are 16-byte vectors.
+// Accumulators start from bias + residual (the residual records are fetched next to the first chunk).
+// Epilogue: relu -> format conversion -> DPP quad transpose -> 16-byte stores straight from the
+// accumulator registers; four lanes fill one 64-byte record per store instruction.  No LDS staging,
+// no barrier after the K loop.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
