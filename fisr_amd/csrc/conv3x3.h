@@ -880,7 +880,13 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
           quad_transpose(q4, lane);
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (xq + k < p.W) reinterpret_cast<uint4*>((char*)p.out + record(xq + k) * sizeof(T))[li & 3] = q4[k];
+            if (xq + k < p.W) {
+              uint4* dst = reinterpret_cast<uint4*>((char*)p.out + record(xq + k) * sizeof(T)) + (li & 3);
+              // streaming store: the activation tensors (GBs) are never re-read from cache by this kernel
+              typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+              u32x4_t nv; nv.x = q4[k].x; nv.y = q4[k].y; nv.z = q4[k].z; nv.w = q4[k].w;
+              __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>(dst));
+            }
         } else {
           uint4* ob = reinterpret_cast<uint4*>((char*)p.out + record(x) * sizeof(T));
 #pragma unroll
