@@ -30,6 +30,7 @@ def scene(tmp_path_factory, gold_dir, syn_weights, syn_blob):
         fio.write_png(str(lr / f"LR_vid_1_fr_07171_seq_{2 * i + 1}.png"), g["frames"][i])
     fio.write_flow(g["flows"], str(root / "flow.flo"))
     fio.write_warp_file(str(root / "warp.npy"), g["warps"])
+    fio.write_warp_file(str(root / "warp.mat"), g["warps"])       # MATLAB v7.3 / HDF5, as the reference stores it
     weights.save_npz(str(ck / "FISRnet-122000.npz"), syn_weights)
     # expected predictions from the oracle (fp64), window by window, 1x1 patch
     fl = O.merge_seq_dim(g["flows"])
@@ -53,10 +54,10 @@ def scene(tmp_path_factory, gold_dir, syn_weights, syn_blob):
     return dict(root=root, preds=preds, gt=gt, g=g)
 
 
-def _args(scene, phase, extra=()):
+def _args(scene, phase, extra=(), warp="warp.npy"):
     r = scene["root"]
     return ["--phase", phase, "--test_data_path", str(r / "LR_LFR"), "--test_label_path", str(r / "HR_HFR"),
-            "--test_flow_data_path", str(r / "flow.flo"), "--test_warped_data_path", str(r / "warp.npy"),
+            "--test_flow_data_path", str(r / "flow.flo"), "--test_warped_data_path", str(r / warp),
             "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(r / "test_img_dir"),
             "--text_dir", str(r / "text_dir"), "--log_dir", str(r / "logdir"),
             "--test_patch", "(1,1)", "--test_input_size", "96,96", *extra]
@@ -65,7 +66,8 @@ def _args(scene, phase, extra=()):
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_phase_test_cfg1(scene, prec, capsys):
     from fisr_amd.fisrnet import FISRnet
-    args = fmain.parse_args(_args(scene, "test", ["--precision", prec]))
+    # the fp32 run reads the warped frames from the HDF5 .mat (the reference's container), the other from .npy
+    args = fmain.parse_args(_args(scene, "test", ["--precision", prec], warp="warp.mat" if prec == "fp32" else "warp.npy"))
     net = FISRnet(args)
     res = net.test()
     out = capsys.readouterr().out
