@@ -99,6 +99,32 @@ class Workload:
         return 3 * sum(t.in_h * t.in_w for t in self.tiles) * FLOP_PER_LR_PX
 
 
+def shader_clock_under_load(precision):
+    """MHz the chip actually runs at while the dominant conv kernel executes: s_memtime ticks per 100 MHz
+    s_memrealtime tick, one sample per workgroup of a 64->64 launch at the bench's batch (diagnostic entry
+    fisr_bench_conv with FISR_TRACE_FILE).  The fast modes are power-throttled far below the nominal 2.4 GHz
+    that the datasheet MFMA peak assumes."""
+    import ctypes
+    import tempfile
+    from fisr_amd import lib as flib
+    pid = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}[precision]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "trace.bin")
+        os.environ["FISR_TRACE_FILE"] = path
+        try:
+            us = ctypes.c_double()
+            rc = flib.lib().fisr_bench_conv(pid, 12, 544, 992, 64, 64, 3, 1, 3, ctypes.byref(us))
+        finally:
+            os.environ.pop("FISR_TRACE_FILE", None)
+        if rc != 0 or not os.path.isfile(path):
+            return None
+        a = np.fromfile(path, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+    a = a[(a[:, 2] > a[:, 0]) & (a[:, 6] > a[:, 5])]
+    if not len(a):
+        return None
+    return float(np.median((a[:, 2] - a[:, 0]) / (a[:, 6] - a[:, 5]) * 100.0))
+
+
 def roofline_pass(net, wl, precision, reps, layer_profile=None):
     torch = wl.torch
     net.profile(1)
@@ -223,6 +249,11 @@ def main():
     if not args.no_roofline:
         roofline = roofline_pass(net, wl, args.precision, max(1, min(args.steps, 2)),
                                  args.layer_profile if rank == 0 else None)
+        if roofline is not None and rank == 0:
+            mhz = shader_clock_under_load(args.precision)
+            if mhz:
+                roofline["shader_clock_mhz_under_load"] = round(mhz)
+                roofline["mfma_issue_frac_at_that_clock"] = round(roofline["mfma_issue_frac"] * 2400.0 / mhz, 4)
 
     fp32_exact = parity = None
     other = {}
