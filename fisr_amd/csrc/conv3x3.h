@@ -85,7 +85,7 @@ __device__ __forceinline__ void fsplit_encode8(const float* v, uint4& h_out, uin
   float r[8], hf[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    h[k] = (_Float16)v[k];
+    h[k] = (_Float16)fminf(fmaxf(v[k], -65504.f), 65504.f);   // saturate instead of overflowing to inf
     hf[k] = (float)h[k];
     r[k] = fp8_clamp((v[k] - hf[k]) * (float)(1 << FS_LSHIFT));
     hf[k] = fp8_clamp(hf[k]);

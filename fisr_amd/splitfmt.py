@@ -78,7 +78,7 @@ def to_fsplit(x: np.ndarray) -> np.ndarray:
     c = x.shape[-1]
     assert c % 16 == 0
     g = x.reshape(x.shape[:-1] + (c // 16, 16))
-    h = g.astype(np.float16)
+    h = np.clip(g, -65504, 65504).astype(np.float16)          # saturating, like the device encoder
     hf = h.astype(np.float32)
     l8 = fp8_e4m3_encode(np.clip((g - hf) * np.float32(2 ** FS_LSHIFT), -448, 448))
     h8 = fp8_e4m3_encode(np.clip(hf, -448, 448))

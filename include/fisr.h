@@ -53,7 +53,8 @@ enum {
                           16 x fp16 h (32 B), 16 x fp8-e4m3 l8 (16 B), 16 x fp8-e4m3 copy of h (16 B).
                           Product = a_h*w_h (v_mfma_f32_32x32x16_f16) + both cross terms in ONE
                           block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per pair of taps: ~2^-15
-                          relative per product at 2.1 instead of 3 MFMA-units (fp32 accumulate). */
+                          relative per product at 2.1 instead of 3 MFMA-units (fp32 accumulate).  Values beyond
+                          the fp16 range saturate to +-65504 when stored (no inf). */
 };
 
 /* flags of fisr_op_conv3x3 */

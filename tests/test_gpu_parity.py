@@ -275,6 +275,20 @@ def test_conv3x3_random_sweep(dev, prec, tol):
         _report(got, exp, tol, f"{prec} sweep case {case}: n{n} {h}x{w} {c0}+{c1}->{cout} flags {flags} res {use_res} f32out {out_f32}")
 
 
+def test_f16f8_saturates_instead_of_overflowing(dev):
+    """Values beyond the fp16 range are stored as +-65504 by the f16f8 encoder (inf would poison every later
+    layer); in-range values are unaffected."""
+    x = np.zeros((1, 8, 32, 16), np.float32)
+    x[0, 3, 4, :4] = [1e5, -1e6, 70000.0, 3.0]
+    w = np.zeros((3, 3, 16, 16), np.float32)
+    for c in range(16):
+        w[1, 1, c, c] = 1.0                                   # identity conv
+    got = hip_conv(x, w, np.zeros(16, np.float32), prec="f16f8")
+    assert np.isfinite(got).all()
+    assert abs(got[0, 3, 4, 0] - 65504) < 64 and abs(got[0, 3, 4, 1] + 65504) < 64 and abs(got[0, 3, 4, 2] - 65504) < 64
+    assert abs(got[0, 3, 4, 3] - 3.0) < 1e-3
+
+
 def test_conv3x3_transpose_detecting(dev):
     """A = delta input, asymmetric weights: catches swapped rows/cols, taps or channel order."""
     x = np.zeros((1, 8, 32, 16), np.float32)
