@@ -48,7 +48,8 @@
 
 // FISR_ABL: performance-diagnosis ablations (WRONG results): bit 1 no global loads/LDS fills after
 // the first chunk, 2 no LDS fragment reads in the tap loop, 4 no epilogue, 8 no MFMAs, 16 epilogue without
-// its stores, 32 epilogue without its format conversion, 64 no quad transpose of the stores.
+// its stores, 32 epilogue without its format conversion, 64 no quad transpose of the stores, 128 weight slab
+// fetched and staged on even chunks only.
 #ifndef FISR_ABL
 #define FISR_ABL 0
 #endif
@@ -549,6 +550,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
           }
         }
       }
+      if (!((FISR_ABL & 128) && (kc & 1)))   // ablation 128: weight slab fetched / staged on even chunks only
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
         const int r = wrec_lo + i * (NTHR / 4);
@@ -589,6 +591,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         }
       }
       const char* wsrc = (const char*)p.wpk + (size_t)(kc + 1) * 9 * p.CoutPad * CHUNK_BYTES;
+      if (!((FISR_ABL & 128) && ((kc + 1) & 1)))
 #pragma unroll
       for (int i = 0; i < NWT; ++i) {
         const int r = wrec_lo + i * (NTHR / 4);  // r = tap*BN + n
