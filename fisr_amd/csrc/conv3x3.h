@@ -49,7 +49,7 @@
 // FISR_ABL: performance-diagnosis ablations (WRONG results): bit 1 no global loads/LDS fills after
 // the first chunk, 2 no LDS fragment reads in the tap loop, 4 no epilogue, 8 no MFMAs, 16 epilogue without
 // its stores, 32 epilogue without its format conversion, 64 no quad transpose of the stores, 128 weight slab
-// fetched and staged on even chunks only.
+// fetched and staged on even chunks only, 256 half of the epilogue's stores.
 #ifndef FISR_ABL
 #define FISR_ABL 0
 #endif
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
           uint4 (&q4)[4] = reinterpret_cast<uint4 (&)[4]>(q);
           quad_transpose(q4, lane);
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
+          for (int k = 0; k < ((FISR_ABL & 256) ? 2 : 4); ++k)   // ablation 256: half of the store instructions
             if (xq + k < p.W) {
               uint4* dst = reinterpret_cast<uint4*>((char*)p.out + record(xq + k) * sizeof(T)) + (li & 3);
               // streaming store: the activation tensors (GBs) are never re-read from cache by this kernel
