@@ -374,7 +374,28 @@ template <> struct Prec<fsplit> {
       g[d] &= keep8;
     }
   }
-  static __device__ __forceinline__ uint4 relu16(uint4 v) { return v; }  // unused
+  // relu of one 16-byte unit in the quad layout used by the heads loader (lane 0: h[0..7], lane 1: h[8..15],
+  // lane 2: l8[0..15], lane 3: h8[0..15] of a quad): the sign of h decides; the fp8 lanes fetch the eight h
+  // dwords of lanes 0 and 1 by DPP.
+  static __device__ __forceinline__ uint4 relu16(uint4 v) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(&v);
+    const bool fp8_lane = (__lane_id() & 2) != 0;
+    uint32_t h0[4], h1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h0[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)d[i], 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
+      h1[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)d[i], 0x55, 0xF, 0xF, true);   // quad_perm [1,1,1,1]
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t keep16 = ((d[i] & 0x8000u) ? 0u : 0xffffu) | ((d[i] & 0x80000000u) ? 0u : 0xffff0000u);
+      const uint32_t w0 = i < 2 ? h0[2 * i] : h1[2 * i - 4], w1 = i < 2 ? h0[2 * i + 1] : h1[2 * i - 3];
+      const uint32_t keep8 = ((w0 & 0x8000u) ? 0u : 0xffu) | ((w0 & 0x80000000u) ? 0u : 0xff00u) |
+                             ((w1 & 0x8000u) ? 0u : 0xff0000u) | ((w1 & 0x80000000u) ? 0u : 0xff000000u);
+      d[i] &= fp8_lane ? keep8 : keep16;
+    }
+    return v;
+  }
 };
 
 template <typename T> struct IsFsplit { static constexpr bool value = false; };
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   constexpr int CC = P::CC;
   constexpr int BN = NT == 0 ? 16 : 32 * NT;   // NT = 0: the 16-row heads variant (16x16 MFMAs, Cout <= 16)
   constexpr int NTA = NT == 0 ? 1 : NT;
-  static_assert(NT != 0 || (OUT_F32 && !IsFsplit<T>::value), "the 16-row variant only has the fp32-scatter epilogue");
+  static_assert(NT != 0 || OUT_F32, "the 16-row variant only has the fp32-scatter epilogue");
   constexpr int EPU = 16 / sizeof(T);  // T elements per 16-byte unit (bsplit counts as 4-byte slots)
   constexpr int NTHR = 64 * (TILE_H / MR);
 
@@ -501,7 +522,9 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   // u = tid + i*NTHR -> pixel u>>2, slot u&3.  bsplit: a thread loads the hi slot s (0/1) and
   // the matching lo slot s+2 of one pixel (relu needs both): pixel (tid>>1) + i*NTHR/2.
   // f16f8: a thread loads the whole 64-byte record of one pixel (relu needs h for l8 and h8).
-  constexpr bool QUAD = IsFsplit<T>::value;
+  // f16f8: the 64-channel kernels load a whole 64-byte record per lane (cheapest relu); the memory-bound heads
+  // (NT = 0) let four lanes fetch the four units of a record (64 contiguous bytes, relu through DPP)
+  constexpr bool QUAD = IsFsplit<T>::value && NT != 0;
   constexpr int NPIX_IT = QUAD ? (HALO_PIX + NTHR - 1) / NTHR
                                : (P::PAIR_LOAD ? (HALO_PIX * 2 + NTHR - 1) / NTHR : (HALO_PIX * 4 + NTHR - 1) / NTHR);
   constexpr int NIN = QUAD ? 4 * NPIX_IT : (P::PAIR_LOAD ? 2 * NPIX_IT : NPIX_IT);  // 16-byte registers, halo tile
@@ -656,7 +679,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
               const f16x8 b = *reinterpret_cast<const f16x8*>(pa + ((m + dy) * HALO_W + ct * 16 + dx) * REC_BYTES + kg * 16);
               acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc4[m][ct], 0, 0, 0);
             }
-        } else {
+        } else if constexpr (std::is_same<T, bsplit>::value) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(wa + tap * 16 * REC_BYTES + (kg & 1) * 16);   // {whi, whi}
 #pragma unroll
           for (int m = 0; m < MR; ++m)
@@ -683,6 +706,55 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
             for (int ct = 0; ct < 2; ++ct) {
               const bf16x8 b = *reinterpret_cast<const bf16x8*>(pa + (m * HALO_W + ct * 16) * REC_BYTES + offp + (kg & 1) * 16);   // a_hi
               acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4[m][ct], 0, 0, 0);
+            }
+        }
+      }
+      if constexpr (IsFsplit<T>::value) {
+        // f16f8 on 16 rows: main term a_h*w_h with v_mfma_f32_16x16x32_f16 over tap PAIRS (K = 32 = 2 taps x 16
+        // channels: lane group kg>>1 picks the tap, kg&1 the 16-byte half of h), both cross terms of FOUR taps in
+        // one v_mfma_scale_f32_16x16x128_f8f6f4 (layout probed, scripts/probes/mx16_layout_probe.hip).
+#pragma unroll
+        for (int tp = 0; tp < 5; ++tp) {
+          const int t0 = 2 * tp, t1 = (2 * tp + 1 < 9) ? 2 * tp + 1 : 8;
+          const bool live = (2 * tp + 1 < 9) || (kg >> 1) == 0;
+          const int offp0 = ((t0 / 3) * HALO_W + (t0 % 3)) * REC_BYTES, offp1 = ((t1 / 3) * HALO_W + (t1 % 3)) * REC_BYTES;
+          const int offp = (kg >> 1) ? offp1 : offp0;
+          const int offw = ((kg >> 1) ? t1 : t0) * 16 * REC_BYTES;
+          f16x8 a = *reinterpret_cast<const f16x8*>(wa + offw + (kg & 1) * 16);
+          if (!live) a = __builtin_bit_cast(f16x8, make_uint4(0u, 0u, 0u, 0u));
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const f16x8 b = *reinterpret_cast<const f16x8*>(pa + (m * HALO_W + ct * 16) * REC_BYTES + offp + (kg & 1) * 16);
+              acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc4[m][ct], 0, 0, 0);
+            }
+        }
+        // Lane group kg carries tap 4g + kg: its 32 operand bytes are bytes 32..63 of that tap's record
+        // (pixel: l8 | h8, weight: wh8 | wl8), i.e. bytes 0-15 = term a_l*w_h, bytes 16-31 = term a_h*w_l.
+        // Probed block structure: the 32-element scale blocks are {bytes 0-15 of groups 0,1}, {bytes 16-31 of
+        // groups 0,1}, {bytes 0-15 of groups 2,3}, {bytes 16-31 of groups 2,3} and take their scales from lane
+        // groups 0, 2, 1, 3 -- so lane groups 0,1 hold the term-0 scales and 2,3 the term-1 scales.
+        const int s_w8 = (kg >> 1) == 0 ? 127 - p.wexp : 127 - p.wexp - 11;   // weights (row operand)
+        const int s_a8 = (kg >> 1) == 0 ? 127 - FS_LSHIFT : 127;              // pixels (column operand)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const int t = 4 * g + kg, tc = t < 9 ? t : 8;
+          const int offp = ((tc / 3) * HALO_W + (tc % 3)) * REC_BYTES;
+          const uint4* wq = reinterpret_cast<const uint4*>(wa + tc * 16 * REC_BYTES + 32);
+          uint4 w0 = wq[0], w1 = wq[1];
+          if (t >= 9) { w0 = make_uint4(0u, 0u, 0u, 0u); w1 = w0; }
+          i32x8 fw;
+          fw[0] = w0.x; fw[1] = w0.y; fw[2] = w0.z; fw[3] = w0.w; fw[4] = w1.x; fw[5] = w1.y; fw[6] = w1.z; fw[7] = w1.w;
+#pragma unroll
+          for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const uint4* pq = reinterpret_cast<const uint4*>(pa + (m * HALO_W + ct * 16) * REC_BYTES + offp + 32);
+              const uint4 p0 = pq[0], p1 = pq[1];
+              i32x8 fp;
+              fp[0] = p0.x; fp[1] = p0.y; fp[2] = p0.z; fp[3] = p0.w; fp[4] = p1.x; fp[5] = p1.y; fp[6] = p1.z; fp[7] = p1.w;
+              acc4[m][ct] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw, fp, acc4[m][ct], 0, 0, 0, s_w8, 0, s_a8);
             }
         }
       }

@@ -226,10 +226,10 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
 }
 
 // N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16,
-// always fp32 output; FISR_CONV_HEAD16=0 turns it off for A/B runs; f16f8 has no 16-row path).
+// always fp32 output; FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
   static const bool head16 = [] { const char* e = getenv("FISR_CONV_HEAD16"); return !(e && e[0] == '0'); }();
-  if (co < 16 && head16 && !std::is_same<T, fsplit>::value) return 0;
+  if (co < 16 && head16) return 0;
   return co <= 32 ? 1 : 2;
 }
 
@@ -291,8 +291,7 @@ template <typename T>
 hipError_t launch_conv(const ConvArgs& a, int nt, bool out_f32, hipStream_t st) {
   const bool m1 = conv_mr<T>() == 1;
   if (nt == 0) {
-    if constexpr (std::is_same<T, fsplit>::value) return hipErrorInvalidValue;
-    else return m1 ? launch_conv_variant<T, 0, true, 1>(a, st) : launch_conv_variant<T, 0, true, 2>(a, st);
+    return m1 ? launch_conv_variant<T, 0, true, 1>(a, st) : launch_conv_variant<T, 0, true, 2>(a, st);
   }
   if (nt == 1) {
     if (out_f32) return m1 ? launch_conv_variant<T, 1, true, 1>(a, st) : launch_conv_variant<T, 1, true, 2>(a, st);
