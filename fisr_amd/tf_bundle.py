@@ -4,8 +4,11 @@ reference's `checkpoint_dir/FISRnet_exp1/FISRnet-<step>.{index,data-00000-of-000
 
 Format (restated from TensorFlow 1.13 upstream, tensorflow/core/util/tensor_bundle/ and
 tensorflow/core/lib/io/{table,format,block}.cc -- not in the reference tree, and no checkpoint
-ships with it, so this reader is PARITY UNPINNED against a real file; it is round-tripped
-against the writer below, which follows the same specification):
+ships with it, so the TABLE layout is PARITY UNPINNED against a real file (it is round-tripped
+against the writer below, which follows the same specification).  The layers underneath are
+pinned: crc32c by its check value, the snappy decompressor against blocks compressed by the real
+libsnappy 1.1.8 (tests/golden/snappy_blocks.npz, oracle/make_golden_snappy.py), the protobuf wire
+coding of BundleEntryProto / TensorShapeProto against google.protobuf in both directions):
 
   <prefix>.index   an SSTable in LevelDB table format: data blocks of prefix-compressed
                    (shared, non_shared, value_len varint32; key delta; value) entries with a
@@ -134,6 +137,13 @@ def _parse_entry(buf):
 
 # ------------------------------------------------------------------ snappy (decompress only)
 def _snappy_decompress(src: bytes) -> bytes:
+    try:
+        return _snappy_decompress_unchecked(src)
+    except IndexError as e:
+        raise ValueError("snappy: truncated or corrupt stream") from e
+
+
+def _snappy_decompress_unchecked(src: bytes) -> bytes:
     n, pos = _get_varint(src, 0)
     out = bytearray()
     while pos < len(src):

@@ -213,3 +213,56 @@ def test_split_format_roundtrip():
     assert np.abs(r - x).max() <= np.abs(x).max() * 2.0 ** -17
     assert np.array_equal(splitfmt.split_round(r), r)         # idempotent
     assert np.array_equal(splitfmt.to_split(np.zeros((1, 16), np.float32)), np.zeros((1, 1, 2, 16), np.uint16))
+
+
+def test_snappy_decompressor_vs_real_snappy(gold_dir):
+    """tests/golden/snappy_blocks.npz was compressed by libsnappy 1.1.8 (oracle/make_golden_snappy.py)."""
+    g = np.load(os.path.join(gold_dir, "snappy_blocks.npz"))
+    names = sorted(set(n.rsplit("_", 1)[0] for n in g.files))
+    assert len(names) >= 10
+    for k in names:
+        assert tf_bundle._snappy_decompress(g[k + "_snappy"].tobytes()) == g[k + "_raw"].tobytes(), k
+    with pytest.raises(ValueError):
+        tf_bundle._snappy_decompress(g["text_snappy"].tobytes()[:-5])          # truncated stream
+
+
+def test_bundle_protos_vs_real_protobuf():
+    """The hand-rolled BundleEntryProto / TensorShapeProto wire coding against google.protobuf (messages declared
+    here from TensorFlow's tensor_bundle.proto / tensor_shape.proto field numbers)."""
+    pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="fisr_bundle_test.proto", package="t", syntax="proto3")
+    F = descriptor_pb2.FieldDescriptorProto
+    shape = fd.message_type.add(name="TensorShapeProto")
+    dim = shape.nested_type.add(name="Dim")
+    dim.field.add(name="size", number=1, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    dim.field.add(name="name", number=2, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    shape.field.add(name="dim", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".t.TensorShapeProto.Dim")
+    shape.field.add(name="unknown_rank", number=3, type=F.TYPE_BOOL, label=F.LABEL_OPTIONAL)
+    ent = fd.message_type.add(name="BundleEntryProto")
+    ent.field.add(name="dtype", number=1, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="shape", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_OPTIONAL, type_name=".t.TensorShapeProto")
+    ent.field.add(name="shard_id", number=3, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="offset", number=4, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="size", number=5, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="crc32c", number=6, type=F.TYPE_FIXED32, label=F.LABEL_OPTIONAL)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    try:
+        Entry = message_factory.GetMessageClass(pool.FindMessageTypeByName("t.BundleEntryProto"))
+    except AttributeError:                      # older protobuf
+        Entry = message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("t.BundleEntryProto"))
+    for shape_, off, size, crc in (((3, 3, 64, 128), 0, 294912, 0xDEADBEEF), ((512,), 193264640, 2048, 1), ((), 5, 4, 0xFFFFFFFF),
+                                   ((3, 3, 1024, 512), (1 << 33) + 7, 18874368, 123456789)):
+        m = Entry(dtype=1, shard_id=0, offset=off, size=size, crc32c=crc)
+        for d in shape_:
+            m.shape.dim.add(size=d)
+        if not shape_:
+            m.shape.SetInParent()
+        wire = m.SerializeToString()
+        e = tf_bundle._parse_entry(wire)                       # real encoder -> my decoder
+        assert (e["dtype"], e["shape"], e["offset"], e["size"], e["crc32c"]) == (1, tuple(shape_), off, size, crc)
+        back = Entry()
+        back.ParseFromString(tf_bundle._entry_proto(1, shape_, off, size, crc))   # my encoder -> real decoder
+        assert back.dtype == 1 and tuple(d.size for d in back.shape.dim) == tuple(shape_)
+        assert (back.offset, back.size, back.crc32c) == (off, size, crc)
