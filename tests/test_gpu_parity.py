@@ -253,7 +253,7 @@ def test_conv3x3_random_sweep(dev, prec, tol):
     relu in/out, residual, depth_to_space, 16-channel-record and fp32-scatter epilogues."""
     rng = np.random.default_rng({"fp32": 11, "bf16x3": 12, "f16f8": 13, "fp16": 14}[prec])
     cc = 32 if prec == "fp16" else 16
-    for case in range(14):
+    for case in range(int(os.environ.get("FISR_SWEEP_CASES", "14"))):       # raise for a one-off campaign
         n = int(rng.integers(1, 3))
         h, w = int(rng.integers(1, 27)), int(rng.integers(1, 70))
         c0 = cc * int(rng.integers(1, 5))
@@ -272,7 +272,12 @@ def test_conv3x3_random_sweep(dev, prec, tol):
         res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
         got = hip_conv(x0, wt, b, x1, res, flags, prec=prec, out_f32=out_f32)
         exp = ref_conv(x0, wt, b, x1, res, flags)
-        _report(got, exp, tol, f"{prec} sweep case {case}: n{n} {h}x{w} {c0}+{c1}->{cout} flags {flags} res {use_res} f32out {out_f32}")
+        # mixed tolerance: the modes' errors are relative to the operand scale (outputs reach |8| with a residual)
+        err = np.abs(got.astype(np.float64) - exp)
+        bad = int((err > tol * (1 + np.abs(exp) / 4)).sum())
+        assert bad == 0 and not np.isnan(got).any(), (
+            f"{prec} sweep case {case}: n{n} {h}x{w} {c0}+{c1}->{cout} flags {flags} res {use_res} f32out {out_f32}: "
+            f"max err {err.max():.3e}, bad {bad}/{err.size}")
 
 
 def test_f16f8_saturates_instead_of_overflowing(dev):
