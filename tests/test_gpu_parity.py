@@ -490,6 +490,25 @@ def test_forward_fp16_error_is_bounded(net16, gold_dir):
             assert abs(O.ssim_pil(q_h[..., 3 * f:3 * f + 3], q_r[..., 3 * f:3 * f + 3]) - 1.0) <= 1e-3
 
 
+def test_forward_random_shapes_vs_oracle(net32, netx3, netf8, syn_blob):
+    """Whole forward on random (n, h, w) -- tall, wide, minimal 32x32 (1x1 bottleneck at level 1) -- against the
+    C oracle in fp64; FISR_FWD_CASES raises the count for a one-off campaign."""
+    rng = np.random.default_rng(77)
+    shapes = [(1, 32, 32), (2, 32, 160), (1, 128, 32)]
+    for _ in range(int(os.environ.get("FISR_FWD_CASES", "2"))):
+        shapes.append((int(rng.integers(1, 4)), 32 * int(rng.integers(1, 6)), 32 * int(rng.integers(1, 6))))
+    for (n, h, w) in shapes:
+        x = rng.random((n, h, w, 29)).astype(np.float32)
+        x[..., 9:17] = (x[..., 9:17] - 0.5) * 0.4
+        ref = C.forward(x, syn_blob, True)
+        xt = torch.from_numpy(x).cuda()
+        for net, tol in ((net32, F32_FWD_TOL), (netx3, 5e-4), (netf8, 2e-3)):
+            outs = net.model(xt)
+            torch.cuda.synchronize()
+            for name, got, exp in zip(("pred_l1", "pred_l2", "pred_l3"), outs, ref):
+                _report(got.cpu().numpy(), exp, tol, f"{net.precision} {name} n{n} {h}x{w}")
+
+
 def test_forward_errors(net32, dev):
     with pytest.raises(ValueError):
         net32.model(torch.zeros((1, 48, 64, 29), device="cuda"))
