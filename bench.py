@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the FISRnet hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--precision bf16x3|fp32|fp16]
+    python bench.py --gpus N --steps K --warmup W [--precision fp32|bf16x3|f16f8|fp16]
+                    [--parallelism frame|tile] [--others bf16x3,f16f8]
 
 A "step" is one pass of the hot path over one 5-frame 1080x1920 LR stack resident in HBM
 (cfg2 of BASELINE.json): 3 sliding windows x [input assembly -> 2x2 tiles of 544x992x29 (32-px
@@ -9,19 +10,26 @@ halo) through the 138-conv FISRnet forward -> trim/stitch -> clip/quantise/YUV->
 inner loops of `FISRnet.test` / `FISR_for_video` (reference FISRnet.py:798-910), producing 9 raw
 = 7 unique 2048x3840 frames.  Flows and warped frames are pre-made inputs as in cfg2.
 
-Default arithmetic is `bf16x3` (every value a hi+lo bf16 pair, 3 bf16 MFMAs per product, fp32
-accumulate: fp32-grade results, far inside the reference tolerance of +-0.02 dB); the exact-fp32
-MFMA path is timed next to it (`fp32_exact`) and the two outputs are compared at full size
-(`parity_vs_fp32`); `other_precisions` adds the fp16+fp8 split mode (`f16f8`, ~2^-15 per product,
-the fastest mode inside the reference tolerance).  `--precision fp32|f16f8` changes the headline.
+The headline (`value`, `dtype`) is the fp32 engine -- cfg2 says fp32, the reference computes in fp32.
+The split-precision engines (bf16x3, f16f8: fp32-grade results on the 16-bit / fp8 matrix pipes, far
+inside the reference tolerance of +-0.02 dB) are timed in the same run under `other_precisions`, each
+with its own roofline, its full-size comparison against the fp32 engine of this run and a check of one
+544x992 tile against the committed fp64-oracle grid (tests/golden/model_544x992_sparse.npz).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank processes its own stack
-(frame-parallel, weights replicated, no data-path collective) -> weak scaling; timing is
-barrier + synchronize on both sides, max over ranks.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+  --parallelism frame (default): every rank processes its own stack (weights replicated, no data-path
+      collective in the compute) and the uint8 output frames are gathered to rank 0 over xGMI, as cfg4 of
+      BASELINE.json asks -> weak scaling.
+  --parallelism tile: the ranks form groups of 4 (one 2x2 tile plan per group, reference seams and
+      numerics); a group works on one stack: every rank packs only its core of the input, the 32-px halos
+      are all-gathered, each rank runs the forward of ITS tile for the 3 windows, the trimmed uint8 tiles
+      are all-gathered (fisr_amd/dist.py).  N = 8 is 2 stacks x 4 tiles.
+Timing is barrier + synchronize on both sides, max over ranks.
 
-One JSON line is printed by rank 0.  `roofline` is measured in a second, instrumented pass
-(HIP events on the launch stream around every kernel, inside libfisr_hip.so); `cpu_baseline`
-times the C oracle (oracle/fisr_oracle.c, OpenMP, fp32) on a bounded sample on rank 0 at N=1.
+One JSON line is printed by rank 0.  `roofline` is measured in a second, instrumented pass (HIP events on
+the launch stream around every kernel, inside libfisr_hip.so; HIP events on the same stream around the glue
+calls); `cpu_baseline` times the C oracle (oracle/fisr_oracle.c, OpenMP, fp32) and `cpu_baseline_onednn`
+the torch-CPU/oneDNN twin (oracle/torch_cpu.py) on ONE full 544x992 tile on rank 0 at N=1.
 """
 import argparse
 import json
@@ -35,9 +43,13 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 2 644 164 MAC)
-PEAK = {"fp32": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
-MFMA_PER_PRODUCT = {"fp32": 1, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
-DTYPE = {"fp32": "f32", "fp16": "f16 (f32 accumulate)",
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md (spec; ~6300 achievable with a float4 copy)
+# dense MFMA peak of the instruction class each engine issues (MI355X_MICROARCH.md), TFLOP/s
+PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}
+# matrix-pipe work per algorithmic product (direct 3x3): Winograd F(2x2,3x3) issues 16/36 of the multiplies
+MFMA_PER_PRODUCT = {"fp32": None, "fp32d": 1, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
+DTYPE = {"fp32": "f32", "fp32d": "f32",
+         "fp16": "f16 (f32 accumulate)",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
          "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)"}
 UNIQUE_PER_STACK = 7                # 3 windows x 3 frames, overlaps counted once (FISRnet.py:913-920)
@@ -55,19 +67,25 @@ def synthetic_stack(seed, H=1080, W=1920):
 
 
 class Workload:
-    """cfg2 on one GPU: device-resident inputs + the step function of one FISRnet engine."""
+    """cfg2 on one GPU (or one tile group): device-resident inputs + the step function of one engine."""
 
-    def __init__(self, torch, dev, rank, patch, batch):
+    def __init__(self, torch, dev, stack_id, patch, batch, parallelism="frame", topo=None, group=None,
+                 gather_group_world=1):
         from fisr_amd import tiling
         self.torch, self.dev, self.patch, self.batch = torch, dev, patch, batch
+        self.parallelism, self.topo, self.group = parallelism, topo, group
+        self.gather_world = gather_group_world
         H0, W0 = 1080, 1920
         self.h, self.w = tiling.crop_hw(H0, W0, patch)
-        frames_np, flows_np = synthetic_stack(100 + rank, H0, W0)
+        frames_np, flows_np = synthetic_stack(100 + stack_id, H0, W0)
         self.frames = [torch.from_numpy(f).to(dev) for f in frames_np]
         self.flows = [torch.from_numpy(f).to(dev) for f in flows_np]
         self.warps = None
         self.tiles = tiling.plan_tiles(self.h, self.w, patch)
         self.full = torch.zeros((3, self.h * 2, self.w * 2, 9), dtype=torch.float32, device=dev)
+        self.yuv = torch.zeros((3, self.h * 2, self.w * 2, 9), dtype=torch.uint8, device=dev)
+        self.gathered = None
+        self.glue_events = None       # instrumented pass: {kernel: [(ev0, ev1, launches)]}
 
     def premake_warps(self, net):
         # pre-made warps (cfg2): produced once with the warp kernel, outside the timed region
@@ -76,23 +94,50 @@ class Workload:
             self.warps.append(net.warp(self.frames[p + 1], self.flows[2 * p]))
             self.warps.append(net.warp(self.frames[p], self.flows[2 * p + 1]))
 
+    # -- glue calls, optionally bracketed by HIP events on the stream they launch on (torch's current stream)
+    def _timed(self, name, launches, fn):
+        if self.glue_events is None:
+            return fn()
+        torch = self.torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.glue_events.setdefault(name, []).append((e0, e1, launches))
+        return out
+
     def step(self, net):
+        return self._step_tile(net) if self.parallelism == "tile" else self._step_frame(net)
+
+    def _step_frame(self, net):
         torch, h, w = self.torch, self.h, self.w
         fr, fl, wp = self.frames, self.flows, self.warps
-        outs = None
+        pack = lambda s: self._timed("pack_input", 1, lambda: net.pack_input(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w))
         if self.batch == "stack":
             # the 3 sliding windows (FISRnet.py:799) x 4 tiles (:847) are independent -> one batched forward
-            inp = torch.cat([net.pack_input(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w)
-                             for s in range(3)], dim=0)
+            inp = torch.cat([pack(s) for s in range(3)], dim=0)
             net.forward_tiled(inp, self.patch, full=self.full)
-            for s in range(3):
-                outs = net.unpack_output(self.full[s])                 # FISRnet.py:883, 903-909
         else:
             for s in range(3):
-                inp = net.pack_input(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w)
-                net.forward_tiled(inp, self.patch, full=self.full[s:s + 1], batch_tiles=(self.batch == "window"))
-                outs = net.unpack_output(self.full[s])
-        return outs
+                net.forward_tiled(pack(s), self.patch, full=self.full[s:s + 1], batch_tiles=(self.batch == "window"))
+        rgb = None
+        for s in range(3):
+            yuv, rgb = self._timed("unpack_output", 1, lambda: net.unpack_output(self.full[s]))   # FISRnet.py:883, 903-909
+            self.yuv[s] = yuv
+        if self.gather_world > 1:
+            # cfg4: the uint8 output frames of every rank travel to rank 0 (RCCL gather over xGMI)
+            from fisr_amd import dist as fdist
+            self.gathered = fdist.gather_to(self.yuv, dst=0)
+        return self.yuv, rgb
+
+    def _step_tile(self, net):
+        from fisr_amd import dist as fdist
+        torch, h, w = self.torch, self.h, self.w
+        fr, fl, wp = self.frames, self.flows, self.warps
+        cores = torch.cat([fdist.pack_core(net, fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w,
+                                           self.patch, self.topo.tile) for s in range(3)], dim=0)
+        yuv, rgb = fdist.tile_parallel_engine_window(net, cores, self.patch, group=self.group, want_rgb=True)
+        return yuv, rgb
 
     @property
     def flop_per_stack(self):
@@ -102,12 +147,13 @@ class Workload:
 def shader_clock_under_load(precision):
     """MHz the chip actually runs at while the dominant conv kernel executes: s_memtime ticks per 100 MHz
     s_memrealtime tick, one sample per workgroup of a 64->64 launch at the bench's batch (diagnostic entry
-    fisr_bench_conv with FISR_TRACE_FILE).  The fast modes are power-throttled far below the nominal 2.4 GHz
-    that the datasheet MFMA peak assumes."""
+    fisr_bench_conv with FISR_TRACE_FILE).  Only meaningful for that one layer shape: reported next to the
+    layer it was sampled in, never multiplied into a step-wide figure."""
     import ctypes
     import tempfile
     from fisr_amd import lib as flib
-    pid = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}[precision]
+    from fisr_amd.fisrnet import _PREC
+    pid = _PREC[precision]
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "trace.bin")
         os.environ["FISR_TRACE_FILE"] = path
@@ -122,17 +168,51 @@ def shader_clock_under_load(precision):
     a = a[(a[:, 2] > a[:, 0]) & (a[:, 6] > a[:, 5])]
     if not len(a):
         return None
-    return float(np.median((a[:, 2] - a[:, 0]) / (a[:, 6] - a[:, 5]) * 100.0))
+    mhz = float(np.median((a[:, 2] - a[:, 0]) / (a[:, 6] - a[:, 5]) * 100.0))
+    flops = 2.0 * 9 * 64 * 64 * 12 * 544 * 992
+    return {"layer": "64->64 @12x544x992, relu in/out + residual", "shader_clock_mhz": round(mhz),
+            "us_per_launch": round(us.value, 1), "tflops": round(flops / us.value / 1e6, 1)}
+
+
+def _pmc_table():
+    """HBM bytes per launch of every kernel, from the rocprofv3 PMC passes of this same command
+    (scripts/gpu_profile.sh -> profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    separate passes as MI355X_MICROARCH.md prescribes)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _pmc_conv_traffic(pmc, name):
+    try:
+        tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
+        if name.startswith("conv3x3_wino"):
+            key = "conv3x3_wino_kernel<" + tname
+        else:
+            nt = name.split("NT")[1][0]
+            key = f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in name else 'false'}"
+        hits = [v for k, v in pmc.items() if k.startswith(key)]
+        if hits:
+            return round(max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch"] / 1e9, 4)
+    except (KeyError, IndexError, ValueError):
+        pass
+    return None
 
 
 def roofline_pass(net, wl, precision, reps, layer_profile=None):
+    """Second, instrumented pass: HIP events around every kernel of the forward (inside the library, on the
+    launch stream) and around the glue calls (torch events on the same stream)."""
     torch = wl.torch
     net.profile(1)
+    wl.glue_events = {}
     for _ in range(reps):
         wl.step(net)
     torch.cuda.synchronize(wl.dev)
     prof = net.profile_read()
     net.profile(0)
+    glue_ev, wl.glue_events = wl.glue_events, None
     if layer_profile:
         net.profile(2)
         wl.step(net)
@@ -148,33 +228,173 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     convs = [p for p in prof if p["name"].startswith("conv3x3") and p["launches"]]
     if not convs:
         return None
+    pmc = _pmc_table()
     dom = max(convs, key=lambda p: p["ms"])
-    tot_ms = sum(p["ms"] for p in prof)
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (scripts/gpu_profile.sh ->
-    # profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)
-    traffic = None
+    peak = PEAK[precision]
+    # ---- HBM-bound kernels: GB/s against the 8 TB/s peak, from algorithmic bytes (and the PMC bytes where
+    # profiles/pmc_traffic.json has the kernel) over the HIP-event time of this run
+    hbm = {}
+
+    def add_hbm(name, ms, launches, alg_bytes, pmc_key):
+        if not launches or ms <= 0:
+            return
+        rec = {"avg_launch_us": round(ms * 1e3 / launches, 2), "launches": int(launches),
+               "algorithmic_gb_per_launch": round(alg_bytes / launches / 1e9, 4),
+               "algorithmic_gbps": round(alg_bytes / (ms * 1e-3) / 1e9, 1)}
+        rec["frac_of_hbm_peak"] = round(rec["algorithmic_gbps"] / HBM_PEAK_GBPS, 4)
+        hit = [v for k, v in pmc.items() if k.startswith(pmc_key)]
+        if hit:
+            b = max(hit, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch"]
+            rec["pmc_gb_per_launch"] = round(b / 1e9, 4)
+        hbm[name] = rec
+
+    for p in prof:
+        if p["launches"] and (not p["name"].startswith("conv3x3") or "NT0" in p["name"]):
+            add_hbm(p["name"], p["ms"], p["launches"], p["bytes"], p["name"].split("<")[0] + "_kernel")
+    px_lr, px_hr = wl.h * wl.w, 4 * wl.h * wl.w
+    glue_bytes = {"pack_input": px_lr * (9 + 32 + 48 + 116.0),            # 3 u8 frames + 4 flows + 4 warps in, 29 f32 out
+                  "unpack_output": px_hr * (36 + 9 + 9.0),                # 9 f32 in, 9 u8 yuv + 9 u8 rgb out
+                  "stitch": None}
+    for name, evs in glue_ev.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        launches = sum(k for _, _, k in evs)
+        if glue_bytes.get(name):
+            add_hbm(name, ms, launches, glue_bytes[name] * launches, name + "_kernel")
+    tot_ms = sum(p["ms"] for p in prof)
+    rl = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak,
+          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": _pmc_conv_traffic(pmc, dom["name"]),
+          "traffic_unit": "GB of HBM per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
+          "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": int(dom["launches"]),
+          "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
+          "algorithmic_gbyte_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
+          "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
+          "all_conv_tflops": round(sum(p["flops"] for p in convs) / (sum(p["ms"] for p in convs) * 1e-3) / 1e12, 2),
+          "kernels": {p["name"]: {"ms": round(p["ms"], 3), "launches": int(p["launches"])} for p in prof},
+          "hbm_bound_kernels": hbm}
+    mpp = MFMA_PER_PRODUCT.get(precision)
+    if dom["name"].startswith("conv3x3_wino"):
+        mpp = 16.0 / 36.0
+        rl["note"] = ("Winograd F(2x2,3x3): `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs, of which "
+                      "the matrix pipe executes 16/36; `mfma_issue_frac` is the fraction of the fp32 MFMA peak "
+                      "actually issued")
+    if mpp:
+        rl["mfma_issue_frac"] = round(mpp * ach / peak, 4)
+    return rl
+
+
+def time_warp(net, wl, reps=8):
+    """The frame warp (separate HIP gather kernel, pre-made in cfg2 so outside `value`): HIP events on its
+    launch stream around `reps` launches at 1080x1920; algorithmic bytes 44 B/px."""
+    torch = wl.torch
+    net.warp(wl.frames[1], wl.flows[0])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    src = wl.frames[1].float().contiguous()
+    e0.record()
+    for _ in range(reps):
+        net.warp(src, wl.flows[0])
+    e1.record()
+    torch.cuda.synchronize(wl.dev)
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    px = wl.flows[0].shape[0] * wl.flows[0].shape[1]
+    rec = {"avg_launch_us": round(us, 2), "algorithmic_gb_per_launch": round(px * 44 / 1e9, 4),
+           "algorithmic_gbps": round(px * 44 / us / 1e3, 1)}
+    rec["frac_of_hbm_peak"] = round(rec["algorithmic_gbps"] / HBM_PEAK_GBPS, 4)
+    hit = _pmc_table().get("warp_kernel")
+    if hit:
+        rec["pmc_gb_per_launch"] = round(hit["hbm_bytes_per_launch"] / 1e9, 4)
+    return rec
+
+
+def oracle_tile_check(net, torch):
+    """One 544x992 reference tile through this engine against the fp64-oracle values committed on a sparse
+    grid (tests/golden/model_544x992_sparse.npz, made by oracle/make_golden_fullsize.py), with the PSNR
+    protocol of SURVEY.md 8c-ii: pseudo ground truth = oracle + Gaussian noise at the reference's published
+    PSNRs (37.86 dB FI-SR channels, 48.07 dB SR channels, README.md:97)."""
+    path = os.path.join(ROOT, "tests", "golden", "model_544x992_sparse.npz")
+    if not os.path.isfile(path):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests_support import make_full_size_input
+    g = np.load(path)
+    x = make_full_size_input(int(g["seed"]), 544, 992)
+    _, _, l3 = net.model(torch.from_numpy(x).to(net.device), want_all=False)
+    st = int(g["stride"])
+    got = np.clip(l3[0, ::st, ::st, :].cpu().numpy().astype(np.float64), 0, 1)
+    exp = np.clip(g["l3_sparse"].astype(np.float64), 0, 1)
+    rng = np.random.default_rng(7)
+    out = {"what": "one 544x992x29 tile vs the fp64 oracle on every 16th HR pixel, clipped to [0,1]",
+           "max_abs": float(np.abs(got - exp).max()), "rms": float(np.sqrt(((got - exp) ** 2).mean()))}
+    shifts = []
+    for ch, db in ((slice(0, 3), 37.86), (slice(3, 6), 48.07), (slice(6, 9), 37.86)):
+        sigma = 10 ** (-db / 20)
+        gt = exp[..., ch] + rng.normal(0, sigma, exp[..., ch].shape)
+        psnr = lambda a: 10 * np.log10(1.0 / ((a - gt) ** 2).mean())
+        shifts.append(abs(psnr(got[..., ch]) - psnr(exp[..., ch])))
+    out["psnr_shift_db_vs_oracle"] = float(max(shifts))
+    out["within_0p02_db"] = bool(max(shifts) <= 0.02)
+    return out
+
+
+def cpu_baselines(W, wl):
+    """Bounded CPU sample on the host cores: ONE full 544x992 reference tile (2.85 TFLOP, 1/12 of a step's
+    tiles) through (a) the C oracle, the parity checker itself ("port", naive OpenMP loops) and (b) the
+    torch-CPU/oneDNN twin of the same graph (channels-last, all cores: the closest stand-in for the
+    reference's TF-1.13 Eigen/MKL-DNN CPU path, which cannot be installed here)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import c_oracle
+    from tests_support import make_full_size_input
+    ch, cw = 544, 992
+    x = make_full_size_input(4242, ch, cw)
+    tile_flop = ch * cw * FLOP_PER_LR_PX
+    tiles_per_stack = wl.flop_per_stack / tile_flop
+    cpu_model = "unknown"
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        tname = {"f32": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[dom["name"].split("<")[1].split(",")[0]]
-        nt = dom["name"].split("NT")[1][0]
-        key = f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in dom['name'] else 'false'}"
-        hits = [v for k, v in pmc.items() if k.startswith(key)]
-        if hits:
-            traffic = round(max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch"] / 1e9, 4)
-    except (OSError, KeyError, IndexError, ValueError):
-        traffic = None
-    return {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK[precision],
-            "unit": "TFLOP/s", "frac": round(ach / PEAK[precision], 4), "traffic": traffic,
-            "traffic_unit": "GB of HBM per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
-            "mfma_issue_frac": round(MFMA_PER_PRODUCT[precision] * ach / PEAK[precision], 4),
-            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": int(dom["launches"]),
-            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
-            "algorithmic_gbyte_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
-            "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
-            "all_conv_tflops": round(sum(p["flops"] for p in convs) / (sum(p["ms"] for p in convs) * 1e-3) / 1e12, 2),
-            "kernels": {p["name"]: {"ms": round(p["ms"], 3), "launches": int(p["launches"])} for p in prof}}
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blob = c_oracle.pack_blob(W)
+    c_oracle.forward(x[:, :32, :32], blob, double=False)           # warm up threads
+    t0 = time.perf_counter()
+    c_oracle.forward(x, blob, double=False)
+    dt = time.perf_counter() - t0
+    cores = int(c_oracle.lib().fisr_oracle_num_threads())
+    port = {"value": round(UNIQUE_PER_STACK / (dt * tiles_per_stack), 5), "unit": "frames/s", "cores": cores,
+            "kind": "port", "cpu_model": cpu_model,
+            "sample": f"1x one full {ch}x{cw}x29 tile through oracle/fisr_oracle.c (fp32, OpenMP, {dt:.2f} s, "
+                      f"{tile_flop / dt / 1e9:.1f} GFLOP/s), x{tiles_per_stack:.0f} tiles per 1080p stack"}
+    onednn = None
+    try:
+        import torch
+        import torch_cpu
+        nthr = os.cpu_count() or 1
+        try:
+            nthr = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            pass
+        torch.set_num_threads(nthr)
+        Wt = torch_cpu.prepare_weights(W)
+        torch_cpu.forward(x[:, :96, :96], Wt)                       # warm-up (primitive creation)
+        ts = []
+        t_all = time.perf_counter()
+        while len(ts) < 3 and (not ts or time.perf_counter() - t_all < 25.0):
+            t0 = time.perf_counter()
+            torch_cpu.forward(x, Wt)
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
+        onednn = {"value": round(UNIQUE_PER_STACK / (dt * tiles_per_stack), 5), "unit": "frames/s",
+                  "cores": int(torch.get_num_threads()), "kind": "port", "cpu_model": cpu_model,
+                  "sample": f"median of {len(ts)}x one full {ch}x{cw}x29 tile through oracle/torch_cpu.py (torch "
+                            f"{torch.__version__} CPU, oneDNN, fp32, channels-last, {dt:.2f} s, "
+                            f"{tile_flop / dt / 1e9:.1f} GFLOP/s), x{tiles_per_stack:.0f} tiles per 1080p stack"}
+    except Exception as e:                                          # noqa: BLE001 -- a baseline must not kill the bench line
+        onednn = {"error": repr(e)}
+    return port, onednn
 
 
 def main():
@@ -182,7 +402,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f16f8", "fp32", "fp16"])
+    ap.add_argument("--precision", default="fp32", choices=sorted(PEAK))
+    ap.add_argument("--others", default="bf16x3,f16f8",
+                    help="further engines timed on rank 0 at N=1 under other_precisions ('' = none)")
+    ap.add_argument("--parallelism", default="frame", choices=["frame", "tile"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")
     ap.add_argument("--batch", default="stack", choices=["stack", "window", "tile"],
                     help="how many independent tiles go through one forward: the whole 5-frame stack "
@@ -190,7 +413,7 @@ def main():
     ap.add_argument("--layer-profile", default=None, help="write a per-layer timing table (JSON) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-fp32-ref", action="store_true", help="skip the exact-fp32 comparison run")
+    ap.add_argument("--no-gather", action="store_true", help="frame-parallel: skip the RCCL gather of the output frames")
     args = ap.parse_args()
     patch = tuple(int(v) for v in args.patch.strip("()").split(","))
 
@@ -203,7 +426,7 @@ def main():
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     # test hooks (a 1-GPU box cannot host two RCCL ranks): FISR_BENCH_BACKEND=gloo and FISR_BENCH_ONE_DEVICE=1
-    # run the N > 1 control flow -- rendezvous, barriers, max-over-ranks -- with every rank on cuda:0
+    # run the N > 1 control flow -- rendezvous, collectives, barriers, max-over-ranks -- with every rank on cuda:0
     backend = os.environ.get("FISR_BENCH_BACKEND", "nccl")
     if os.environ.get("FISR_BENCH_ONE_DEVICE"):
         local_rank = 0
@@ -216,13 +439,28 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from fisr_amd import dist as fdist
     from fisr_amd import weights
     from fisr_amd.fisrnet import FISRnet
+
+    topo = group = None
+    parallelism = args.parallelism
+    n_tiles = patch[0] * patch[1]
+    if parallelism == "tile" and (world == 1 or world % n_tiles):
+        if rank == 0 and world > 1:
+            print(f"# --parallelism tile needs a multiple of {n_tiles} ranks; world={world} runs frame-parallel", file=sys.stderr)
+        parallelism = "frame"
+    if parallelism == "tile":
+        topo = fdist.TileTopology(patch, world, rank)
+        group = topo.make_group()
+    stacks = topo.n_groups if topo else world            # independent 5-frame stacks per step over the job
+    stack_id = topo.group_index if topo else rank
 
     W = weights.synthetic_weights(2020)
     net = FISRnet(device=f"cuda:{local_rank}", precision=args.precision)
     net.set_weights(W)
-    wl = Workload(torch, dev, rank, patch, args.batch)
+    wl = Workload(torch, dev, stack_id, patch, args.batch, parallelism, topo, group,
+                  gather_group_world=world if (parallelism == "frame" and not args.no_gather) else 1)
     wl.premake_warps(net)
 
     def sync():
@@ -243,21 +481,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    value = world * UNIQUE_PER_STACK * args.steps / elapsed
+    value = stacks * UNIQUE_PER_STACK * args.steps / elapsed
 
+    solo = rank == 0 and world == 1
     roofline = None
-    if not args.no_roofline:
+    if not args.no_roofline and parallelism == "frame":
+        gw, wl.gather_world = wl.gather_world, 1          # the instrumented pass times kernels, not the collective
         roofline = roofline_pass(net, wl, args.precision, max(1, min(args.steps, 2)),
                                  args.layer_profile if rank == 0 else None)
-        if roofline is not None and rank == 0:
-            mhz = shader_clock_under_load(args.precision)
-            if mhz:
-                roofline["shader_clock_mhz_under_load"] = round(mhz)
-                roofline["mfma_issue_frac_at_that_clock"] = round(roofline["mfma_issue_frac"] * 2400.0 / mhz, 4)
+        wl.gather_world = gw
+        if roofline is not None and solo:
+            roofline["hbm_bound_kernels"]["warp"] = time_warp(net, wl)
+            roofline["clock_sample"] = shader_clock_under_load(args.precision)
 
-    fp32_exact = parity = None
+    parity_oracle = None
     other = {}
-    if rank == 0 and world == 1 and not args.no_fp32_ref:
+    if solo:
+        parity_oracle = oracle_tile_check(net, torch)
         wl.step(net)
         torch.cuda.synchronize(dev)
         out_main = wl.full.clone()
@@ -271,76 +511,64 @@ def main():
                     "psnr_db": round(10 * np.log10(1.0 / mse), 2) if mse > 0 else None,
                     "uint8_mismatch_frac": float(((a * 255).to(torch.uint8) != (b * 255).to(torch.uint8)).double().mean())}
 
-        out_fp32 = out_main if args.precision == "fp32" else None
-        for alt in ("fp32", "f16f8", "bf16x3"):
-            if alt == args.precision:
-                continue
+        for alt in [a for a in args.others.split(",") if a and a != args.precision]:
             eng = FISRnet(device=f"cuda:{local_rank}", precision=alt)
             eng.set_weights(W)
-            wl.step(eng)                                      # warm-up + this precision's output
+            wl.step(eng)                                      # warm-up + this engine's output
             torch.cuda.synchronize(dev)
             out_alt = wl.full.clone()
+            nrep = max(2, min(args.steps, 5))
             t0 = time.perf_counter()
-            for _ in range(2):
+            for _ in range(nrep):
                 wl.step(eng)
             torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) / 2
-            rl = roofline_pass(eng, wl, alt, 1)
+            dt = (time.perf_counter() - t0) / nrep
+            rl = None if args.no_roofline else roofline_pass(eng, wl, alt, 1)
             rec = {"value": round(UNIQUE_PER_STACK / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
-                   "dtype": DTYPE[alt],
-                   "roofline": {k: rl[k] for k in ("kernel", "achieved", "peak", "frac", "mfma_issue_frac", "avg_launch_us")} if rl else None}
-            if alt == "fp32":
-                out_fp32 = out_alt
-                fp32_exact = rec
-                parity = compare(out_main, out_fp32, f"{args.precision} vs exact fp32")
-            else:
-                if out_fp32 is not None:
-                    rec["parity_vs_fp32"] = compare(out_alt, out_fp32, f"{alt} vs exact fp32")
-                other[alt] = rec
+                   "steps": nrep, "dtype": DTYPE[alt],
+                   "roofline": {k: rl[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                   "mfma_issue_frac", "avg_launch_us", "launches", "share_of_gpu_time",
+                                                   "all_conv_tflops") if k in rl} if rl else None,
+                   "parity_vs_" + args.precision: compare(out_alt, out_main, f"{alt} vs the {args.precision} engine"),
+                   "parity_vs_oracle": oracle_tile_check(eng, torch)}
+            other[alt] = rec
             eng.close()
             del eng, out_alt
             torch.cuda.empty_cache()
 
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import c_oracle
-        ch, cw = 256, 384
-        x = np.random.default_rng(3).random((1, ch, cw, 29)).astype(np.float32)
-        blob = c_oracle.pack_blob(W)
-        c_oracle.forward(x[:, :32, :32], blob, double=False)           # warm up threads
-        t0 = time.perf_counter()
-        reps = 0
-        while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 50):
-            c_oracle.forward(x, blob, double=False)
-            reps += 1
-        dt = (time.perf_counter() - t0) / reps
-        cpu_flops = ch * cw * FLOP_PER_LR_PX / dt
-        cores = c_oracle.lib().fisr_oracle_num_threads()
-        cpu_baseline = {"value": round(UNIQUE_PER_STACK / (wl.flop_per_stack / cpu_flops), 5), "unit": "frames/s",
-                        "cores": int(cores), "kind": "port",
-                        "sample": f"{reps}x one {ch}x{cw}x29 forward through oracle/fisr_oracle.c (fp32, OpenMP, "
-                                  f"{cpu_flops / 1e9:.1f} GFLOP/s), extrapolated by FLOPs to the tiled 1080p stack"}
+    cpu_port = cpu_onednn = None
+    if solo and not args.no_cpu_baseline:
+        cpu_port, cpu_onednn = cpu_baselines(W, wl)
 
     if rank == 0:
         t0_ = wl.tiles[0]
+        if parallelism == "tile":
+            par = (f"tile-parallel: {stacks} stack(s) x {n_tiles} tiles, one tile per GPU, RCCL all-gather of 32-px "
+                   "input halos and of uint8 output tiles inside each group of " + str(n_tiles))
+            scaling = "strong" if stacks == 1 else "weak"
+        elif world > 1:
+            par = f"frame-parallel x{world} (one stack per GPU" + ("" if args.no_gather else ", RCCL gather of the uint8 output frames to rank 0") + ")"
+            scaling = "weak"
+        else:
+            par, scaling = "single GPU", "weak"
         line = {
             "metric": "2K->4K FISR output frames/sec per node (unique frames of 5-frame 1080p stacks)",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"cfg2: 5-frame 1080x1920 stack -> 3 windows x {patch[0]}x{patch[1]} tiles of "
                                    f"{t0_.in_h}x{t0_.in_w}x29 (32-px halo) -> 7 unique {wl.h * 2}x{wl.w * 2} frames; "
                                    "pre-made flow+warp resident in HBM; synthetic seeded weights",
-                       "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
-                       "tiles_per_forward": {"stack": 3 * len(wl.tiles), "window": len(wl.tiles), "tile": 1}[args.batch],
+                       "engine": net.engine_description(),
+                       "parallelism": par,
+                       "tiles_per_forward": 3 if parallelism == "tile" else {"stack": 3 * len(wl.tiles), "window": len(wl.tiles), "tile": 1}[args.batch],
                        "tflop_per_step": round(wl.flop_per_stack / 1e12, 3),
-                       "raw_fps": round(world * 9 * args.steps / elapsed, 3),
-                       "forwards_per_s": round(world * 3 * args.steps / elapsed, 3),
-                       "achieved_tflops_whole_step": round(world * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "fp32_exact": fp32_exact, "parity_vs_fp32": parity,
-            "other_precisions": other or None,
+                       "raw_fps": round(stacks * 9 * args.steps / elapsed, 3),
+                       "forwards_per_s": round(stacks * 3 * args.steps / elapsed, 3),
+                       "achieved_tflops_whole_step": round(stacks * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
+            "roofline": roofline, "cpu_baseline": cpu_port, "cpu_baseline_onednn": cpu_onednn,
+            "parity_vs_oracle": parity_oracle, "other_precisions": other or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

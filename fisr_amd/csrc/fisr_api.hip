@@ -79,6 +79,27 @@ int fail(fisr_ctx* ctx, int code, const std::string& msg) {
   } while (0)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Every entry point that launches work selects the device the work belongs to and restores the caller's
+// current device on return (a host may drive several GPUs, one ctx each, from one thread; torch's notion of
+// the current device must not change behind its back).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (dev < 0) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+// Device that owns a device pointer (glue entry points have no ctx: the output tensor decides); -1 if unknown.
+inline int device_of(const void* p) {
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged ? a.device : -1;
+}
 inline int ilog2(int v) { int k = 0; while ((1 << (k + 1)) <= v) ++k; return k; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int grid_for(size_t work, int block = 256) {
@@ -584,7 +605,8 @@ int fisr_create(fisr_ctx** out, int device_id) {
   if (e != hipSuccess || ndev == 0)
     return fail(nullptr, FISR_EHIP, std::string("fisr_create: no HIP device (") + hipGetErrorString(e) + ")");
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, FISR_EINVAL, "fisr_create: bad device id");
-  HIP_OK(nullptr, hipSetDevice(device_id));
+  DeviceGuard guard(device_id);
+  HIP_OK(nullptr, guard.err);
   fisr_ctx* c = new fisr_ctx();
   c->dev = device_id;
   for (auto& s : all_specs()) {
@@ -599,7 +621,7 @@ int fisr_create(fisr_ctx** out, int device_id) {
 
 void fisr_destroy(fisr_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->dev);
+  DeviceGuard guard(ctx->dev);
   for (auto& kv : ctx->convs) {
     if (kv.second.d_w) (void)hipFree(kv.second.d_w);
     if (kv.second.d_b) (void)hipFree(kv.second.d_b);
@@ -651,7 +673,8 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
     if (!cw.have_w) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/w");
     if (!cw.have_b) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/b");
   }
-  HIP_OK(ctx, hipSetDevice(ctx->dev));
+  DeviceGuard guard(ctx->dev);
+  HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
     int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second); });
     if (rc) return rc;
@@ -677,7 +700,8 @@ int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out
   const size_t need = fisr_workspace_bytes(ctx, n, h, w);
   if (workspace_bytes < need)
     return fail(ctx, FISR_ENOMEM, "fisr_forward: workspace " + std::to_string(workspace_bytes) + " < " + std::to_string(need));
-  HIP_OK(ctx, hipSetDevice(ctx->dev));
+  DeviceGuard guard(ctx->dev);
+  HIP_OK(ctx, guard.err);
   hipStream_t st = (hipStream_t)stream;
   auto run = [&](auto tag) -> int {
     typedef decltype(tag) T;
@@ -723,6 +747,8 @@ int fisr_profile_read(fisr_ctx* ctx, int cap, const char** name, double* total_m
 int fisr_warp(const float* src, const float* flow, float scale, int h, int w, int quantized, float* dst, void* stream) {
   if (!src || !flow || !dst || h < 1 || w < 1) return fail(nullptr, FISR_EINVAL, "fisr_warp: bad argument");
   static const ColorConsts cc = make_color_consts();
+  DeviceGuard guard(device_of(dst));
+  HIP_OK(nullptr, guard.err);
   hipLaunchKernelGGL(warp_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, src, flow, scale,
                      h, w, quantized, dst, cc);
   HIP_OK(nullptr, hipGetLastError());
@@ -736,6 +762,8 @@ int fisr_pack_input(const uint8_t* const* fr, const float* const* fl, const floa
   PackPtrs pp;
   for (int i = 0; i < 3; ++i) pp.fr[i] = fr[i];
   for (int i = 0; i < 4; ++i) { pp.fl[i] = fl[i]; pp.wp[i] = wp[i]; }
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
   hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, pp, h0, w0, h, w, out);
   HIP_OK(nullptr, hipGetLastError());
   return 0;
@@ -744,6 +772,8 @@ int fisr_pack_input(const uint8_t* const* fr, const float* const* fl, const floa
 int fisr_unpack_output(const float* pred, int h, int w, uint8_t* yuv_u8, uint8_t* rgb_u8, void* stream) {
   if (!pred || h < 1 || w < 1) return fail(nullptr, FISR_EINVAL, "fisr_unpack_output: bad argument");
   static const ColorConsts cc = make_color_consts();
+  DeviceGuard guard(device_of(pred));
+  HIP_OK(nullptr, guard.err);
   hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, pred, h, w,
                      yuv_u8, rgb_u8, cc);
   HIP_OK(nullptr, hipGetLastError());
@@ -754,31 +784,48 @@ int fisr_stitch(const float* tile, int th, int tw, int sy, int sx, int ch, int c
                 int dy, int dx, void* stream) {
   if (!tile || !full || sy < 0 || sx < 0 || sy + ch > th || sx + cw > tw || dy < 0 || dx < 0 || dy + ch > fh || dx + cw > fw)
     return fail(nullptr, FISR_EINVAL, "fisr_stitch: region out of range");
+  DeviceGuard guard(device_of(full));
+  HIP_OK(nullptr, guard.err);
   hipLaunchKernelGGL(stitch_kernel, dim3(grid_for((size_t)ch * cw * 9)), dim3(256), 0, (hipStream_t)stream, tile, tw, sy,
                      sx, ch, cw, full, fw, dy, dx);
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }
 
+// One 8-byte accumulator per device for the two reductions below, allocated on first use and kept (a
+// hipMalloc/hipFree pair per call is an implicit device-wide synchronisation).  The calls end with a stream
+// synchronise, so one slot per device is enough for the single-threaded hosts this ABI serves.
+static double* reduce_scratch(int dev) {
+  static double* slot[64] = {};
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!slot[dev] && hipMalloc((void**)&slot[dev], sizeof(double)) != hipSuccess) slot[dev] = nullptr;
+  return slot[dev];
+}
+
 int fisr_sse_vs_u8(const float* pred, const uint8_t* gt, size_t count, double* out_host, void* stream) {
   if (!pred || !gt || !out_host) return fail(nullptr, FISR_EINVAL, "fisr_sse_vs_u8: null argument");
-  double* d = nullptr;
-  HIP_OK(nullptr, hipMalloc((void**)&d, sizeof(double)));
+  const int dev = device_of(pred);
+  DeviceGuard guard(dev);
+  HIP_OK(nullptr, guard.err);
+  double* d = reduce_scratch(dev);
+  if (!d) return fail(nullptr, FISR_EHIP, "fisr_sse_vs_u8: pred is not a device pointer / no scratch");
   hipStream_t st = (hipStream_t)stream;
   HIP_OK(nullptr, hipMemsetAsync(d, 0, sizeof(double), st));
   hipLaunchKernelGGL(sse_u8_kernel, dim3(grid_for(count)), dim3(256), 0, st, pred, gt, count, d);
   HIP_OK(nullptr, hipGetLastError());
   HIP_OK(nullptr, hipMemcpyAsync(out_host, d, sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_OK(nullptr, hipStreamSynchronize(st));
-  (void)hipFree(d);
   return 0;
 }
 
 int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, int coff, double* out_host, void* stream) {
   if (!a || !b || !out_host || h < 7 || w < 7 || cstride < 3 || coff < 0 || coff + 3 > cstride)
     return fail(nullptr, FISR_EINVAL, "fisr_ssim_u8: bad argument");
-  double* d = nullptr;
-  HIP_OK(nullptr, hipMalloc((void**)&d, sizeof(double)));
+  const int dev = device_of(a);
+  DeviceGuard guard(dev);
+  HIP_OK(nullptr, guard.err);
+  double* d = reduce_scratch(dev);
+  if (!d) return fail(nullptr, FISR_EHIP, "fisr_ssim_u8: a is not a device pointer / no scratch");
   hipStream_t st = (hipStream_t)stream;
   HIP_OK(nullptr, hipMemsetAsync(d, 0, sizeof(double), st));
   const size_t tiles = (size_t)(h / 7) * (w / 7) * 3;
@@ -787,7 +834,6 @@ int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, 
   double sum = 0;
   HIP_OK(nullptr, hipMemcpyAsync(&sum, d, sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_OK(nullptr, hipStreamSynchronize(st));
-  (void)hipFree(d);
   *out_host = sum / (double)tiles;
   return 0;
 }
@@ -809,8 +855,10 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   if (out_f32 && (res || (flags & FISR_CONV_D2S)))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: the fp32-output store has no residual / d2s");
   if (c0 % cc || c1 % cc || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
-  if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4)))
-    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two");
+  if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4) || cout / 4 < CONV_REC))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two >= 16 (whole 16-channel records)");
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
   ConvW cw;
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
@@ -840,6 +888,8 @@ int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int 
   const int uc = prec_unit(precision);
   if (c % (prec_grouped16(precision) ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_maxpool2: c must be a multiple of the channel unit");
   const size_t work = (size_t)n * (h / 2) * (w / 2) * c / uc;
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
   with_prec(precision, [&](auto tag) {
     typedef decltype(tag) T;
     hipLaunchKernelGGL(maxpool2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, n, h, w, c);
@@ -854,6 +904,8 @@ int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int
   const int uc = prec_unit(precision);
   if (c % (prec_grouped16(precision) ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of the channel unit");
   const size_t work = (size_t)n * h * w * c / uc;
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
   with_prec(precision, [&](auto tag) {
     typedef decltype(tag) T;
     hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, (const T*)in, (T*)out, n, h, w, c);

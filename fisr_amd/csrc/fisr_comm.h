@@ -74,7 +74,8 @@ int fisr_comm_unique_id(void* id_out) {
 int fisr_comm_init(fisr_comm** out, const void* id, int nranks, int rank, int device_id) {
   if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, FISR_EINVAL, "fisr_comm_init: bad argument");
   if (!rccl().why.empty()) return fail(nullptr, FISR_ESTATE, rccl().why);
-  HIP_OK(nullptr, hipSetDevice(device_id));
+  DeviceGuard guard(device_id);
+  HIP_OK(nullptr, guard.err);
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof uid);
   fisr_comm* c = new fisr_comm;
@@ -88,6 +89,8 @@ int fisr_comm_init(fisr_comm** out, const void* id, int nranks, int rank, int de
 int fisr_comm_allgather(fisr_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
   if (!c || !send || !recv) return fail(nullptr, FISR_EINVAL, "fisr_comm_allgather: null");
   if (bytes_per_rank == 0) return 0;
+  DeviceGuard guard(c->dev);
+  HIP_OK(nullptr, guard.err);
   const ncclResult_t r = rccl().AllGather(send, recv, bytes_per_rank, ncclUint8, c->comm, (hipStream_t)stream);
   return r == ncclSuccess ? 0 : rccl_fail("ncclAllGather", r);
 }
@@ -95,6 +98,8 @@ int fisr_comm_allgather(fisr_comm* c, const void* send, void* recv, size_t bytes
 int fisr_comm_sendrecv(fisr_comm* c, const void* send, void* recv, size_t bytes, int peer, void* stream) {
   if (!c || !send || !recv || peer < 0 || peer >= c->nranks) return fail(nullptr, FISR_EINVAL, "fisr_comm_sendrecv: bad argument");
   if (bytes == 0) return 0;
+  DeviceGuard guard(c->dev);
+  HIP_OK(nullptr, guard.err);
   ncclResult_t r = rccl().GroupStart();
   if (r == ncclSuccess) r = rccl().Send(send, bytes, ncclUint8, peer, c->comm, (hipStream_t)stream);
   if (r == ncclSuccess) r = rccl().Recv(recv, bytes, ncclUint8, peer, c->comm, (hipStream_t)stream);
@@ -108,6 +113,7 @@ int fisr_comm_size(const fisr_comm* c) { return c ? c->nranks : 0; }
 
 void fisr_comm_destroy(fisr_comm* c) {
   if (!c) return;
+  DeviceGuard guard(c->dev);
   if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
   delete c;
 }

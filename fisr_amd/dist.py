@@ -7,8 +7,9 @@ The reference is single-GPU (main.py:19-20).  Its work units are independent (SU
     5-frame stack -- is an independent forward; weights are replicated (193 MB).  Units are
     dealt round-robin; NO data-path collective.  This is what bench.py scales (weak scaling).
   * tile-parallel: the num_patch[0] x num_patch[1] tiles of one window (FISRnet.py:847-880) go
-    to different ranks (one tile per rank, world == number of tiles) for latency.  Two real
-    exchange steps, both all-gathers over xGMI:
+    to different ranks (one tile per rank; the ranks form world / tiles independent tile groups,
+    e.g. 8 GPUs = 2 windows x (2x2) tiles with the reference's default seams) for latency.  Two real
+    exchange steps, both all-gathers over xGMI inside a tile group:
       1. input halos -- each rank assembles only its own core region of the 29-ch input; the
          32-px border ring of every core is all-gathered and each rank cuts the strips its tile
          needs out of its neighbours' rings (7 MB/rank at 1080p 2x2);
@@ -38,111 +39,240 @@ def shard_units(n_units: int, world: int, rank: int) -> List[int]:
 
 
 def tile_of_rank(num_patch: Tuple[int, int], world: int, rank: int) -> int:
-    if world != num_patch[0] * num_patch[1]:
-        raise ValueError(f"tile-parallel needs world ({world}) == number of tiles {num_patch}")
-    return rank
+    """Tile index of `rank` inside its tile group (see TileTopology); world must be a multiple of the tiles."""
+    return TileTopology(num_patch, world, rank).tile
+
+
+class TileTopology:
+    """How `world` ranks share the tiles of the reference's test_patch plan.
+
+    T = num_patch[0] * num_patch[1] tiles per window (FISRnet.py:847).  world must be a multiple of T: the
+    ranks form world / T *tile groups* of T consecutive ranks; a group works on one window (or stack of
+    windows) at a time, rank `g*T + t` owning tile t, so 8 GPUs run 2 windows x (2x2) tiles with the
+    reference's default seams and numerics, or 1 window x (2x4) tiles (`--test_patch (2,4)`).  Groups are
+    independent of each other (frame-parallel across groups); the two collectives of the path (halo rings
+    in, uint8 tiles out) stay inside a group."""
+
+    def __init__(self, num_patch: Tuple[int, int], world: int, rank: int):
+        nh, nw = int(num_patch[0]), int(num_patch[1])
+        T = nh * nw
+        if T < 1 or world < 1 or world % T:
+            raise ValueError(f"tile-parallel needs world ({world}) to be a multiple of the number of tiles {tuple(num_patch)}")
+        if not 0 <= rank < world:
+            raise ValueError("rank out of range")
+        self.num_patch, self.world, self.rank, self.tiles = (nh, nw), world, rank, T
+        self.n_groups = world // T
+        self.group_index, self.tile = divmod(rank, T)
+        self.group_ranks = list(range(self.group_index * T, (self.group_index + 1) * T))
+        self.pH, self.pW = divmod(self.tile, nw)
+
+    def all_group_ranks(self) -> List[List[int]]:
+        return [list(range(g * self.tiles, (g + 1) * self.tiles)) for g in range(self.n_groups)]
+
+    def make_group(self):
+        """torch.distributed subgroup of this rank's tile group (every rank must call this: new_group is
+        collective over the default group, all groups are created in the same order on all ranks)."""
+        import torch.distributed as dist
+        if self.n_groups == 1:
+            return None                      # the default group IS the tile group
+        mine = None
+        for ranks in self.all_group_ranks():
+            g = dist.new_group(ranks)
+            if self.rank in ranks:
+                mine = g
+        return mine
+
+
+def _group_rank_size(group):
+    import torch.distributed as dist
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _all_gather(t, group=None):
+    """all_gather of one contiguous tensor per rank -> list of tensors.  RCCL ("nccl") moves device
+    tensors directly over xGMI; gloo (CPU tests, and the one-box GPU tests where several ranks share a
+    device) only carries host tensors for this collective, so device tensors are staged through the host."""
+    import torch
+    import torch.distributed as dist
+    _, world = _group_rank_size(group)
+    backend = dist.get_backend(group)
+    if t.is_cuda and backend != "nccl":
+        host = t.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return [p.to(t.device) for p in parts]
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    return parts
+
+
+def gather_to(t, dst: int = 0, group=None):
+    """Gather one contiguous tensor per rank to rank `dst` (frame-parallel output collection, cfg4 of
+    BASELINE.json: "RCCL gather of outputs"): returns [world, *t.shape] on dst, None elsewhere.  Same
+    host staging rule as _all_gather for non-RCCL backends."""
+    import torch
+    import torch.distributed as dist
+    rank, world = _group_rank_size(group)
+    gdst = dst if group is None else dist.get_global_rank(group, dst)
+    staged = t.is_cuda and dist.get_backend(group) != "nccl"
+    src = (t.cpu() if staged else t).contiguous()
+    parts = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+    dist.gather(src, parts, dst=gdst, group=group)
+    if rank != dst:
+        return None
+    out = torch.stack(parts)
+    return out.to(t.device) if staged else out
 
 
 # ----------------------------------------------------------------------------- halo exchange
 def border_ring(core, pb: int = PB):
-    """core [sH,sW,C] -> one flat buffer [top pb rows | bottom pb rows | left pb cols | right pb cols]."""
+    """core [..., sH, sW, C] -> flat buffer [top pb rows | bottom pb rows | left pb cols | right pb cols]
+    (leading batch dims kept: one ring per window when a stack of windows is exchanged at once)."""
     import torch
-    return torch.cat([core[:pb].reshape(-1), core[-pb:].reshape(-1),
-                      core[:, :pb].reshape(-1), core[:, -pb:].reshape(-1)])
+    lead = core.shape[:-3]
+    f = lambda x: x.reshape(lead + (-1,))
+    return torch.cat([f(core[..., :pb, :, :]), f(core[..., -pb:, :, :]),
+                      f(core[..., :, :pb, :]), f(core[..., :, -pb:, :])], dim=-1)
 
 
 def _ring_views(ring, sH: int, sW: int, c: int, pb: int):
+    lead = ring.shape[:-1]
     o = 0
-    top = ring[o:o + pb * sW * c].view(pb, sW, c); o += pb * sW * c
-    bot = ring[o:o + pb * sW * c].view(pb, sW, c); o += pb * sW * c
-    left = ring[o:o + sH * pb * c].view(sH, pb, c); o += sH * pb * c
-    right = ring[o:o + sH * pb * c].view(sH, pb, c)
+    top = ring[..., o:o + pb * sW * c].reshape(lead + (pb, sW, c)); o += pb * sW * c
+    bot = ring[..., o:o + pb * sW * c].reshape(lead + (pb, sW, c)); o += pb * sW * c
+    left = ring[..., o:o + sH * pb * c].reshape(lead + (sH, pb, c)); o += sH * pb * c
+    right = ring[..., o:o + sH * pb * c].reshape(lead + (sH, pb, c))
     return top, bot, left, right
 
 
 def assemble_tile_input(core, rings: Sequence, num_patch: Tuple[int, int], rank: int, pb: int = PB):
-    """Build this rank's halo'd tile input (what FISRnet.py:865 slices out of the full frame) from
-    its own core [sH,sW,C] and the all-gathered border rings of all ranks."""
+    """Build tile `rank`'s halo'd input (what FISRnet.py:865 slices out of the full frame) from its own
+    core [..., sH, sW, C] and the all-gathered border rings of all tiles of the group."""
     import torch
     nh, nw = num_patch
     pH, pW = rank // nw, rank % nw
-    sH, sW, c = core.shape
+    sH, sW, c = core.shape[-3:]
+    lead = core.shape[:-3]
     up, down, lft, rgt = pH > 0, pH < nh - 1, pW > 0, pW < nw - 1
     H = sH + pb * (up + down)
     W = sW + pb * (lft + rgt)
-    out = torch.zeros((H, W, c), dtype=core.dtype, device=core.device)
+    out = torch.zeros(lead + (H, W, c), dtype=core.dtype, device=core.device)
     y0, x0 = pb * up, pb * lft
-    out[y0:y0 + sH, x0:x0 + sW] = core
+    out[..., y0:y0 + sH, x0:x0 + sW, :] = core
 
     def ring(r):
         return _ring_views(rings[r], sH, sW, c, pb)
 
     if up:
-        out[:pb, x0:x0 + sW] = ring(rank - nw)[1]                     # neighbour's bottom rows
+        out[..., :pb, x0:x0 + sW, :] = ring(rank - nw)[1]                     # neighbour's bottom rows
     if down:
-        out[y0 + sH:, x0:x0 + sW] = ring(rank + nw)[0]                # neighbour's top rows
+        out[..., y0 + sH:, x0:x0 + sW, :] = ring(rank + nw)[0]                # neighbour's top rows
     if lft:
-        out[y0:y0 + sH, :pb] = ring(rank - 1)[3]                      # neighbour's right cols
+        out[..., y0:y0 + sH, :pb, :] = ring(rank - 1)[3]                      # neighbour's right cols
     if rgt:
-        out[y0:y0 + sH, x0 + sW:] = ring(rank + 1)[2]                 # neighbour's left cols
+        out[..., y0:y0 + sH, x0 + sW:, :] = ring(rank + 1)[2]                 # neighbour's left cols
     # corners come from the diagonal neighbour's top/bottom rows
     if up and lft:
-        out[:pb, :pb] = ring(rank - nw - 1)[1][:, -pb:]
+        out[..., :pb, :pb, :] = ring(rank - nw - 1)[1][..., :, -pb:, :]
     if up and rgt:
-        out[:pb, x0 + sW:] = ring(rank - nw + 1)[1][:, :pb]
+        out[..., :pb, x0 + sW:, :] = ring(rank - nw + 1)[1][..., :, :pb, :]
     if down and lft:
-        out[y0 + sH:, :pb] = ring(rank + nw - 1)[0][:, -pb:]
+        out[..., y0 + sH:, :pb, :] = ring(rank + nw - 1)[0][..., :, -pb:, :]
     if down and rgt:
-        out[y0 + sH:, x0 + sW:] = ring(rank + nw + 1)[0][:, :pb]
+        out[..., y0 + sH:, x0 + sW:, :] = ring(rank + nw + 1)[0][..., :, :pb, :]
     return out
 
 
 def exchange_halos(core, num_patch: Tuple[int, int], group=None, pb: int = PB):
-    """All-gather the 32-px border rings and return this rank's halo'd tile input."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    tile_of_rank(num_patch, world, rank)
-    mine = border_ring(core, pb).contiguous()
-    rings = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(rings, mine, group=group)
+    """All-gather the 32-px border rings inside the tile group and return this rank's halo'd tile input.
+    core: [sH,sW,C] or [B,sH,sW,C] (B windows exchanged in one collective)."""
+    rank, world = _group_rank_size(group)
+    if world != num_patch[0] * num_patch[1]:
+        raise ValueError(f"tile group of {world} ranks cannot hold the tiles of {tuple(num_patch)}")
+    rings = _all_gather(border_ring(core, pb).contiguous(), group)
     return assemble_tile_input(core, rings, num_patch, rank, pb)
 
 
 # ----------------------------------------------------------------------------- output gather
 def gather_tiles(my_tile, num_patch: Tuple[int, int], group=None):
-    """my_tile [sH*sf, sW*sf, C] (already trimmed) -> full frame [h*sf, w*sf, C] on every rank."""
+    """my_tile [..., sH*sf, sW*sf, C] (already trimmed) -> full frame [..., h*sf, w*sf, C] on every rank
+    of the tile group."""
     import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    tile_of_rank(num_patch, world, rank)
-    my_tile = my_tile.contiguous()
-    parts = [torch.empty_like(my_tile) for _ in range(world)]
-    dist.all_gather(parts, my_tile, group=group)
+    rank, world = _group_rank_size(group)
+    if world != num_patch[0] * num_patch[1]:
+        raise ValueError(f"tile group of {world} ranks cannot hold the tiles of {tuple(num_patch)}")
+    parts = _all_gather(my_tile.contiguous(), group)
     nh, nw = num_patch
-    rows = [torch.cat(parts[r * nw:(r + 1) * nw], dim=1) for r in range(nh)]
-    return torch.cat(rows, dim=0)
+    rows = [torch.cat(parts[r * nw:(r + 1) * nw], dim=-2) for r in range(nh)]
+    return torch.cat(rows, dim=-3)
 
 
 def tile_parallel_window(core_input, num_patch: Tuple[int, int], forward: Callable, sf: int = 2, group=None,
                          postprocess: Callable | None = None, pb: int = PB):
-    """One window, one tile per rank.  core_input [sH,sW,29] is this rank's core region of the
-    packed input; `forward(tile_in [1,H,W,29]) -> [1,H*sf,W*sf,9]` is the FISRnet forward
-    (net.model(...)[2] on the GPU path).  Returns the full frame on every rank."""
-    import torch.distributed as dist
-    rank = dist.get_rank(group)
+    """One window (or a batch of B windows), one tile per rank of the tile group.  core_input [sH,sW,29] /
+    [B,sH,sW,29] is this rank's core region of the packed input; `forward(tile_in [B,H,W,29]) ->
+    [B,H*sf,W*sf,9]` is the FISRnet forward (net.model(...)[2] on the GPU path).  Returns the full frame(s)
+    on every rank of the group.  Reference unit of work: FISRnet.py:847-880."""
+    rank, _ = _group_rank_size(group)
     nh, nw = num_patch
     pH, pW = rank // nw, rank % nw
+    batched = core_input.dim() == 4
     tile_in = exchange_halos(core_input, num_patch, group, pb)
-    pred = forward(tile_in.unsqueeze(0))[0]
+    pred = forward(tile_in if batched else tile_in.unsqueeze(0))
+    if not batched:
+        pred = pred[0]
     # trim_patch_boundary (utils.py:138-159): drop pb*sf HR pixels on the sides that carry a halo
     y0 = pb * sf if pH > 0 else 0
     x0 = pb * sf if pW > 0 else 0
-    sH, sW = core_input.shape[0], core_input.shape[1]
-    pred = pred[y0:y0 + sH * sf, x0:x0 + sW * sf]
+    sH, sW = core_input.shape[-3], core_input.shape[-2]
+    pred = pred[..., y0:y0 + sH * sf, x0:x0 + sW * sf, :]
     if postprocess is not None:
         pred = postprocess(pred)
     return gather_tiles(pred, num_patch, group)
+
+
+def core_region(h: int, w: int, num_patch: Tuple[int, int], tile: int):
+    """(y0, y1, x0, x1) of tile `tile`'s core (no halo) in the cropped h x w frame."""
+    nh, nw = num_patch
+    sH, sW = h // nh, w // nw
+    pH, pW = divmod(tile, nw)
+    return pH * sH, (pH + 1) * sH, pW * sW, (pW + 1) * sW
+
+
+def pack_core(net, frames_u8, flows, warps, h: int, w: int, num_patch: Tuple[int, int], tile: int):
+    """Input assembly (FISRnet.py:828-843) of ONLY this rank's core region: the 11 source tensors are cut
+    to the core rectangle and packed by the HIP kernel -> [1, sH, sW, 29] float32 on the GPU."""
+    y0, y1, x0, x1 = core_region(h, w, num_patch, tile)
+    cut = lambda t: t[y0:y1, x0:x1].contiguous()
+    return net.pack_input([cut(f) for f in frames_u8], [cut(f) for f in flows], [cut(f) for f in warps],
+                          y1 - y0, x1 - x0)
+
+
+def tile_parallel_engine_window(net, cores, num_patch: Tuple[int, int], group=None, want_rgb: bool = False):
+    """The tile-parallel path with the real engine: cores [B,sH,sW,29] (this rank's core of B windows) ->
+    halo all-gather -> fisr_forward on the halo'd tile (batch B) -> trim -> on-GPU clip/quantise/colour
+    (fisr_unpack_output, per pixel, so per tile is exact) -> all-gather of the uint8 tiles.  Returns the
+    full uint8 YUV frames [B, 2h, 2w, 9] on every rank of the tile group (71 MB per 4K window instead of
+    283 MB in fp32), or (yuv, rgb [B, 3, 2h, 2w, 3]) with want_rgb."""
+    import torch
+
+    def fwd(tile_in):
+        return net.model(tile_in, want_all=False)[2]
+
+    def quantise(pred):                                            # [B, sH*2, sW*2, 9] float32 -> uint8
+        outs = []
+        for p in pred:
+            yuv, rgb = net.unpack_output(p.contiguous(), want_rgb=want_rgb)
+            if want_rgb:                                           # [3,h,w,3] -> 9 more channels, one gather
+                yuv = torch.cat([yuv, rgb.permute(1, 2, 0, 3).reshape(yuv.shape)], dim=-1)
+            outs.append(yuv)
+        return torch.stack(outs)
+
+    out = tile_parallel_window(cores, num_patch, fwd, sf=net.scale_factor, group=group, postprocess=quantise)
+    if not want_rgb:
+        return out
+    B, H2, W2, _ = out.shape
+    return out[..., :9].contiguous(), out[..., 9:].reshape(B, H2, W2, 3, 3).permute(0, 3, 1, 2, 4).contiguous()
 
 
 class FisrComm:

@@ -28,9 +28,15 @@ from . import tiling
 from . import weights as _weights
 from .lib import FisrError
 
-_PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32,
+_PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32, "fp32d": _lib.PREC_F32,
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
          "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8}
+
+
+# ONE default arithmetic for every entry point (FISRnet(), main.py, bench.py): the reference computes in
+# fp32 (cfg2 of BASELINE.json), so the default is the fp32 engine; the split-precision modes are opt-in.
+DEFAULT_PRECISION = "fp32"
+PRECISIONS = ("fp32", "bf16x3", "f16f8", "fp16")     # CLI names
 
 
 def _torch():
@@ -57,9 +63,33 @@ def default_args(**over) -> SimpleNamespace:
         test_img_dir="./test_img_dir", checkpoint_dir="./checkpoint_dir",
         test_patch=(2, 2), test_input_size=(1080, 1920),
         frame_folder_path="./FISR_test_folder/scene1", FISR_input_size=(1080, 1920), frame_num=5,
-        FISR_test_patch=(2, 2), precision="fp32", device="cuda:0")
+        FISR_test_patch=(2, 2), precision=DEFAULT_PRECISION, device="cuda:0", batch_tiles=True)
     a.__dict__.update(over)
     return a
+
+
+def fit_pack_inputs(fr, fl, wp, h: int, w: int):
+    """Shape contract of `pack_input`: the kernel indexes all 11 tensors with ONE row stride (that of frame
+    0), whereas the reference slices every array independently with [:h,:w] (FISRnet.py:828-843) and raises
+    when one is too small.  So: every tensor must be [H,W,C] with the right C and at least the crop size;
+    tensors larger than frame 0 are cropped (top-left) to frame 0's size; smaller ones are an error.
+    Returns (frames, flows, warps, h0, w0)."""
+    h0, w0 = fr[0].shape[:2]
+    if h > h0 or w > w0:
+        raise ValueError(f"pack_input: crop {h}x{w} exceeds the frame size {h0}x{w0}")
+
+    def fit(t, c, what):
+        if t.dim() != 3 or t.shape[2] != c:
+            raise ValueError(f"pack_input: {what} must be [h,w,{c}], got {tuple(t.shape)}")
+        if t.shape[0] < h or t.shape[1] < w:
+            raise ValueError(f"pack_input: {what} is {t.shape[0]}x{t.shape[1]}, smaller than the crop {h}x{w}")
+        if t.shape[0] < h0 or t.shape[1] < w0:
+            raise ValueError(f"pack_input: {what} is {t.shape[0]}x{t.shape[1]} but frame 0 is {h0}x{w0}: "
+                             "crop the inputs to a common size first")
+        return t if tuple(t.shape[:2]) == (h0, w0) else t[:h0, :w0].contiguous()
+
+    return ([fit(f, 3, f"frame {i}") for i, f in enumerate(fr)], [fit(f, 2, f"flow {i}") for i, f in enumerate(fl)],
+            [fit(f, 3, f"warp {i}") for i, f in enumerate(wp)], h0, w0)
 
 
 class FISRnet:
@@ -78,7 +108,8 @@ class FISRnet:
                   "test_img_dir", "checkpoint_dir", "test_patch", "test_input_size", "frame_folder_path",
                   "FISR_input_size", "frame_num", "FISR_test_patch"):
             setattr(self, k, getattr(args, k, getattr(default_args(), k)))
-        self.precision = precision or getattr(args, "precision", "fp32")
+        self.precision = precision or getattr(args, "precision", DEFAULT_PRECISION)
+        self.batch_tiles = bool(getattr(args, "batch_tiles", True))
         if self.precision not in _PREC:
             raise ValueError(f"unknown precision {self.precision!r}")
         torch = _torch()
@@ -171,6 +202,10 @@ class FISRnet:
             outs = self.model(static_in, want_all=want_all)
         return graph, static_in, outs
 
+    def engine_description(self) -> str:
+        """One line for logs / bench.py: library version and the arithmetic of this engine."""
+        return f"{self._L.fisr_version().decode()} precision={self.precision}"
+
     # ------------------------------------------------------------------ profiling hooks
     def profile(self, on) -> None:
         """on: 0/False off, 1/True per kernel class, 2 per layer."""
@@ -209,7 +244,7 @@ class FISRnet:
         wp = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in warps]
         if len(fr) != 3 or len(fl) != 4 or len(wp) != 4:
             raise ValueError("pack_input needs 3 frames, 4 flows, 4 warps")
-        h0, w0 = fr[0].shape[:2]
+        fr, fl, wp, h0, w0 = fit_pack_inputs(fr, fl, wp, h, w)
         out = torch.empty((1, h, w, 29), dtype=torch.float32, device=self.device)
         a = (ctypes.c_void_p * 3)(*[f.data_ptr() for f in fr])
         b = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in fl])
@@ -247,7 +282,7 @@ class FISRnet:
 
     # ------------------------------------------------------------------ tiled forward (FISRnet.py:845-883)
     def forward_tiled(self, inp, num_patch: Tuple[int, int] = (2, 2), tiles: Optional[Sequence[int]] = None,
-                      full=None, timed: bool = False, batch_tiles: bool = True):
+                      full=None, timed: bool = False, batch_tiles: Optional[bool] = None):
         """inp [B,h,w,29] on the GPU (B windows of equal size) -> full prediction [B,h*2,w*2,9]
         float32 ([h*2,w*2,9] when B == 1; not clipped -- the clip of FISRnet.py:883 is applied by
         unpack_output / sse_vs_u8).  `tiles` restricts the work to a subset of tile indices
@@ -257,8 +292,12 @@ class FISRnet:
         independent, so equal-shaped tiles (all four in the default 2x2 plan) go through ONE
         batched forward here: bit-identical results, but every conv launch gets 4x (12x for a
         whole 5-frame stack) more workgroups, which is what fills 256 CUs on the deep, small
-        layers.  batch_tiles=False restores the one-tile-per-forward schedule."""
+        layers.  batch_tiles=False restores the one-tile-per-forward schedule (workspace ~5 KB per LR pixel
+        of ONE tile instead of all of them); it is also the automatic fall-back when the batched workspace
+        does not fit in free HBM (the reference tiles precisely because of limited memory)."""
         torch = _torch()
+        if batch_tiles is None:
+            batch_tiles = self.batch_tiles
         B, h, w, _ = inp.shape
         sf = self.scale_factor
         plan = [t for t in tiling.plan_tiles(h, w, tuple(num_patch), sf) if tiles is None or t.index in tiles]
@@ -269,12 +308,24 @@ class FISRnet:
         groups = {}
         for t in plan:
             groups.setdefault((t.in_h, t.in_w) if batch_tiles else t.index, []).append(t)
-        for grp in groups.values():
+        work = list(groups.values())
+        while work:
+            grp = work.pop(0)
             simg = torch.cat([inp[:, t.h_lo:t.h_hi, t.w_lo:t.w_hi, :] for t in grp], dim=0).contiguous()
             if timed:
                 torch.cuda.synchronize(self.device)
                 t0 = time.time()
-            _, _, pred = self.model(simg, sf, want_all=False)
+            try:
+                _, _, pred = self.model(simg, sf, want_all=False)
+            except torch.OutOfMemoryError:
+                if len(grp) == 1:
+                    raise
+                # workspace of the batched group does not fit: run its tiles one by one instead
+                del simg
+                self._ws = None
+                torch.cuda.empty_cache()
+                work = [[t] for t in grp] + work
+                continue
             if timed:
                 torch.cuda.synchronize(self.device)
                 self.inf_time.extend([(time.time() - t0) / (len(grp) * B)] * (len(grp) * B))

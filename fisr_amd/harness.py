@@ -113,6 +113,7 @@ def run_test(net):
     test_img_dir = os.path.join(net.test_img_dir, net.model_dir)
     os.makedirs(test_img_dir, exist_ok=True)
     fisr_psnr, sr_psnr, fisr_ssim, sr_ssim = [], [], [], []
+    fisr_psnr_y, sr_psnr_y = [], []
     net.inf_time = []
     start = time.time()
     n_scenes = len(data_paths) // n_test_in_seq
@@ -122,8 +123,7 @@ def run_test(net):
             full = net.forward_tiled(inp, num_patch, timed=True)
             yuv_u8, rgb_u8 = net.unpack_output(full)
             have_gt = len(label_paths) >= (scene_i + 1) * n_test_label_seq
-            psnr, ssim = [float("nan")] * 3, [float("nan")] * 3
-            yuv_host = yuv_u8.cpu().numpy()
+            psnr, ssim, psnr_y = [float("nan")] * 3, [float("nan")] * 3, [float("nan")] * 3
             for seq_i in range(n_gt_seq):
                 name = (os.path.basename(label_paths[scene_i * n_test_label_seq + sample_i * 2 + seq_i])[3:]
                         if have_gt else f"s{scene_i}_w{sample_i}_f{seq_i}.png")
@@ -132,6 +132,10 @@ def run_test(net):
                     gt_d = torch.from_numpy(np.ascontiguousarray(gt)).to(net.device)
                     sse = net.sse_vs_u8(full[:, :, 3 * seq_i:3 * seq_i + 3].contiguous(), gt_d)
                     psnr[seq_i] = _psnr_from_sse(sse, gt.size)
+                    # Y-only PSNR, for information (BASELINE.json's metric says "PSNR-Y"; the reference itself
+                    # scores the 3 YUV channels jointly, FISRnet.py:883-889)
+                    sse_y = net.sse_vs_u8(full[:, :, 3 * seq_i:3 * seq_i + 1].contiguous(), gt_d[:, :, 0:1].contiguous())
+                    psnr_y[seq_i] = _psnr_from_sse(sse_y, gt.size // 3)
                     # FISRnet.py:890-891: both sides as uint8(x*255) (GT: uint8 -> /255 -> *255 truncation)
                     # (x/255*255 truncates to x-1 for some x: done on the host exactly like the reference)
                     gt_q = (np.clip(gt.astype(np.float64) / 255., 0, 1) * 255).astype("uint8")
@@ -141,26 +145,60 @@ def run_test(net):
             print(" <Test> [%4d/%4d]-th image, scene: %2d-%d, time: %4.4f(minutes), test_PSNR: fr1 (FI-SR) %.8f[dB], "
                   "fr2 (SR) %.8f[dB], fr3 (FI-SR) %.8f[dB]  " % (scene_i * 3 + sample_i, n_scenes * 3, scene_i, sample_i,
                                                                  (time.time() - start) / 60, psnr[0], psnr[1], psnr[2]))
+            print(" ---- test_SSIM: fr1 (FI-SR) %.8f, fr2 (SR) %.8f, fr3 (FI-SR) %.8f  "
+                  % (ssim[0], ssim[1], ssim[2]))                  # FISRnet.py:897-899
             fisr_psnr.append(psnr[0]); sr_psnr.append(psnr[1])
             fisr_ssim.append(ssim[0]); sr_ssim.append(ssim[1])
+            fisr_psnr_y.append(psnr_y[0]); sr_psnr_y.append(psnr_y[1])
             if sample_i == 2:                                     # FISRnet.py:918-920
-                fisr_psnr.append(psnr[2]); fisr_ssim.append(ssim[2])
+                fisr_psnr.append(psnr[2]); fisr_ssim.append(ssim[2]); fisr_psnr_y.append(psnr_y[2])
     res = dict(FISR_PSNR=float(np.mean(fisr_psnr)), SR_PSNR=float(np.mean(sr_psnr)),
                FISR_SSIM=float(np.mean(fisr_ssim)), SR_SSIM=float(np.mean(sr_ssim)),
+               FISR_PSNR_Y=float(np.mean(fisr_psnr_y)), SR_PSNR_Y=float(np.mean(sr_psnr_y)),
                inference_time_per_frame=float(np.mean(net.inf_time)) * num_patch[0] * num_patch[1])
     print("######### Test (average) test_PSNR: FISR %.8f[dB], SR %.8f[dB]  #########" % (res["FISR_PSNR"], res["SR_PSNR"]))
     print("######### Test (average) test_SSIM: FISR %.8f, SR %.8f #########" % (res["FISR_SSIM"], res["SR_SSIM"]))
+    print("######### (extra) Y-channel-only test_PSNR: FISR %.8f[dB], SR %.8f[dB]  #########" % (res["FISR_PSNR_Y"], res["SR_PSNR_Y"]))
     print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % res["inference_time_per_frame"])
     return res
 
 
-def run_fisr_for_video(net, flow_file_name, warp_file_name):
+def _dist_state():
+    """(rank, world) of the torch.distributed default group, (0, 1) when not initialised."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def run_fisr_for_video(net, flow_file_name, warp_file_name, parallel=None):
     """`--phase FISR_for_video`: writes <frame_folder>/FISR_frames/pred_{k}.png (RGB) and
-    pred_YUV_{k}.png, k = 2*fr + seq_i, later windows overwrite earlier (FISRnet.py:1064-1077)."""
+    pred_YUV_{k}.png, k = 2*fr + seq_i, later windows overwrite earlier (FISRnet.py:1064-1077).
+
+    parallel (default: net.args.parallelism, else None) shards the work over the ranks of an initialised
+    torch.distributed job (one process per GPU):
+      "frame": window fr goes to rank fr % world (independent forwards, no data-path collective); a frame
+               that two windows produce is written by the later window only, which is the file the
+               reference's sequential overwrite leaves behind.
+      "tile":  the ranks form tile groups of num_patch[0]*num_patch[1] ranks (fisr_amd/dist.py); window fr
+               goes to group fr % n_groups; every rank packs only its core of the input, the 32-px halos
+               are all-gathered, each rank runs the forward of ITS tile, the trimmed uint8 tiles are
+               all-gathered and the group's first rank writes the PNGs."""
     import torch
+    from . import dist as fdist
     ok, _ = (True, 0) if net._finalized else net.load(net.checkpoint_dir)
     if not ok:
         raise FileNotFoundError(f"no checkpoint under {os.path.join(net.checkpoint_dir, net.model_dir)}")
+    if parallel is None:
+        parallel = getattr(net.args, "parallelism", None)
+    rank, world = _dist_state()
+    if parallel in (None, "none") or world == 1 and parallel == "frame":
+        parallel, rank, world = None, 0, 1
+    if parallel not in (None, "frame", "tile"):
+        raise ValueError(f"parallel must be None, 'frame' or 'tile', got {parallel!r}")
     paths = sorted_pngs(net.frame_folder_path)
     num_fr = net.frame_num
     out_dir = os.path.join(net.frame_folder_path, "FISR_frames")
@@ -177,22 +215,53 @@ def run_fisr_for_video(net, flow_file_name, warp_file_name):
     net.inf_time = []
     start = time.time()
     written = []
-    for fr in range(num_fr - 2):
-        h, w = tiling.crop_hw(H, W, num_patch)
+    n_win = num_fr - 2
+    topo = grp = None
+    if parallel == "tile":
+        topo = fdist.TileTopology(num_patch, world, rank)
+        grp = topo.make_group()
+        my_windows = [fr for fr in range(n_win) if fr % topo.n_groups == topo.group_index]
+        writer = topo.tile == 0
+    elif parallel == "frame":
+        my_windows = fdist.shard_units(n_win, world, rank)
+        writer = True
+    else:
+        my_windows = list(range(n_win))
+        writer = True
+    h, w = tiling.crop_hw(H, W, num_patch)
+    for fr in my_windows:
         frames = [torch.from_numpy(fio.read_png(paths[fr + k])).to(net.device) for k in range(3)]
         flows = [torch.from_numpy(np.ascontiguousarray(flow[fr, k])).to(net.device) for k in range(4)]
         warps = [torch.from_numpy(np.ascontiguousarray(warp[fr, k])).to(net.device) for k in range(4)]
-        inp = net.pack_input(frames, flows, warps, h, w)
-        full = net.forward_tiled(inp, num_patch, timed=True)
-        yuv_u8, rgb_u8 = net.unpack_output(full)
-        yuv_host = yuv_u8.cpu().numpy()
-        for seq_i in range(3):
-            k = str(fr * 2 + seq_i).zfill(digits)
-            fio.write_png(os.path.join(out_dir, f"pred_{k}.png"), rgb_u8[seq_i].cpu().numpy())
-            fio.write_png(os.path.join(out_dir, f"pred_YUV_{k}.png"), yuv_host[:, :, 3 * seq_i:3 * seq_i + 3])
-            written.append(k)
+        if parallel == "tile":
+            torch.cuda.synchronize(net.device)
+            t0 = time.time()
+            core = fdist.pack_core(net, frames, flows, warps, h, w, num_patch, topo.tile)
+            yuv_b, rgb_b = fdist.tile_parallel_engine_window(net, core, num_patch, group=grp, want_rgb=True)
+            yuv_u8, rgb_u8 = yuv_b[0], rgb_b[0]
+            torch.cuda.synchronize(net.device)
+            # the reference's figure is (mean time of one tile forward) x tiles: here the tiles run
+            # concurrently, so the whole window took `dt` = one tile's time
+            net.inf_time.append(time.time() - t0)
+        else:
+            inp = net.pack_input(frames, flows, warps, h, w)
+            full = net.forward_tiled(inp, num_patch, timed=True)
+            yuv_u8, rgb_u8 = net.unpack_output(full)
+        if writer:
+            yuv_host = yuv_u8.cpu().numpy()
+            for seq_i in range(3):
+                if parallel is not None and seq_i == 2 and fr != n_win - 1:
+                    continue        # frame 2fr+2 is also frame 0 of window fr+1, whose file the reference keeps
+                k = str(fr * 2 + seq_i).zfill(digits)
+                fio.write_png(os.path.join(out_dir, f"pred_{k}.png"), rgb_u8[seq_i].cpu().numpy())
+                fio.write_png(os.path.join(out_dir, f"pred_YUV_{k}.png"), yuv_host[:, :, 3 * seq_i:3 * seq_i + 3])
+                written.append(k)
         print(" <FISR processing> [%4d/%4d]-th input multiple data sample (stride1), time: %4.4f(minutes)  "
               % (fr + 1, num_fr - 2, (time.time() - start) / 60))
-    per_frame = float(np.mean(net.inf_time)) * num_patch[0] * num_patch[1]
+    tiles_serial = 1 if parallel == "tile" else num_patch[0] * num_patch[1]
+    per_frame = float(np.mean(net.inf_time)) * tiles_serial if net.inf_time else float("nan")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % per_frame)
     return dict(frames=sorted(set(written)), out_dir=out_dir, inference_time_per_frame=per_frame)

@@ -11,13 +11,18 @@ Differences from the reference, all deliberate:
   * `--phase train` is out of scope (inference-only build) and exits with an error.
   * `--phase FISR_for_video` needs a pre-computed flow file (`--flow_file`): the PWC-Net flow
     estimator (main.py:210) is a "next" row; the frame warp (main.py:213) runs on the GPU.
-  * extra flags: `--precision {fp32,bf16x3,fp16}`, `--device`, `--synthetic_weights SEED`.
+  * extra flags: `--precision {fp32,bf16x3,f16f8,fp16}` (default fp32, the reference's arithmetic),
+    `--device`, `--synthetic_weights SEED`, `--no_batch_tiles` (one tile per forward, the reference's
+    schedule: smallest workspace).
 """
 from __future__ import annotations
 
 import argparse
 import os
 import sys
+
+
+from .fisrnet import DEFAULT_PRECISION, PRECISIONS
 
 
 def _tuple2(s):
@@ -57,8 +62,15 @@ def parse_args(argv=None):
     p.add_argument("--frame_num", type=int, default=5)
     p.add_argument("--FISR_test_patch", type=_tuple2, default=(2, 2))
     # build-specific
-    p.add_argument("--precision", type=str, default="bf16x3", choices=["fp32", "bf16x3", "f16f8", "fp16"])
-    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--precision", type=str, default=DEFAULT_PRECISION, choices=sorted(PRECISIONS))
+    p.add_argument("--no_batch_tiles", dest="batch_tiles", action="store_false",
+                   help="run the tiles of a window one forward at a time (reference schedule, smallest workspace)")
+    p.add_argument("--device", type=str, default=None, help="default cuda:<LOCAL_RANK>")
+    p.add_argument("--parallelism", type=str, default="none", choices=["none", "frame", "tile"],
+                   help="FISR_for_video under `python -m torch.distributed.run --nproc-per-node N -m fisr_amd.main ...`: "
+                        "'frame' = windows round-robin over the GPUs; 'tile' = the test_patch tiles of a window on "
+                        "different GPUs with an RCCL all-gather of the 32-px halos and of the uint8 output tiles "
+                        "(N must be a multiple of the tile count: 8 GPUs = 2 windows x 2x2 tiles)")
     p.add_argument("--flow_file", type=str, default=None, help="pre-computed 5-D .flo for FISR_for_video")
     p.add_argument("--warp_file", type=str, default=None, help="pre-computed warp (.mat/.npy); default: warp on the GPU")
     p.add_argument("--synthetic_weights", type=int, default=None, metavar="SEED",
@@ -83,6 +95,23 @@ def main(argv=None):
     from . import harness, weights
     from .fisrnet import FISRnet
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device is None:
+        args.device = f"cuda:{local_rank}"
+    if world > 1:
+        # one process per GPU; backend "nccl" is RCCL over xGMI on ROCm (FISR_DIST_BACKEND=gloo for CPU-staged tests)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(torch.device(args.device))
+        backend = os.environ.get("FISR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(args.device))
+        else:
+            dist.init_process_group(backend)
+        if args.parallelism == "none":
+            args.parallelism = "frame"
     net = FISRnet(args)
     if args.synthetic_weights is not None:
         net.set_weights(weights.synthetic_weights(args.synthetic_weights))

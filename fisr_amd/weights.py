@@ -155,16 +155,21 @@ def find_checkpoint(checkpoint_dir: str, model_dir: str):
                 return prefix, "tf_bundle", step
             if os.path.isfile(prefix + ".npz"):
                 return prefix + ".npz", "npz", step
-    cands = sorted(f for f in os.listdir(d) if f.endswith(".npz"))
-    if cands:
-        name = cands[-1]
-        m = list(re.finditer(r"(\d+)(?!.*\d)", name[:-4]))
-        return os.path.join(d, name), "npz", int(m[0].group(0)) if m else 0
-    idx = sorted(f for f in os.listdir(d) if f.endswith(".index"))
-    if idx:
-        name = idx[-1][:-6]
-        m = list(re.finditer(r"(\d+)(?!.*\d)", name))
-        return os.path.join(d, name), "tf_bundle", int(m[0].group(0)) if m else 0
+    # No usable `checkpoint` state file.  The reference's load() returns False here (FISRnet.py:1113-1115);
+    # as a convenience the newest container in the directory is used instead -- by training step (natural
+    # order: FISRnet-10 after FISRnet-9), and loudly.
+    def step_of(stem):
+        m = list(re.finditer(r"(\d+)(?!.*\d)", stem))
+        return int(m[0].group(0)) if m else 0
+
+    for suffix, kind in ((".npz", "npz"), (".index", "tf_bundle")):
+        cands = sorted((f for f in os.listdir(d) if f.endswith(suffix)),
+                       key=lambda f: (step_of(f[:-len(suffix)]), f))
+        if cands:
+            name = cands[-1]
+            stem = name[:-len(suffix)]
+            print(f" [!] no 'checkpoint' state file in {d}: falling back to the highest step found, {name}")
+            return os.path.join(d, name if kind == "npz" else stem), kind, step_of(stem)
     return None, None, 0
 
 

@@ -34,7 +34,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
     if not pmc:
         print(f"\n## kernel trace stats ({rel}); durations from the GPU timestamps of each dispatch")
         print(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
-        for n, c, s, a, mn, mx in rows[:16]:
+        for n, c, s, a, mn, mx in rows:              # every kernel: warp / maxpool rows must not be cut
             print(f"{short(n):72s} {c:6d} {s / 1e6:10.3f} {a / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * s / tot:6.2f}")
     else:
         print(f"\n## counters ({rel})")
@@ -42,7 +42,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         for n, cn, c, s in pmc:
             agg[short(n)][cn] = (c, s)
         dur = {short(r[0]): (r[1], r[2]) for r in rows}
-        for k in sorted(agg, key=lambda k: -dur.get(k, (0, 0))[1])[:6]:
+        for k in sorted(agg, key=lambda k: -dur.get(k, (0, 0))[1]):
             print(f"{k}  dispatches {dur.get(k, (0, 0))[0]}  total_ms {dur.get(k, (0, 0))[1] / 1e6:.3f}")
             for cn, (c, s) in sorted(agg[k].items()):
                 print(f"    {cn:30s} sum {s:.6g}   per_dispatch {s / max(c, 1):.6g}")
@@ -62,6 +62,16 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         continue
     for n, cn, c, s in rows:
         traffic.setdefault(short(n), {})[cn] = {"dispatches": c, "kib_per_dispatch": s / max(c, 1)}
+durations = {}   # average dispatch duration (ns) per kernel, from the kernel-trace pass (no counters attached)
+for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+    cur = sqlite3.connect(f).cursor()
+    try:
+        if list(cur.execute("select count(*) from pmc_events"))[0][0]:
+            continue
+        for n, c, a in cur.execute("select name, count(*), avg(duration) from kernels group by name"):
+            durations[short(n)] = (c, a)
+    except sqlite3.Error:
+        continue
 out = {}
 for k, d in traffic.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
@@ -70,6 +80,10 @@ for k, d in traffic.items():
                   "write_bytes_per_launch": d["WRITE_SIZE"]["kib_per_dispatch"] * 1024,
                   "hbm_bytes_per_launch": d["FETCH_SIZE"]["kib_per_dispatch"] * 2048 + d["WRITE_SIZE"]["kib_per_dispatch"] * 1024,
                   "dispatches": d["FETCH_SIZE"]["dispatches"]}
+        if k in durations:
+            out[k]["avg_duration_us_trace_pass"] = durations[k][1] / 1e3
+            out[k]["hbm_gbps"] = out[k]["hbm_bytes_per_launch"] / durations[k][1]
+            out[k]["frac_of_8tbps"] = out[k]["hbm_gbps"] / 8000.0
 if out:
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)

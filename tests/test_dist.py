@@ -43,25 +43,35 @@ def _worker(rank, world, port, num_patch, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = torch.Generator().manual_seed(7)
+        # world may hold several tile groups (8 ranks = 2 windows x (2,2) tiles): every group works on its
+        # own window, the collectives stay inside the group
+        topo = fdist.TileTopology(num_patch, world, rank)
+        grp = topo.make_group()
+        g = torch.Generator().manual_seed(7 + topo.group_index)
         h, w = 64 * num_patch[0], 96 * num_patch[1]
         inp = torch.rand((1, h, w, 29), generator=g)
-        nh, nw = num_patch
-        sH, sW = h // nh, w // nw
-        pH, pW = rank // nw, rank % nw
-        core = inp[0, pH * sH:(pH + 1) * sH, pW * sW:(pW + 1) * sW].contiguous()
+        y0, y1, x0, x1 = fdist.core_region(h, w, num_patch, topo.tile)
+        core = inp[0, y0:y1, x0:x1].contiguous()
         # 1. halo exchange reproduces the reference's input slice
-        tile_in = fdist.exchange_halos(core, num_patch)
-        t = tiling.plan_tiles(h, w, num_patch)[rank]
+        tile_in = fdist.exchange_halos(core, num_patch, grp)
+        t = tiling.plan_tiles(h, w, num_patch)[topo.tile]
         ok_halo = torch.equal(tile_in, inp[0, t.h_lo:t.h_hi, t.w_lo:t.w_hi])
         # 2. the whole tile-parallel window equals the single-process tile loop
-        frame = fdist.tile_parallel_window(core, num_patch, _fake_forward)
+        frame = fdist.tile_parallel_window(core, num_patch, _fake_forward, group=grp)
         ok_frame = torch.equal(frame, _reference_frame(inp, num_patch))
+        # 2b. a batch of windows (a 5-frame stack = 3 windows) through ONE pair of collectives
+        inp3 = torch.rand((3, h, w, 29), generator=g)
+        frames3 = fdist.tile_parallel_window(inp3[:, y0:y1, x0:x1].contiguous(), num_patch, _fake_forward, group=grp)
+        ok_frame = ok_frame and all(torch.equal(frames3[b], _reference_frame(inp3[b:b + 1], num_patch)) for b in range(3))
         # 3. frame-parallel sharding covers every unit exactly once
         units = fdist.shard_units(7, world, rank)
         gathered = [None] * world
         dist.all_gather_object(gathered, units)
         ok_units = sorted(sum(gathered, [])) == list(range(7))
+        # 3b. frame-parallel output collection (cfg4: gather of the uint8 frames to rank 0)
+        mine = torch.full((2, 3), rank, dtype=torch.uint8)
+        got = fdist.gather_to(mine, dst=0)
+        ok_units = ok_units and ((got is None) if rank else (got.shape == (world, 2, 3) and got[:, 0, 0].tolist() == list(range(world))))
         # 4. max-over-ranks timing reduction used by bench.py
         tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -70,9 +80,10 @@ def _worker(rank, world, port, num_patch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_patch", [(1, 2), (2, 2)])
-def test_tile_parallel_gloo(num_patch):
-    world = num_patch[0] * num_patch[1]
+@pytest.mark.parametrize("num_patch,groups", [((1, 2), 1), ((2, 2), 1), ((2, 2), 2), ((2, 4), 1)])
+def test_tile_parallel_gloo(num_patch, groups):
+    """(2,2) x 2 groups and (2,4) x 1 group are the two 8-GPU plans of one node."""
+    world = num_patch[0] * num_patch[1] * groups
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -95,3 +106,8 @@ def test_shard_units_and_errors():
         fdist.shard_units(4, 2, 2)
     with pytest.raises(ValueError):
         fdist.tile_of_rank((2, 2), 2, 0)
+    assert fdist.tile_of_rank((2, 2), 8, 6) == 2
+    t = fdist.TileTopology((2, 2), 8, 6)
+    assert (t.n_groups, t.group_index, t.tile, t.pH, t.pW, t.group_ranks) == (2, 1, 2, 1, 0, [4, 5, 6, 7])
+    assert fdist.core_region(1024, 1920, (2, 2), 3) == (512, 1024, 960, 1920)
+    assert fdist.core_region(1024, 1920, (2, 4), 5) == (512, 1024, 480, 960)

@@ -118,3 +118,57 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "fisr.h"\nint main(void) { fisr_ctx* c = 0; (void)c; return FISR_OK; }\n')
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                            "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_pack_input_shape_contract():
+    """pack_input indexes all 11 tensors with frame 0's row stride, so mismatched inputs must
+    be cropped to a common size or rejected -- never read with the wrong stride (reference: independent
+    [:h,:w] slices, FISRnet.py:828-843)."""
+    torch = pytest.importorskip("torch")
+    from fisr_amd.fisrnet import fit_pack_inputs
+    z = lambda h, w, c, dt=torch.float32: torch.zeros((h, w, c), dtype=dt)
+    fr = [z(40, 64, 3, torch.uint8) for _ in range(3)]
+    fl = [z(40, 64, 2) for _ in range(4)]
+    wp = [z(40, 64, 3) for _ in range(4)]
+    a, b, c, h0, w0 = fit_pack_inputs(fr, fl, wp, 32, 64)
+    assert (h0, w0) == (40, 64) and all(t.shape[:2] == (40, 64) for t in a + b + c)
+    # larger flow / warp arrays (different padding of the .flo / .mat) are cropped to frame 0's size
+    fl2 = [z(48, 80, 2) for _ in range(4)]
+    fl2[0][:40, :64, 0] = 7.0
+    _, b2, _, _, _ = fit_pack_inputs(fr, fl2, wp, 32, 64)
+    assert all(t.shape == (40, 64, 2) and t.is_contiguous() for t in b2) and float(b2[0][39, 63, 0]) == 7.0
+    with pytest.raises(ValueError, match="smaller"):          # a warp smaller than the crop
+        fit_pack_inputs(fr, fl, [z(24, 64, 3)] + wp[1:], 32, 64)
+    with pytest.raises(ValueError, match="common size"):      # covers the crop but not frame 0
+        fit_pack_inputs(fr, fl, [z(36, 64, 3)] + wp[1:], 32, 64)
+    with pytest.raises(ValueError, match=r"\[h,w,2\]"):        # wrong channel count
+        fit_pack_inputs(fr, [z(40, 64, 3)] + fl[1:], wp, 32, 64)
+    with pytest.raises(ValueError, match="exceeds"):
+        fit_pack_inputs(fr, fl, wp, 64, 64)
+    with pytest.raises(ValueError):                           # frames 1-2 must match frame 0 as well
+        fit_pack_inputs([fr[0], z(32, 64, 3, torch.uint8), fr[2]], fl, wp, 32, 64)
+
+
+def test_checkpoint_fallback_sorts_by_step(tmp_path, syn_weights, capsys):
+    """Without a `checkpoint` state file the highest training step wins (natural order: 10 after 9)."""
+    d = tmp_path / "ckpt" / "FISRnet_exp1"
+    d.mkdir(parents=True)
+    small = {k: v for k, v in list(syn_weights.items())[:2]}
+    for step in (9, 10, 2):
+        weights.save_npz(str(d / f"FISRnet-{step}.npz"), small)
+    path, kind, step = weights.find_checkpoint(str(tmp_path / "ckpt"), "FISRnet_exp1")
+    assert (os.path.basename(path), kind, step) == ("FISRnet-10.npz", "npz", 10)
+    assert "falling back" in capsys.readouterr().out
+    # with a state file the named checkpoint wins, silently
+    (d / "checkpoint").write_text('model_checkpoint_path: "FISRnet-9"\n')
+    path, kind, step = weights.find_checkpoint(str(tmp_path / "ckpt"), "FISRnet_exp1")
+    assert (os.path.basename(path), step) == ("FISRnet-9.npz", 9)
+    assert "falling back" not in capsys.readouterr().out
+
+
+def test_one_default_precision_everywhere():
+    from fisr_amd import fisrnet, main
+    assert fisrnet.default_args().precision == fisrnet.DEFAULT_PRECISION == "fp32"
+    assert main.parse_args(["--phase", "test"]).precision == fisrnet.DEFAULT_PRECISION
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'ap.add_argument("--precision", default="fp32"' in src

@@ -218,3 +218,18 @@ def test_remap_exact_mode_vs_scipy_map_coordinates():
     q = O.remap_linear_replicate(src, mapx, mapy, quantized=True)
     # quantising coordinates to 1/32 px moves a sample by at most 1/64 px in x and y
     assert np.abs(q - mine).max() <= 255 * (1 / 64) * 2 + 1e-9
+
+
+def test_torch_cpu_twin_matches_numpy_oracle(syn_weights):
+    """oracle/torch_cpu.py (the oneDNN CPU baseline of bench.py) is the same graph as the numpy oracle:
+    float64 agreement to rounding on all three levels (conv/pool through torch's CPU kernels, the TF-specific
+    resize / depth_to_space / strided sub-sampling restated by hand in both)."""
+    torch = pytest.importorskip("torch")
+    import torch_cpu as T
+    x = np.random.default_rng(11).random((2, 32, 64, 29)).astype(np.float32)
+    x[..., 9:17] = (x[..., 9:17] - 0.5) * 0.4
+    ref = O.model(x, syn_weights)
+    got = T.forward(x, T.prepare_weights(syn_weights, torch.float64))
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() < 1e-12
