@@ -45,10 +45,10 @@ import numpy as np
 FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 2 644 164 MAC)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md (spec; ~6300 achievable with a float4 copy)
 # dense MFMA peak of the instruction class each engine issues (MI355X_MICROARCH.md), TFLOP/s
-PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}
+PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}
 # matrix-pipe work per algorithmic product (direct 3x3): Winograd F(2x2,3x3) issues 16/36 of the multiplies
-MFMA_PER_PRODUCT = {"fp32": None, "fp32d": 1, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
-DTYPE = {"fp32": "f32", "fp32d": "f32",
+MFMA_PER_PRODUCT = {"fp32": 1, "fp32d": 1, "fp32w": None, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
+DTYPE = {"fp32": "f32", "fp32d": "f32", "fp32w": "f32",
          "fp16": "f16 (f32 accumulate)",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
          "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)"}
@@ -372,26 +372,32 @@ def cpu_baselines(W, wl):
     try:
         import torch
         import torch_cpu
-        nthr = os.cpu_count() or 1
-        try:
-            nthr = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            pass
-        torch.set_num_threads(nthr)
+        # torch's own default intra-op thread count (physical cores visible to the process); forcing the SMT
+        # thread count oversubscribes the box and is several times slower
         Wt = torch_cpu.prepare_weights(W)
         torch_cpu.forward(x[:, :96, :96], Wt)                       # warm-up (primitive creation)
-        ts = []
-        t_all = time.perf_counter()
-        while len(ts) < 3 and (not ts or time.perf_counter() - t_all < 25.0):
-            t0 = time.perf_counter()
-            torch_cpu.forward(x, Wt)
-            ts.append(time.perf_counter() - t0)
-        dt = float(np.median(ts))
-        onednn = {"value": round(UNIQUE_PER_STACK / (dt * tiles_per_stack), 5), "unit": "frames/s",
+        qh, qw = ch // 2, cw // 2
+        t0 = time.perf_counter()
+        torch_cpu.forward(x[:, :qh, :qw], Wt)                       # quarter tile: estimate before committing
+        dq = time.perf_counter() - t0
+        if dq * 4 <= 20.0:
+            sh, sw, ts = ch, cw, []
+            t_all = time.perf_counter()
+            while len(ts) < 3 and (not ts or time.perf_counter() - t_all + ts[-1] < 25.0):
+                t0 = time.perf_counter()
+                torch_cpu.forward(x, Wt)
+                ts.append(time.perf_counter() - t0)
+            dt = float(np.median(ts))
+            what = f"median of {len(ts)}x one full {ch}x{cw}x29 tile"
+        else:
+            sh, sw, dt = qh, qw, dq
+            what = f"1x one {qh}x{qw}x29 quarter tile (a full tile would exceed the bench's CPU budget)"
+        s_flop = sh * sw * FLOP_PER_LR_PX
+        onednn = {"value": round(UNIQUE_PER_STACK / (wl.flop_per_stack / (s_flop / dt)), 5), "unit": "frames/s",
                   "cores": int(torch.get_num_threads()), "kind": "port", "cpu_model": cpu_model,
-                  "sample": f"median of {len(ts)}x one full {ch}x{cw}x29 tile through oracle/torch_cpu.py (torch "
-                            f"{torch.__version__} CPU, oneDNN, fp32, channels-last, {dt:.2f} s, "
-                            f"{tile_flop / dt / 1e9:.1f} GFLOP/s), x{tiles_per_stack:.0f} tiles per 1080p stack"}
+                  "sample": f"{what} through oracle/torch_cpu.py (torch {torch.__version__} CPU, oneDNN, fp32, "
+                            f"channels-last, {dt:.2f} s, {s_flop / dt / 1e9:.1f} GFLOP/s), extrapolated by FLOPs to the "
+                            f"{tiles_per_stack:.0f} tiles of a 1080p stack"}
     except Exception as e:                                          # noqa: BLE001 -- a baseline must not kill the bench line
         onednn = {"error": repr(e)}
     return port, onednn

@@ -18,6 +18,7 @@
 
 #include "../../include/fisr.h"
 #include "conv3x3.h"
+#include "conv3x3_wino.h"
 #include "glue_kernels.h"
 
 using namespace fisr;
@@ -35,6 +36,7 @@ struct ConvW {
   float* d_b = nullptr;
   int cin_pad = 0, cout_pad = 0, nt = 2;
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
+  void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino.h), else NULL
 };
 
 struct ProfEntry {
@@ -48,6 +50,7 @@ struct ProfEntry {
 struct fisr_ctx {
   int dev = 0;
   int precision = -1;
+  bool wino = false;      // FISR_PREC_F32W: eligible convs run the Winograd F(2x2,3x3) kernel
   bool finalized = false;
   std::map<std::string, ConvW> convs;  // keyed by conv name (without /w, /b)
   std::string err;
@@ -160,14 +163,14 @@ template <> struct PrecName<fsplit> { static const char* get() { return "f16f8";
 // call f(T()) with the activation type of `precision`
 template <typename F>
 auto with_prec(int precision, F&& f) {
-  if (precision == FISR_PREC_F32) return f(float());
+  if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W) return f(float());
   if (precision == FISR_PREC_F16) return f(_Float16());
   if (precision == FISR_PREC_F16F8) return f(fsplit());
   return f(bsplit());
 }
 inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
-         precision == FISR_PREC_F16F8;
+         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W;
 }
 inline bool prec_grouped16(int precision) { return precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8; }
 
@@ -187,7 +190,7 @@ inline uint8_t host_fp8_e4m3(float f) {
   return sign | (uint8_t)(((ex + 7) << 3) | ((int)r - 8));
 }
 inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 ? 32 : 16; }
-inline int prec_unit(int precision) { return precision == FISR_PREC_F32 ? 4 : 8; }   // glue kernels: channels per 16 bytes
+inline int prec_unit(int precision) { return precision == FISR_PREC_F32 || precision == FISR_PREC_F32W ? 4 : 8; }   // glue kernels: channels per 16 bytes
 constexpr int CONV_REC = 16;   // the conv kernel stores whole 16-channel records
 
 // host bf16 round-to-nearest-even (finite inputs)
@@ -246,6 +249,35 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
   for (int n = 0; n < co; ++n) bp[n] = b[n];
 }
 
+// Winograd F(2x2,3x3) weights: U = G g G^T per (ci, co), computed in double and rounded once to fp32, stored as
+// the kernel's LDS image (conv3x3_wino.h): [Cin/8][Cout/64][position 16][row 64][32-byte record], the two 16-byte
+// halves of a record swapped when bit 3 of the row is set; rows in the MFMA row order of pack_weights.
+inline bool wino_eligible(int ci, int co) { (void)ci; return co >= W_BN && co % W_BN == 0; }
+void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int nb = co / W_BN, nch = cin_pad / W_CH;
+  wp.assign((size_t)nch * nb * W_SLAB, 0);
+  for (int c = 0; c < ci; ++c)
+    for (int n = 0; n < co; ++n) {
+      double g[3][3], t[4][3], u[4][4];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) g[a][b] = w[((size_t)(a * 3 + b) * ci + c) * co + n];
+      for (int i = 0; i < 4; ++i)
+        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) u[i][j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+      const int kc = c / W_CH, cc = c % W_CH, h = cc >> 2, e = cc & 3;
+      const int blk = n / W_BN, nl = n % W_BN;
+      const int wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+      const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+      char* slab = wp.data() + ((size_t)kc * nb + blk) * W_SLAB;
+      for (int pos = 0; pos < 16; ++pos) {
+        float* rec = reinterpret_cast<float*>(slab + ((size_t)pos * 64 + row) * W_REC + ((h ^ ((row >> 3) & 1)) * 16));
+        rec[e] = (float)u[pos >> 2][pos & 3];
+      }
+    }
+}
+
 // N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16,
 // always fp32 output; FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
@@ -255,7 +287,7 @@ template <typename T> inline int nt_for(int co) {
 }
 
 template <typename T>
-int upload_conv(fisr_ctx* ctx, ConvW& cw) {
+int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false) {
   constexpr int CC = Prec<T>::CC;
   cw.nt = nt_for<T>(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
@@ -276,6 +308,12 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw) {
   HIP_OK(ctx, hipMalloc((void**)&cw.d_b, bp.size() * sizeof(float)));
   HIP_OK(ctx, hipMemcpy(cw.d_w, wp.data(), wp.size(), hipMemcpyHostToDevice));
   HIP_OK(ctx, hipMemcpy(cw.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (cw.d_wu) { (void)hipFree(cw.d_wu); cw.d_wu = nullptr; }
+  if (wino && std::is_same<T, float>::value && wino_eligible(cw.ci, cw.co)) {
+    pack_weights_wino(cw.w.data(), cw.ci, cw.co, cw.cin_pad, wp);
+    HIP_OK(ctx, hipMalloc(&cw.d_wu, wp.size()));
+    HIP_OK(ctx, hipMemcpy(cw.d_wu, wp.data(), wp.size(), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -305,6 +343,27 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles * (a.CoutPad / (NT == 0 ? 16 : 32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
   hipLaunchKernelGGL(kern, grid, dim3(64 * (TILE_H / MR)), lds, st, a);
+  return hipGetLastError();
+}
+
+// Winograd kernel (fp32 only; a.wpk = the conv's d_wu).  FISR_WINO_GLDS=0 stages the U slab through registers.
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
+  static const bool glds = [] { const char* e = getenv("FISR_WINO_GLDS"); return !(e && e[0] == '0'); }();
+  static bool attr_done[64][2] = {};
+  constexpr size_t lds = wino_lds_bytes();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const void* kern = glds ? reinterpret_cast<const void*>(conv3x3_wino_kernel<true>)
+                          : reinterpret_cast<const void*>(conv3x3_wino_kernel<false>);
+  if (dev < 0 || dev >= 64 || !attr_done[dev][glds]) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_done[dev][glds] = true;
+  }
+  const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
+  dim3 grid(tiles * (a.CoutPad / W_BN));
+  if (glds) hipLaunchKernelGGL(conv3x3_wino_kernel<true>, grid, dim3(256), lds, st, a);
+  else      hipLaunchKernelGGL(conv3x3_wino_kernel<false>, grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -450,8 +509,11 @@ struct Runner {
     a.out_cstride = cstride ? cstride : cw.co;
     a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr; a.wexp = cw.wexp;
     const double px = (double)n * h * w;
+    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32;
+    if (use_wino) a.wpk = cw.d_wu;
     char cls[96];
-    snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
+    if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino<f32w,F2x2>");
+    else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
     std::string cname(cls);
     if (ctx->prof_mode == 2) {
       char shp[64];
@@ -460,7 +522,7 @@ struct Runner {
     }
     ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
                  px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
-    check(launch_conv<T>(a, cw.nt, out_f32, st), name.c_str());
+    check(use_wino ? launch_conv_wino(a, st) : launch_conv<T>(a, cw.nt, out_f32, st), name.c_str());
   }
 
   // ops.py:39-44 res_block, in place on X with scratch A.
@@ -594,7 +656,7 @@ size_t ws_bytes_t(fisr_ctx* ctx, int n, int h, int w) {
 
 extern "C" {
 
-const char* fisr_version(void) { return "fisr_hip 0.1 (gfx950)"; }
+const char* fisr_version(void) { return "fisr_hip 0.2 (gfx950)"; }
 
 const char* fisr_last_error(const fisr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -625,6 +687,7 @@ void fisr_destroy(fisr_ctx* ctx) {
   for (auto& kv : ctx->convs) {
     if (kv.second.d_w) (void)hipFree(kv.second.d_w);
     if (kv.second.d_b) (void)hipFree(kv.second.d_b);
+    if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
   }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
@@ -676,9 +739,10 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   DeviceGuard guard(ctx->dev);
   HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
-    int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second); });
+    int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, precision == FISR_PREC_F32W); });
     if (rc) return rc;
   }
+  ctx->wino = precision == FISR_PREC_F32W;
   ctx->precision = precision;
   ctx->finalized = true;
   return 0;
@@ -849,7 +913,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   const int cc = prec_chunk(precision);
   if (cout % CONV_REC) {
     // partial 16-channel records only exist on the fp32-output heads (channel-scatter store, no residual)
-    if (precision == FISR_PREC_F32) out_f32 = 1;
+    if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W) out_f32 = 1;
     if (!out_f32) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: cout must be a multiple of 16 unless out_f32");
   }
   if (out_f32 && (res || (flags & FISR_CONV_D2S)))
@@ -863,10 +927,11 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
   cw.b.assign(b_host, b_host + cout);
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32;
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
+  a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
@@ -874,10 +939,12 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
+  hipError_t e = use_wino ? launch_conv_wino(a, st)
+                          : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
   hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(cw.d_w);
   (void)hipFree(cw.d_b);
+  if (cw.d_wu) (void)hipFree(cw.d_wu);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv sync: ") + hipGetErrorString(e2));
   return 0;
@@ -932,8 +999,9 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   uint32_t st = 12345u;
   const bool zero_fill = getenv("FISR_BENCH_ZERO") != nullptr;   // DVFS probe: zero operands draw less power
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu;
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
   HIP_OK(nullptr, hipMalloc(&d_out, out_b));
@@ -952,7 +1020,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
         HIP_OK(nullptr, hipMemcpy((char*)d_res + o, hbuf.data(), std::min(hbuf.size() * 2, out_b - o), hipMemcpyHostToDevice));
   }
   ConvArgs a;
-  a.in0 = d_in; a.in1 = nullptr; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = d_res; a.out = d_out;
+  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = d_res; a.out = d_out;
   a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
@@ -961,7 +1029,8 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   const char* trace_file = getenv("FISR_TRACE_FILE");
   unsigned long long* d_trace = nullptr;
-  const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) * (cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
+  const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
+                         (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
   if (trace_file) {
     HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 64));
     HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 64));
@@ -971,12 +1040,14 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   HIP_OK(nullptr, hipEventCreate(&e0));
   HIP_OK(nullptr, hipEventCreate(&e1));
   hipError_t e = hipSuccess;
-  for (int i = 0; i < 2 && e == hipSuccess; ++i)
-    e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
+  auto launch = [&]() -> hipError_t {
+    if (use_wino) return launch_conv_wino(a, nullptr);
+    return with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
+  };
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = launch();
   HIP_OK(nullptr, hipDeviceSynchronize());
   HIP_OK(nullptr, hipEventRecord(e0, nullptr));
-  for (int i = 0; i < iters && e == hipSuccess; ++i)
-    e = with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
+  for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch();
   HIP_OK(nullptr, hipEventRecord(e1, nullptr));
   HIP_OK(nullptr, hipEventSynchronize(e1));
   float ms = 0.f;
@@ -990,7 +1061,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
-  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b);
+  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
   return 0;
 }

@@ -29,6 +29,7 @@ from . import weights as _weights
 from .lib import FisrError
 
 _PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32, "fp32d": _lib.PREC_F32,
+         "fp32w": _lib.PREC_F32W,
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
          "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8}
 
@@ -36,7 +37,7 @@ _PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32, 
 # ONE default arithmetic for every entry point (FISRnet(), main.py, bench.py): the reference computes in
 # fp32 (cfg2 of BASELINE.json), so the default is the fp32 engine; the split-precision modes are opt-in.
 DEFAULT_PRECISION = "fp32"
-PRECISIONS = ("fp32", "bf16x3", "f16f8", "fp16")     # CLI names
+PRECISIONS = ("fp32", "fp32w", "fp32d", "bf16x3", "f16f8", "fp16")     # CLI names
 
 
 def _torch():
@@ -113,7 +114,7 @@ class FISRnet:
         if self.precision not in _PREC:
             raise ValueError(f"unknown precision {self.precision!r}")
         torch = _torch()
-        self.device = torch.device(device or getattr(args, "device", "cuda:0"))
+        self.device = torch.device(device or getattr(args, "device", None) or "cuda:0")
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise FisrError("FISRnet needs a ROCm GPU (cuda device); there is no CPU fallback")
         self._L = _lib.lib()

@@ -49,6 +49,12 @@ enum {
                           accumulate: fp32-grade results at 16/3 x the fp32 MFMA rate.  Activation
                           tensors use the split layout: per pixel, per 16 channels, 16 bf16 hi
                           (32 B) then 16 bf16 lo (32 B). */
+  FISR_PREC_F32W = 4, /* fp32 activations/weights like FISR_PREC_F32; the convolutions with Cout % 64 == 0 (132 of the
+                         138) run Winograd F(2x2,3x3) minimal filtering in fp32 -- transforms in fp32 adds, products on
+                         v_mfma_f32_32x32x2_f32 with fp32 accumulation, 16 instead of 36 multiplies per 2x2 outputs --
+                         the algorithm cuDNN uses for fp32 3x3 convolutions under the reference's TF 1.13; the rest
+                         (3/6-channel heads) use the direct kernel.  Results differ from FISR_PREC_F32 by fp32
+                         rounding only (different summation order). */
   FISR_PREC_F16F8 = 3  /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels
                           16 x fp16 h (32 B), 16 x fp8-e4m3 l8 (16 B), 16 x fp8-e4m3 copy of h (16 B).
                           Product = a_h*w_h (v_mfma_f32_32x32x16_f16) + both cross terms in ONE

@@ -19,12 +19,12 @@ SHAPES = [  # n, h, w, cin, cout, flags, res
     (12, 136, 248, 64, 64, 3, 1),
     (1, 544, 992, 64, 64, 3, 1),
 ]
-PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}
+PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}
 L = lib.lib()
 for prec in (sys.argv[1:] or ["bf16x3"]):
     for (n, h, w, ci, co, fl, rs) in SHAPES:
         us = ctypes.c_double()
-        iters = 5 if prec == "fp32" else 10
+        iters = 5 if prec.startswith("fp32") else 10
         rc = L.fisr_bench_conv(PID[prec], n, h, w, ci, co, fl, rs, iters, ctypes.byref(us))
         if rc:
             print(prec, (n, h, w, ci, co), "ERR", L.fisr_last_error(None))

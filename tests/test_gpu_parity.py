@@ -41,6 +41,14 @@ def net32(dev, syn_weights):
 
 
 @pytest.fixture(scope="module")
+def net32w(dev, syn_weights):
+    n = FISRnet(device="cuda:0", precision="fp32w")
+    n.set_weights(syn_weights)
+    yield n
+    n.close()
+
+
+@pytest.fixture(scope="module")
 def netx3(dev, syn_weights):
     n = FISRnet(device="cuda:0", precision="bf16x3")
     n.set_weights(syn_weights)
@@ -72,13 +80,13 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
 
 
-PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}
+PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}
 
 
 def to_dev(x, prec):
     """numpy float32 [N,H,W,C] -> device tensor in the activation format of `prec`."""
     x = np.ascontiguousarray(x, np.float32)
-    if prec == "fp32":
+    if prec in ("fp32", "fp32w"):
         return torch.from_numpy(x).cuda()
     if prec == "fp16":
         return torch.from_numpy(x).cuda().half().contiguous()
@@ -88,7 +96,7 @@ def to_dev(x, prec):
 
 
 def from_dev(t, prec, shape):
-    if prec == "fp32":
+    if prec in ("fp32", "fp32w"):
         return t.cpu().numpy().reshape(shape)
     if prec == "fp16":
         return t.float().cpu().numpy().reshape(shape)
@@ -99,7 +107,7 @@ def from_dev(t, prec, shape):
 
 
 def empty_dev(shape, prec):
-    if prec == "fp32":
+    if prec in ("fp32", "fp32w"):
         return torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
     if prec == "fp16":
         return torch.full(shape, float("nan"), dtype=torch.float16, device="cuda")
@@ -186,6 +194,56 @@ def test_conv3x3_fp32_vs_oracle(dev, shape):
     # value through all K steps: allow sqrt(K)-scaled rounding for the 512-channel case
     tol = F32_OP_TOL * (2 if (use_res and c0 + c1 >= 256) else 1)
     _report(got, exp, tol, f"conv {shape}")
+
+
+@pytest.mark.parametrize("shape", [
+    # n, h, w, c0, c1, cout, flags, use_res
+    (1, 8, 32, 16, 0, 64, 0, False),            # exactly one tile, two 8-channel chunks
+    (1, 8, 32, 64, 0, 64, 0, False),            # 8 chunks
+    (1, 16, 64, 32, 0, 64, 3, True),            # relu in/out + residual, 2x2 tiles
+    (2, 24, 24, 64, 0, 128, 1, False),          # batch 2, ragged width, two N-blocks
+    (1, 3, 3, 32, 0, 64, 0, False),             # deepest level of the 96x96 config: odd sizes below one wtile row
+    (1, 12, 12, 128, 0, 256, 2, False),
+    (1, 17, 45, 16, 0, 64, 0, False),           # odd sizes: half-filled 2x2 output tiles on both axes
+    (1, 16, 40, 64, 64, 64, 0, False),          # dual-source concat (decoder conv/0)
+    (1, 8, 32, 64, 0, 256, 7, False),           # relu, relu, depth_to_space store (heads conv/1)
+    (1, 10, 33, 64, 0, 256, 6, False),          # d2s with ragged tile
+    (1, 8, 32, 48, 0, 64, 0, False),            # level-2/3 first conv (38 -> pad 48)
+    (1, 8, 8, 512, 0, 512, 0, True),            # bottleneck shape, 64 chunks
+    (3, 40, 100, 64, 0, 64, 3, True),           # many tiles: the XCD-aware work order covers every tile once
+])
+def test_conv3x3_fp32_winograd_vs_oracle(dev, shape):
+    """FISR_PREC_F32W: Winograd F(2x2,3x3) in fp32 (conv3x3_wino.h) against the fp64 direct oracle.  The
+    transforms amplify fp32 rounding by a small constant (input transform: sums of 4 values, output: of 9), so
+    the bound is 4x the direct kernel's."""
+    n, h, w, c0, c1, cout, flags, use_res = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31) + 5)
+    x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+    wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+    got = hip_conv(x0, wt, b, x1, res, flags, prec="fp32w")
+    exp = ref_conv(x0, wt, b, x1, res, flags)
+    _report(got, exp, 4 * F32_OP_TOL, f"winograd conv {shape}")
+    if flags & flib.CONV_RELU_OUT:
+        assert got.min() >= 0
+
+
+def test_conv3x3_fp32_winograd_residual_in_place(dev):
+    """res_block's conv/1 writes onto its residual (ops.py:43): every element is read and written by the same lane."""
+    L = flib.lib()
+    rng = np.random.default_rng(77)
+    n, h, w, c = 1, 24, 72, 64
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    r = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    dx, dr = torch.from_numpy(x).cuda(), torch.from_numpy(r).cuda()
+    flib.check(L.fisr_op_conv3x3(ctypes.c_void_p(dx.data_ptr()), c, None, 0, _fp(wt), _fp(b), c,
+                                 ctypes.c_void_p(dr.data_ptr()), ctypes.c_void_p(dr.data_ptr()), n, h, w, 0, 4, 0, _stream()))
+    torch.cuda.synchronize()
+    _report(dr.cpu().numpy(), ref_conv(x, wt, b, None, r, 0), 4 * F32_OP_TOL, "winograd in-place residual")
 
 
 @pytest.mark.parametrize("shape", [
@@ -406,6 +464,52 @@ def test_forward_fp32_cfg1_96x96_windows(net32, gold_dir):
     for s in range(3):
         _, _, l3 = net32.model(torch.from_numpy(g["inp"][s:s + 1]).cuda(), want_all=False)
         _report(l3.cpu().numpy()[0], g["l3"][s].astype(np.float64), F32_FWD_TOL + 1e-6, f"window {s}")
+
+
+def test_forward_fp32_winograd_vs_goldens(net32w, gold_dir, syn_blob):
+    """The fp32 engine with Winograd F(2x2,3x3) convolutions (FISR_PREC_F32W) against the same fp64-oracle goldens
+    as the direct fp32 engine and at the same bound (2e-4 on O(1) outputs after 138 convs; measured ~1e-5), all
+    three levels; the three cfg1 windows with the PSNR protocol; one full 544x992 tile on the sparse grid; random
+    shapes incl. the minimal 32x32 (level-1 maps of 8x8 .. 1x1: tiles mostly padding)."""
+    g = np.load(os.path.join(gold_dir, "model_32x64.npz"))
+    l1, l2, l3 = net32w.model(torch.from_numpy(g["x"]).cuda())
+    torch.cuda.synchronize()
+    for name, got, exp in (("l1", l1, g["l1"]), ("l2", l2, g["l2"]), ("l3", l3, g["l3"])):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - exp)
+        print(f"fp32w {name}: max {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}")
+        _report(got.cpu().numpy(), exp, F32_FWD_TOL, f"fp32w pred_{name}")
+    g96 = np.load(os.path.join(gold_dir, "model_96.npz"))
+    rng = np.random.default_rng(8)
+    for s_ in range(3):
+        _, _, l3 = net32w.model(torch.from_numpy(g96["inp"][s_:s_ + 1]).cuda(), want_all=False)
+        hip = l3.cpu().numpy()[0].astype(np.float64)
+        ref = g96["l3"][s_].astype(np.float64)
+        _report(hip, ref, F32_FWD_TOL + 1e-6, f"fp32w window {s_}")
+        d = _psnr_protocol(hip, ref, rng)
+        print(f"fp32w window {s_}: rms {np.sqrt(np.mean((hip - ref) ** 2)):.3e} max {np.abs(hip - ref).max():.3e} dPSNR {d}")
+        assert max(d) <= 0.0005, d
+    gs = np.load(os.path.join(gold_dir, "model_544x992_sparse.npz"))
+    from tests_support import make_full_size_input
+    x = make_full_size_input(int(gs["seed"]), 544, 992)
+    _, _, l3 = net32w.model(torch.from_numpy(x).cuda(), want_all=False)
+    st = int(gs["stride"])
+    _report(l3[0, ::st, ::st, :].cpu().numpy(), gs["l3_sparse"], F32_FWD_TOL, "fp32w 544x992 tile sparse grid")
+    del l3
+    rng = np.random.default_rng(78)
+    for (n, h, w) in [(1, 32, 32), (2, 32, 160), (1, 128, 32), (3, 64, 96)]:
+        xr = rng.random((n, h, w, 29)).astype(np.float32)
+        xr[..., 9:17] = (xr[..., 9:17] - 0.5) * 0.4
+        ref = C.forward(xr, syn_blob, True)
+        outs = net32w.model(torch.from_numpy(xr).cuda())
+        torch.cuda.synchronize()
+        for name, got, exp in zip(("pred_l1", "pred_l2", "pred_l3"), outs, ref):
+            _report(got.cpu().numpy(), exp, F32_FWD_TOL, f"fp32w {name} n{n} {h}x{w}")
+    # determinism / batch independence, as for the direct engine
+    xb = rng.random((2, 32, 64, 29)).astype(np.float32)
+    xb[1] = xb[0]
+    a = net32w.model(torch.from_numpy(xb).cuda())[2].cpu().numpy()
+    b = net32w.model(torch.from_numpy(xb).cuda())[2].cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(a[0], a[1])
 
 
 def test_forward_batch_and_determinism(net32):
