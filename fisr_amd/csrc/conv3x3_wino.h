@@ -19,12 +19,15 @@
 // MFMA row operand and the host packs the rows so that a lane owns 16 consecutive channels (one 64-byte
 // record of the activation tensor), exactly as in conv3x3.h.
 //
-// K loop over 8-channel chunks, ONE barrier per chunk, everything double-buffered in LDS (150 KB):
-//   RAW[2]  (8+2)x(32+2) halo pixels x 32 B          global -> registers -> LDS (relu-on-load here)
+// K loop over 8-channel chunks, ONE barrier per chunk, all of LDS in use (163 712 of 163 840 bytes):
+//   RAW[3]  (8+2)x(32+2) halo pixels x 32 B          LDS-DMA from the activation tensor, three chunks ahead
 //   V[2]    16 positions x 64 wtiles x 32 B          B^T d B of the NEXT chunk, computed by all 256 threads
-//                                                    from RAW while the MFMAs of the current chunk run
-//   U[2]    16 positions x 64 channels x 32 B        straight global -> LDS copies (the host stores the
-//                                                    slab in its final LDS image, swizzle included)
+//                                                    from RAW (relu-on-load here) while the MFMAs of the
+//                                                    current chunk run
+//   U[2]    16 positions x 64 channels x 32 B        LDS-DMA of the host-made slab (its final LDS image)
+// Nothing is staged through registers: every global byte goes global -> LDS by global_load_lds_dwordx4.
+// One wave per SIMD means nobody else hides a stall, so the pipeline depths are explicit: a raw chunk has two
+// whole MFMA phases (~8k cycles) to arrive from HBM, a weight slab one (L2 hit).
 // LDS records are 32 B (8 fp32); the two 16-byte halves of record i are swapped when bit 3 of i is set, so
 // the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-byte slots (conflict-free fragment
 // reads without padding; MI355X_MICROARCH.md, LDS table).
@@ -39,15 +42,29 @@ constexpr int W_BN = 64;                       // output channels per workgroup
 constexpr int W_NWT = 64;                      // Winograd tiles per workgroup (4 x 16 over the 8 x 32 pixel tile)
 constexpr int W_SLAB = 16 * 64 * W_REC;        // one V or U buffer: 32768 B
 constexpr int W_RAW = HALO_PIX * W_REC;        // one raw halo buffer: 10880 B
-constexpr int W_RAW_UNITS = HALO_PIX * 2;      // 16-byte units of a raw halo chunk
-constexpr size_t wino_lds_bytes() { return (size_t)4 * W_SLAB + 2 * W_RAW; }
+constexpr int W_RAW_UNITS = HALO_PIX * 2;      // 16-byte units of a raw halo chunk: 680 = 10 full waves + 40 lanes
+constexpr size_t wino_lds_bytes() { return (size_t)4 * W_SLAB + 3 * W_RAW; }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// GLDS: the U slab goes global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write);
-// otherwise it is staged through registers like the raw halo.
-template <bool GLDS>
+// FISR_WABL: performance-diagnosis ablations of this kernel (WRONG results): 1 no input transform in the loop,
+// 2 no copies in the loop, 4 no MFMAs in the loop, 8 no fragment reads in the loop (stage 0's are reused),
+// 16 no scheduler interleave requests, 32 no padding fix, 64 no output transform (raw accumulators stored).
+#ifndef FISR_WABL
+#define FISR_WABL 0
+#endif
+
+// One LDS-DMA copy instruction per FISR_GLDS_COPY: lane l moves 16 bytes from (gbase + voff) to LDS byte address
+// M0 + 16*l.  Written in inline asm ON PURPOSE: hipcc treats a global_load_lds it knows about as a FLAT access
+// pending on both counters and then drains vmcnt(0) / lgkmcnt(0) at every later wait and puts a vmcnt wait in
+// front of the next ds_read (it cannot disambiguate LDS addresses).  Hidden from the compiler, the copies are
+// ordered by the counted s_waitcnt of this file alone -- and there is no compiler-tracked VMEM load in the
+// K loop whose wait the hidden copies could falsify.
+#define FISR_GLDS_BEGIN(KEEP, LDS)  "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
+#define FISR_GLDS_COPY(OFF, G)      "global_load_lds_dwordx4 %[" #OFF "], %[" #G "]\n\t"
+#define FISR_GLDS_NEXT_ROW          "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+#define FISR_GLDS_END(KEEP)         "s_mov_b32 m0, %[" #KEEP "]"
+
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sV = smem;
@@ -86,65 +103,97 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
 
   const int nch = (p.C0 + p.C1) / W_CH;
 
-  // ---- raw halo loader: unit u = tid + 256*i -> halo pixel u >> 1, 16-byte half u & 1 (= tid & 1) ----
-  const int r_half = tid & 1;
-  int in_pix[3];
+  // ---- raw halo chunk: 680 16-byte units, unit u = tid + 256*i -> halo pixel u >> 1, half u & 1 (= tid & 1) ----
+  // Every unit is copied from a CLAMPED address (padding and beyond-the-image units read some valid pixel), so the
+  // number of copy instructions per wave is fixed -- the counted waits rely on it -- and the units that must be
+  // zero (SAME padding, ragged edges) are overwritten with zeros by the same thread once the copy has landed.
+  // Waves 0, 1: three full copies; wave 2: two full + lanes 0..39; wave 3: two.
+  unsigned raw_voff0[3], raw_voff1[3];                  // byte offsets into in0 / in1 (32-bit: tensors < 4 GB, host-checked)
+  bool in_ok[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int u = tid + 256 * i;
-    const int pix = u >> 1;
+    const int pix = min(u >> 1, HALO_PIX - 1);
     const int py = pix / HALO_W, px = pix - py * HALO_W;
     const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool ok = u < W_RAW_UNITS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    in_pix[i] = ok ? (nb * p.H + gy) * p.W + gx : -1;
+    in_ok[i] = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;       // (units >= 680 are never copied nor fixed)
+    const unsigned gp = (unsigned)((nb * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(max(gx, 0), p.W - 1));
+    raw_voff0[i] = (gp * (unsigned)p.C0 + (unsigned)(tid & 1) * 4u) * 4u;
+    raw_voff1[i] = (gp * (unsigned)p.C1 + (unsigned)(tid & 1) * 4u) * 4u;
   }
-  auto load_raw = [&](int kc, uint4 (&r)[3]) {
-    const float* src;
-    int csrc, coff;
-    const int c0 = kc * W_CH;
-    if (c0 < p.C0) { src = (const float*)p.in0; csrc = p.C0; coff = c0; }
-    else           { src = (const float*)p.in1; csrc = p.C1; coff = c0 - p.C0; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      uint4 q = make_uint4(0u, 0u, 0u, 0u);
-      if (in_pix[i] >= 0) q = *reinterpret_cast<const uint4*>(src + (size_t)in_pix[i] * csrc + coff + r_half * 4);
-      r[i] = q;
+  const unsigned raw_lds0 = (unsigned)(size_t)(lds_ptr_t)sR + (unsigned)wave * 1024u;
+  auto copy_raw = [&](int kc, int slot) {
+    const int c0 = min(kc, nch - 1) * W_CH;          // past the last chunk: a harmless repeat of the last one
+    const bool first = c0 < p.C0;
+    const char* g = first ? (const char*)p.in0 + (size_t)c0 * 4 : (const char*)p.in1 + (size_t)(c0 - p.C0) * 4;
+    const unsigned o0 = first ? raw_voff0[0] : raw_voff1[0];
+    const unsigned o1 = first ? raw_voff0[1] : raw_voff1[1];
+    const unsigned o2 = first ? raw_voff0[2] : raw_voff1[2];
+    const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)W_RAW;
+    unsigned keep;
+    if (wave < 2) {
+      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g)
+                   FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o2, g) FISR_GLDS_END(keep)
+                   : [keep] "=&s"(keep) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2) : "memory", "scc");
+    } else if (wave == 2) {
+      unsigned long long ex;
+      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g)
+                   FISR_GLDS_NEXT_ROW
+                   "s_mov_b64 %[ex], exec\n\ts_bfm_b64 exec, 40, 0\n\t"      // units 640..679: lanes 0..39 of wave 2
+                   FISR_GLDS_COPY(o2, g)
+                   "s_mov_b64 exec, %[ex]\n\t" FISR_GLDS_END(keep)
+                   : [keep] "=&s"(keep), [ex] "=&s"(ex) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2)
+                   : "memory", "scc");
+    } else {
+      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g) FISR_GLDS_END(keep)
+                   : [keep] "=&s"(keep) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1) : "memory", "scc");
     }
   };
-  const float relu_in_floor = p.relu_in ? 0.f : -__builtin_huge_valf();   // branch-free relu-on-load
-  auto store_raw = [&](int buf, const uint4 (&r)[3]) {
+  // zeros over the units of a landed raw chunk that are padding (by the thread that copied them)
+  const bool any_pad = !(in_ok[0] && in_ok[1] && (in_ok[2] || tid + 512 >= W_RAW_UNITS));
+  auto fix_raw = [&](int slot) {
+    if (any_pad) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int u = tid + 256 * i;
-      if (i < 2 || u < W_RAW_UNITS) {
-        f32x4 f = __builtin_bit_cast(f32x4, r[i]);
-        f.x = fmaxf(f.x, relu_in_floor); f.y = fmaxf(f.y, relu_in_floor);
-        f.z = fmaxf(f.z, relu_in_floor); f.w = fmaxf(f.w, relu_in_floor);
-        *reinterpret_cast<f32x4*>(sR + buf * W_RAW + u * 16) = f;
+      for (int i = 0; i < 3; ++i) {
+        const int u = tid + 256 * i;
+        if (!in_ok[i] && u < W_RAW_UNITS) *reinterpret_cast<f32x4*>(sR + slot * W_RAW + u * 16) = z;
       }
     }
   };
+
   // ---- U slab: 2048 16-byte units, a linear copy of the host-made LDS image of (chunk kc, N-block) ----
   const char* const u_base = (const char*)p.wpk + (size_t)nblk * W_SLAB;
   const size_t u_stride = (size_t)nblocks * W_SLAB;
-  auto load_u = [&](int kc, int buf, uint4 (&r)[8]) {
-    const char* g = u_base + (size_t)kc * u_stride;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if constexpr (GLDS) {
-        // LDS destination = wave-uniform base + lane * 16: units (wave*64 + 256*i) .. +63
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + (size_t)(tid + 256 * i) * 16),
-                                         (lds_ptr_t)(sU + buf * W_SLAB + (wave * 64 + 256 * i) * 16), 16, 0, 0);
-      } else {
-        r[i] = *reinterpret_cast<const uint4*>(g + (size_t)(tid + 256 * i) * 16);
-      }
-    }
+  const unsigned u_lds0 = (unsigned)(size_t)(lds_ptr_t)sU + (unsigned)wave * 1024u;   // LDS byte address, this wave's 1 KB
+  const unsigned u_voff = (unsigned)tid * 16u;
+  auto copy_u = [&](int kc, int buf) {
+    const char* g = u_base + (size_t)kc * u_stride;                 // wave-uniform: SGPR pair
+    const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)W_SLAB;
+    unsigned keep;
+    // unit (tid + 256*i), i = 0..7: global byte offset voff + 4096*i, LDS destination M0 + lane*16
+    asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g) FISR_GLDS_NEXT_ROW
+                 FISR_GLDS_COPY(o2, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o3, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o4, g)
+                 FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o5, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o6, g) FISR_GLDS_NEXT_ROW
+                 FISR_GLDS_COPY(o7, g) FISR_GLDS_END(keep)
+                 : [keep] "=&s"(keep)
+                 : [g] "s"(g), [lds] "s"(lds), [o0] "v"(u_voff), [o1] "v"(u_voff + 0x1000u), [o2] "v"(u_voff + 0x2000u),
+                   [o3] "v"(u_voff + 0x3000u), [o4] "v"(u_voff + 0x4000u), [o5] "v"(u_voff + 0x5000u),
+                   [o6] "v"(u_voff + 0x6000u), [o7] "v"(u_voff + 0x7000u)
+                 : "memory", "scc");
   };
-  auto store_u = [&](int buf, const uint4 (&r)[8]) {
-    if constexpr (!GLDS) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(sU + buf * W_SLAB + (tid + 256 * i) * 16) = r[i];
-    }
+  // Waits and the workgroup barrier.  __syncthreads() is a release fence (vmcnt(0)); here a wave waits for all its
+  // copies EXCEPT the youngest raw chunk's (copies complete in order; the raw copies of the chunk three ahead are
+  // issued after the U copy precisely so that they may stay in flight across the barrier), fixes the padding of the
+  // chunk that has just landed, waits for its own LDS writes and joins the barrier.
+  auto wait_copies_keep_youngest_raw = [&]() {
+    if (wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
   // ---- input transform V = B^T d B: thread = (wtile t_w, channel quad t_cq, row half t_rh) ----
@@ -158,13 +207,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
   const float sgn = t_rh ? -1.f : 1.f;
   const int t_roff = ((2 * t_ty) * HALO_W + 2 * t_tx) * W_REC + t_cq * 16;
   const int t_voff = ((8 * t_rh) * 64 + t_w) * W_REC + ((t_cq ^ ((t_w >> 3) & 1)) * 16);
+  const float relu_in_floor = p.relu_in ? 0.f : -__builtin_huge_valf();   // branch-free relu-on-load
+  auto relu4 = [&](f32x4 f) {
+    f.x = fmaxf(f.x, relu_in_floor); f.y = fmaxf(f.y, relu_in_floor);
+    f.z = fmaxf(f.z, relu_in_floor); f.w = fmaxf(f.w, relu_in_floor);
+    return f;
+  };
   // The transform is cut in five slices so that it can be spread between the MFMAs of the running chunk:
   //   slice 0: raw reads of columns 0,1      slice 1: raw reads of columns 2,3 + row stage of columns 0,1
   //   slice 2: row stage of columns 2,3      slice 3: column stage + stores of T-row A
   //   slice 4: column stage + stores of T-row B
   f32x4 txa[2], tza[2], tyb[2], tzb[2], TA[4], TB[4];
-  auto tr_read = [&](int rbuf, int cpair) {
-    const char* rb = sR + rbuf * W_RAW + t_roff;
+  auto tr_read = [&](int slot, int cpair) {
+    const char* rb = sR + slot * W_RAW + t_roff;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int c = 2 * cpair + k;
@@ -177,8 +232,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
   auto tr_rows = [&](int cpair) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      TA[2 * cpair + k] = txa[k] - tza[k];
-      TB[2 * cpair + k] = tyb[k] + sgn * tzb[k];
+      TA[2 * cpair + k] = relu4(txa[k]) - relu4(tza[k]);
+      TB[2 * cpair + k] = relu4(tyb[k]) + sgn * relu4(tzb[k]);
     }
   };
   auto tr_cols = [&](int vbuf, int which) {
@@ -188,9 +243,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
     *reinterpret_cast<f32x4*>(vw + 1 * 64 * W_REC) = T[1] + T[2];
     *reinterpret_cast<f32x4*>(vw + 2 * 64 * W_REC) = T[2] - T[1];
     *reinterpret_cast<f32x4*>(vw + 3 * 64 * W_REC) = T[1] - T[3];
-  };
-  auto transform = [&](int rbuf, int vbuf) {     // the whole thing at once (prologue)
-    tr_read(rbuf, 0); tr_rows(0); tr_read(rbuf, 1); tr_rows(1); tr_cols(vbuf, 0); tr_cols(vbuf, 1);
   };
 
   // ---- MFMA phase: for every position, 8 channels = one 16-byte fragment per operand = 4 MFMAs (K = 2) ----
@@ -226,51 +278,62 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
     __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200, NOTHER, 0);           \
   }
 
-  // ---- prologue: chunk 0 staged and transformed, chunk 1 raw in LDS ----
-  uint4 rraw[3], ru[8];
-  load_raw(0, rraw);
-  load_u(0, 0, ru);
-  store_raw(0, rraw);
-  store_u(0, ru);
-  if (nch > 1) load_raw(1, rraw);
-  __syncthreads();
-  transform(0, 0);
-  if (nch > 1) store_raw(1, rraw);
-  // LDS-DMA copies are tracked by vmcnt only: drain them explicitly before the barrier that publishes the slab
-  if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // ---- prologue: U(0) and raw(0..2) requested; chunk 0 transformed; raw(1) fixed ----
+  // raw chunk c lives in RAW[c % 3]: requested at iteration c-3, landed + padding fixed at the end of iteration
+  // c-2, transformed during iteration c-1 (into V[c & 1]), multiplied in iteration c.
+  copy_raw(0, 0);
+  copy_u(0, 0);
+  copy_raw(1, 1);
+  copy_raw(2, 2);
+  if (wave < 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // raw(0), U(0) landed; raw(1), raw(2) in flight
+  else          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  fix_raw(0);
+  lds_barrier();
+  tr_read(0, 0); tr_rows(0); tr_read(0, 1); tr_rows(1); tr_cols(0, 0); tr_cols(0, 1);     // chunk 0 -> V[0]
+  wait_copies_keep_youngest_raw();                                  // raw(1) landed; raw(2) in flight
+  fix_raw(1);
+  lds_barrier();
   if (p.trace) t_first = __builtin_readcyclecounter();
 
-  // ---- main loop: MFMAs of chunk kc || input transform of chunk kc+1 || loads of U(kc+1), raw(kc+2) ----
+  // ---- main loop: MFMAs of chunk kc || input transform of chunk kc+1 || copies of U(kc+1), raw(kc+3) ----
+  int slot1 = 1, slot2 = 2, slot3 = 0;                 // RAW slots of chunks kc+1, kc+2, kc+3
   for (int kc = 0; kc + 1 < nch; ++kc) {
     const int b = kc & 1;
-    load_u(kc + 1, b ^ 1, ru);
-    const bool more = kc + 2 < nch;
-    if (more) load_raw(kc + 2, rraw);
+    if (!(FISR_WABL & 2)) {
+      copy_u(kc + 1, b ^ 1);
+      copy_raw(kc + 3, slot3);
+    }
     frag_load(b, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {
-      if (pp < 7) frag_load(b, pp + 1, (pp + 1) & 1);
-      // transform of chunk kc+1, RAW[(kc+1)&1] -> V[(kc+1)&1], one slice per stage
-      if (pp == 0) tr_read(b ^ 1, 0);
-      if (pp == 1) { tr_rows(0); tr_read(b ^ 1, 1); }
-      if (pp == 2) tr_rows(1);
-      if (pp == 3) tr_cols(b ^ 1, 0);
-      if (pp == 4) tr_cols(b ^ 1, 1);
-      FISR_WINO_MMA(pp, pp & 1, x) FISR_WINO_MMA(pp, pp & 1, y) FISR_WINO_MMA(pp, pp & 1, z) FISR_WINO_MMA(pp, pp & 1, w)
-      FISR_WINO_INTERLEAVE(3)
+      if (pp < 7 && !(FISR_WABL & 8)) frag_load(b, pp + 1, (pp + 1) & 1);
+      if (!(FISR_WABL & 1)) {
+        if (pp == 0) tr_read(slot1, 0);
+        if (pp == 1) { tr_rows(0); tr_read(slot1, 1); }
+        if (pp == 2) tr_rows(1);
+        if (pp == 3) tr_cols(b ^ 1, 0);
+        if (pp == 4) tr_cols(b ^ 1, 1);
+      }
+      if (!(FISR_WABL & 4)) {
+        FISR_WINO_MMA(pp, (FISR_WABL & 8) ? 0 : (pp & 1), x) FISR_WINO_MMA(pp, (FISR_WABL & 8) ? 0 : (pp & 1), y)
+        FISR_WINO_MMA(pp, (FISR_WABL & 8) ? 0 : (pp & 1), z) FISR_WINO_MMA(pp, (FISR_WABL & 8) ? 0 : (pp & 1), w)
+      }
+      if (!(FISR_WABL & 16)) { FISR_WINO_INTERLEAVE(3) }
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_u(b ^ 1, ru);
-    if (more) store_raw(b, rraw);       // RAW[kc&1] held chunk kc (consumed one iteration ago)
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(FISR_WABL & 2)) wait_copies_keep_youngest_raw();      // U(kc+1) and raw(kc+2) landed; raw(kc+3) stays in flight
+    if (!(FISR_WABL & 32)) fix_raw(slot2);
+    lds_barrier();
+    const int s_ = slot1; slot1 = slot2; slot2 = slot3; slot3 = s_;
   }
+
   // epilogue geometry: lane (li, kh) owns wtile 32*wh + li -> pixels (y0 + 2*ty + i, x0 + 2*tx + j), and the
   // 16-channel record c0 .. c0+15.  The residual records (4 pixels x 64 B) and the bias are requested BEFORE the
   // last chunk's MFMAs so their latency hides under them (the residual may alias the output: every element is
-  // read and written by the same lane only, so hoisting the reads above the stores is safe).
+  // read and written by the same lane only, so hoisting the reads above the stores is safe).  These are the only
+  // compiler-tracked global loads of the kernel; the hidden copies still in flight (a repeat of the last raw
+  // chunk) are OLDER, so the compiler's counted waits for them stay conservative.
   const int w_ = 32 * wh + li;
   const int ty = w_ >> 4, tx = w_ & 15;
   const int c0 = n0 + 32 * nh + 16 * kh;
@@ -311,6 +374,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
   if (p.trace) t_main = __builtin_readcyclecounter();
 
   // ---- epilogue: output transform A^T M A per lane, + bias (+ residual), relu, 64-byte records ----
+  // One output-tile row i at a time and four channels at a time: few accumulators are in flight between the
+  // accumulator file and the VALU, so nothing spills.
   {
     const float relu_floor = p.relu_out ? 0.f : -__builtin_huge_valf();
     const int cq_shift = p.d2s_shift;
@@ -321,36 +386,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
       }
       return ((size_t)(nb * p.H + y) * p.W + xc) * p.Cout + c0;
     };
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      // s[c][r] = column c of row i of (A^T M):  i = 0: m0c + m1c + m2c,  i = 1: m1c - m2c - m3c
-      float s[4][16];
+      u32x4_t* dst0 = reinterpret_cast<u32x4_t*>((float*)p.out + (px_ok[i][0] ? record(y0 + 2 * ty + i, x0 + 2 * tx) : 0));
+      u32x4_t* dst1 = reinterpret_cast<u32x4_t*>((float*)p.out + (px_ok[i][1] ? record(y0 + 2 * ty + i, x0 + 2 * tx + 1) : 0));
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int k = 0; k < 4; ++k) {                  // channels 4k .. 4k+3 of the record
+        f32x4 o0, o1;
+        const f32x4 r0 = __builtin_bit_cast(f32x4, rres[i][0][k]), r1 = __builtin_bit_cast(f32x4, rres[i][1][k]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          s[c][r] = i == 0 ? (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r]
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * k + e;
+          // s_c = column c of row i of (A^T M):  i = 0: m0c + m1c + m2c,  i = 1: m1c - m2c - m3c
+          float sc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            sc[c] = i == 0 ? (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r]
                            : (acc[4 + c][r] - acc[8 + c][r]) - acc[12 + c][r];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float o[16], rv[16];
-        Rec16<float>::decode(rres[i][j], rv);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float yv = j == 0 ? (s[0][r] + s[1][r]) + s[2][r] : (s[1][r] - s[2][r]) - s[3][r];
-          o[r] = fmaxf((yv + bv[r]) + rv[r], relu_floor);
+          const float y0v = (FISR_WABL & 64) ? acc[e][r] : (sc[0] + sc[1]) + sc[2];
+          const float y1v = (FISR_WABL & 64) ? acc[4 + e][r] : (sc[1] - sc[2]) - sc[3];
+          o0[e] = fmaxf((y0v + bv[r]) + r0[e], relu_floor);
+          o1[e] = fmaxf((y1v + bv[r]) + r1[e], relu_floor);
         }
-        if (px_ok[i][j]) {
-          uint4 q[4];
-          Rec16<float>::encode(o, q);
-          typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-          u32x4_t* dst = reinterpret_cast<u32x4_t*>((float*)p.out + record(y0 + 2 * ty + i, x0 + 2 * tx + j));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            u32x4_t nv; nv.x = q[k].x; nv.y = q[k].y; nv.z = q[k].z; nv.w = q[k].w;
-            __builtin_nontemporal_store(nv, dst + k);
-          }
-        }
+        if (px_ok[i][0]) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, o0), dst0 + k);
+        if (px_ok[i][1]) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, o1), dst1 + k);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -361,5 +422,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
     tr[4] = t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = 0;
   }
 }
+
+#undef FISR_GLDS_BEGIN
+#undef FISR_GLDS_COPY
+#undef FISR_GLDS_NEXT_ROW
+#undef FISR_GLDS_END
 
 }  // namespace fisr

@@ -253,6 +253,11 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
 // the kernel's LDS image (conv3x3_wino.h): [Cin/8][Cout/64][position 16][row 64][32-byte record], the two 16-byte
 // halves of a record swapped when bit 3 of the row is set; rows in the MFMA row order of pack_weights.
 inline bool wino_eligible(int ci, int co) { (void)ci; return co >= W_BN && co % W_BN == 0; }
+// the kernel addresses its input tensors with 32-bit byte offsets
+inline bool wino_fits(int n, int h, int w, int c0, int c1) {
+  const double px = (double)n * h * w;
+  return px * std::max(c0, c1) * 4.0 < 4294967296.0;
+}
 void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
   const int nb = co / W_BN, nch = cin_pad / W_CH;
@@ -346,24 +351,21 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Winograd kernel (fp32 only; a.wpk = the conv's d_wu).  FISR_WINO_GLDS=0 stages the U slab through registers.
+// Winograd kernel (fp32 only; a.wpk = the conv's d_wu).
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
-  static const bool glds = [] { const char* e = getenv("FISR_WINO_GLDS"); return !(e && e[0] == '0'); }();
-  static bool attr_done[64][2] = {};
+  static bool attr_done[64] = {};
   constexpr size_t lds = wino_lds_bytes();
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const void* kern = glds ? reinterpret_cast<const void*>(conv3x3_wino_kernel<true>)
-                          : reinterpret_cast<const void*>(conv3x3_wino_kernel<false>);
-  if (dev < 0 || dev >= 64 || !attr_done[dev][glds]) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64) attr_done[dev][glds] = true;
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles * (a.CoutPad / W_BN));
-  if (glds) hipLaunchKernelGGL(conv3x3_wino_kernel<true>, grid, dim3(256), lds, st, a);
-  else      hipLaunchKernelGGL(conv3x3_wino_kernel<false>, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -509,7 +511,7 @@ struct Runner {
     a.out_cstride = cstride ? cstride : cw.co;
     a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr; a.wexp = cw.wexp;
     const double px = (double)n * h * w;
-    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32;
+    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1);
     if (use_wino) a.wpk = cw.d_wu;
     char cls[96];
     if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino<f32w,F2x2>");
@@ -929,7 +931,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.b.assign(b_host, b_host + cout);
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32;
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1);
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
@@ -1001,7 +1003,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu;
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_fits(n, h, w, cin, 0);
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
   HIP_OK(nullptr, hipMalloc(&d_out, out_b));

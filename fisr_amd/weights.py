@@ -91,28 +91,57 @@ def num_parameters() -> int:
     return sum(int(np.prod(s)) for s in variable_shapes().values())
 
 
-def synthetic_weights(seed: int = 2020, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+def synthetic_weights(seed: int = 2020, gain: float = 1.0, rb_damp: float = 0.3,
+                      head_scale: float = 1.0) -> "OrderedDict[str, np.ndarray]":
     """Seeded stand-in weights (no checkpoint ships with the reference).
 
     Scaled so activations stay O(1) through 46 convs per level: conv kernels
     ~ N(0, gain^2 * 2/(9*Cin)) (He), the second conv of every residual block damped
-    by 0.3 so the identity path dominates, `conv/2` heads centred on 0.5 so that
-    predictions land inside [0,1] like real YUV frames.  Generated in
-    `conv_specs()` order from one `default_rng(seed)` stream.
+    by `rb_damp` (0.3: the identity path dominates; 0.6 lets the decoder activations
+    grow to ~1.5 rms, a harsher set for the reduced-precision engines), `conv/2` heads
+    centred on 0.5 so that predictions land inside [0,1] like real YUV frames.
+    Generated in `conv_specs()` order from one `default_rng(seed)` stream.
     """
     rng = np.random.default_rng(seed)
     out = OrderedDict()
     for name, ci, co in conv_specs():
         std = gain * np.sqrt(2.0 / (9.0 * ci))
         if re.search(r"res_block/\d/conv/1$", name):
-            std *= 0.3
+            std *= rb_damp
         b_mean, b_std = 0.0, 0.01
         if name.endswith("conv/2"):
-            std = gain * 0.25 * np.sqrt(1.0 / (9.0 * ci))
+            std = head_scale * gain * 0.25 * np.sqrt(1.0 / (9.0 * ci))
             b_mean = 0.5
         out[name + "/w"] = (rng.standard_normal((3, 3, ci, co)) * std).astype(np.float32)
         out[name + "/b"] = (b_mean + rng.standard_normal((co,)) * b_std).astype(np.float32)
     return out
+
+
+def spec_weights(seed: int = 2020, head_gain: float = 4.0) -> "OrderedDict[str, np.ndarray]":
+    """The weight set SURVEY.md 8d specifies: every conv `w ~ N(0, (0.8*sqrt(2/(9*(Ci+Co))))^2)` (Glorot-normal
+    x 0.8, the reference's own initialiser family, ops.py:8), `b ~ N(0, 0.01^2)`, NO damping of the residual
+    branches, `default_rng(seed)` in `conv_specs()` order.  As the survey allows ("rescale the three conv/2
+    heads if not O(1)"), only the conv/2 heads are touched: weights x head_gain and bias + 0.5, so that the
+    predictions spread over [0,1] (std ~0.15) instead of sitting at 0 +- 0.03 where the clip would hide errors."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, ci, co in conv_specs():
+        w = rng.standard_normal((3, 3, ci, co)) * (0.8 * np.sqrt(2.0 / (9.0 * (ci + co))))
+        b = rng.standard_normal((co,)) * 0.01
+        if name.endswith("conv/2"):
+            w = w * head_gain
+            b = b + 0.5
+        out[name + "/w"] = w.astype(np.float32)
+        out[name + "/b"] = b.astype(np.float32)
+    return out
+
+
+# The weight sets the parity tests run on (name -> factory): the benign default, the survey's spec, a harsher one.
+WEIGHT_SETS = {
+    "default": lambda: synthetic_weights(2020),
+    "survey_spec": lambda: spec_weights(2020),
+    "harsh": lambda: synthetic_weights(7, 1.0, rb_damp=0.6, head_scale=0.4),
+}
 
 
 def check_complete(weights) -> None:

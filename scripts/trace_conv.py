@@ -3,7 +3,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, n, h, w, ci, co, fl, rs = sys.argv[1], *map(int, sys.argv[2:9])
-prec = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
+prec = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
 os.environ["FISR_TRACE_FILE"] = out
 from fisr_amd import lib
 L = lib.lib()
