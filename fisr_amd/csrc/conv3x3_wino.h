@@ -423,9 +423,4 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const ConvArgs p) 
   }
 }
 
-#undef FISR_GLDS_BEGIN
-#undef FISR_GLDS_COPY
-#undef FISR_GLDS_NEXT_ROW
-#undef FISR_GLDS_END
-
 }  // namespace fisr

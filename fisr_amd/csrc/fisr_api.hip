@@ -18,7 +18,7 @@
 
 #include "../../include/fisr.h"
 #include "conv3x3.h"
-#include "conv3x3_wino.h"
+#include "conv3x3_wino8.h"
 #include "glue_kernels.h"
 
 using namespace fisr;
@@ -351,21 +351,29 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Winograd kernel (fp32 only; a.wpk = the conv's d_wu).
+// Winograd kernels (fp32 only; a.wpk = the conv's d_wu).  Default: the 8-wave kernel (conv3x3_wino8.h);
+// FISR_WINO_VARIANT=4 selects the 4-wave one (conv3x3_wino.h) for A/B runs.
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
+  static const int variant = [] { const char* e = getenv("FISR_WINO_VARIANT"); return e && e[0] == '4' ? 4 : 8; }();
   static bool attr_done[64] = {};
   constexpr size_t lds = wino_lds_bytes();
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    const void* kerns[3] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
+                            reinterpret_cast<const void*>(conv3x3_wino8_kernel<false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>)};
+    for (const void* k : kerns) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles * (a.CoutPad / W_BN));
-  hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), lds, st, a);
+  if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), lds, st, a);
+  else if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8_kernel<true>, grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(conv3x3_wino8_kernel<false>, grid, dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
