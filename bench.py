@@ -10,7 +10,9 @@ halo) through the 138-conv FISRnet forward -> trim/stitch -> clip/quantise/YUV->
 inner loops of `FISRnet.test` / `FISR_for_video` (reference FISRnet.py:798-910), producing 9 raw
 = 7 unique 2048x3840 frames.  Flows and warped frames are pre-made inputs as in cfg2.
 
-The headline (`value`, `dtype`) is the fp32 engine -- cfg2 says fp32, the reference computes in fp32.
+The headline (`value`, `dtype`) is the fp32 engine -- cfg2 says fp32, the reference computes in fp32: fp32 tensors,
+fp32 arithmetic, Winograd F(2x2,3x3) minimal filtering for the 3x3 convolutions (as cuDNN does under the
+reference's TensorFlow); `fp32d` under `other_precisions` is the same engine with the direct exact-fp32 kernel.
 The split-precision engines (bf16x3, f16f8: fp32-grade results on the 16-bit / fp8 matrix pipes, far
 inside the reference tolerance of +-0.02 dB) are timed in the same run under `other_precisions`, each
 with its own roofline, its full-size comparison against the fp32 engine of this run and a check of one
@@ -47,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md (spec; ~6300 achievabl
 # dense MFMA peak of the instruction class each engine issues (MI355X_MICROARCH.md), TFLOP/s
 PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}
 # matrix-pipe work per algorithmic product (direct 3x3): Winograd F(2x2,3x3) issues 16/36 of the multiplies
-MFMA_PER_PRODUCT = {"fp32": 1, "fp32d": 1, "fp32w": None, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
+MFMA_PER_PRODUCT = {"fp32": None, "fp32d": 1, "fp32w": None, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
 DTYPE = {"fp32": "f32", "fp32d": "f32", "fp32w": "f32",
          "fp16": "f16 (f32 accumulate)",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
@@ -409,7 +411,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=sorted(PEAK))
-    ap.add_argument("--others", default="bf16x3,f16f8",
+    ap.add_argument("--others", default="fp32d,bf16x3,f16f8",
                     help="further engines timed on rank 0 at N=1 under other_precisions ('' = none)")
     ap.add_argument("--parallelism", default="frame", choices=["frame", "tile"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")

@@ -28,8 +28,11 @@ from . import tiling
 from . import weights as _weights
 from .lib import FisrError
 
-_PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "float32": _lib.PREC_F32, "fp32d": _lib.PREC_F32,
-         "fp32w": _lib.PREC_F32W,
+# "fp32" is the fp32 engine as it ships: fp32 tensors, fp32 arithmetic, Winograd F(2x2,3x3) for the 132 convs with
+# Cout % 64 == 0 (what cuDNN does for the reference's TF 1.13) -- "fp32w" names it explicitly; "fp32d" is the same
+# engine with the direct (exact fmaf-chain) MFMA kernel for every conv.
+_PREC = {"fp32": _lib.PREC_F32W, "f32": _lib.PREC_F32W, "float32": _lib.PREC_F32W, "fp32w": _lib.PREC_F32W,
+         "fp32d": _lib.PREC_F32,
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
          "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8}
 

@@ -67,7 +67,7 @@ def _worker(rank, world, port, num_patch, precision, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_patch,groups,precision", [((2, 2), 1, "fp32"), ((2, 2), 2, "bf16x3"), ((2, 4), 1, "fp32")])
+@pytest.mark.parametrize("num_patch,groups,precision", [((2, 2), 1, "fp32"), ((2, 2), 2, "bf16x3"), ((2, 4), 1, "fp32d")])
 def test_tile_parallel_real_engine_bit_exact(num_patch, groups, precision):
     """world = tiles x groups gloo ranks on cuda:0: the sharded path equals forward_tiled bit for bit
     (tiles are independent given the halo, so sharding must not change a single byte)."""

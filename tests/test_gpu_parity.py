@@ -34,7 +34,7 @@ def dev():
 
 @pytest.fixture(scope="module")
 def net32(dev, syn_weights):
-    n = FISRnet(device="cuda:0", precision="fp32")
+    n = FISRnet(device="cuda:0", precision="fp32d")      # the direct (exact fmaf-chain) fp32 engine
     n.set_weights(syn_weights)
     yield n
     n.close()
@@ -42,7 +42,7 @@ def net32(dev, syn_weights):
 
 @pytest.fixture(scope="module")
 def net32w(dev, syn_weights):
-    n = FISRnet(device="cuda:0", precision="fp32w")
+    n = FISRnet(device="cuda:0", precision="fp32")       # the shipped fp32 engine: Winograd F(2x2,3x3) where eligible
     n.set_weights(syn_weights)
     yield n
     n.close()
