@@ -1,0 +1,438 @@
+// C-ABI of the on-GPU optical flow (included at the end of fisr_api.hip): PWC-Net-large as the reference's
+// `FISR_for_video_Compute_Flow` runs it (FISR_tfoptflow/FISR_for_video_pwcnet_predict_from_img_test.py:84-147 over
+// model_pwcnet.py:1525-1593).  Weights are installed by TF variable name ('pwcnet/featpyr/conv1a/kernel', ...), exactly
+// what a `pwcnet.ckpt-595000` bundle holds (script :31); the forward is a schedule of the kernels in pwc_kernels.h.
+#include "pwc_kernels.h"
+
+namespace {
+
+constexpr int PWC_LVLS = 6, PWC_PRED = 2;
+const int PWC_CH[7] = {4, 16, 32, 64, 96, 128, 196};     // [0] = padded RGB input
+const int PWC_DENSE[5] = {128, 128, 96, 64, 32};
+const int PWC_CTXT[7][2] = {{128, 1}, {128, 2}, {128, 4}, {96, 8}, {64, 16}, {32, 1}, {2, 1}};
+
+inline int pad4(int c) { return (c + 3) & ~3; }
+
+// Channel layout of the decoder buffer D[lvl] (tf.concat order of model_pwcnet.py:1424, 1428-1445, every group padded
+// to a multiple of 4): [act4 32 | act3 64 | act2 96 | act1 128 | act0 128 | corr 81(84) | c1 C | up_flow 2(4) | up_feat 2(4)]
+struct DecLayout {
+  int c1;                        // feature channels of the level (0 at the top level: x = corr only)
+  int off_act[5];                // act0 .. act4
+  int off_corr, off_c1, off_upflow, off_upfeat, total;
+  explicit DecLayout(int lvl) {
+    c1 = lvl == PWC_LVLS ? 0 : PWC_CH[lvl];
+    off_act[4] = 0; off_act[3] = 32; off_act[2] = 96; off_act[1] = 192; off_act[0] = 320;
+    off_corr = 448; off_c1 = off_corr + 84;
+    off_upflow = off_c1 + c1; off_upfeat = off_upflow + (c1 ? 4 : 0);
+    total = off_upfeat + (c1 ? 4 : 0);
+  }
+  // buffer channel (absolute) of TF channel j of the tensor that STARTS at dense stage `from` (5 = x itself,
+  // i = input of conv{lvl}_i is stage 5 - ... see map_from)
+  std::vector<int> map_from(int first_act /* 0..4: the newest act included, 5: none */) const {
+    std::vector<int> m;
+    for (int a = first_act == 5 ? -1 : first_act; a >= 0; --a)
+      for (int k = 0; k < PWC_DENSE[a]; ++k) m.push_back(off_act[a] + k);
+    for (int k = 0; k < 81; ++k) m.push_back(off_corr + k);
+    for (int k = 0; k < c1; ++k) m.push_back(off_c1 + k);
+    if (c1) { m.push_back(off_upflow); m.push_back(off_upflow + 1); m.push_back(off_upfeat); m.push_back(off_upfeat + 1); }
+    return m;
+  }
+};
+
+struct PwcVar {
+  std::vector<int64_t> shape;
+  std::vector<float> v;
+  bool have = false;
+};
+
+struct PwcConv {                 // one packed convolution
+  float* d_w = nullptr; float* d_b = nullptr;
+  int cin_buf = 0, cout = 0, cout_pad = 0;
+};
+struct PwcDeconv { float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0; };
+
+}  // namespace
+
+struct fisr_pwc {
+  int dev = 0;
+  bool finalized = false;
+  std::map<std::string, PwcVar> vars;
+  std::map<std::string, PwcConv> convs;
+  std::map<std::string, PwcDeconv> deconvs;
+  std::string err;
+};
+
+namespace {
+
+int pfail(fisr_pwc* c, int code, const std::string& msg) { g_err = msg; if (c) c->err = msg; return code; }
+
+std::vector<std::pair<std::string, std::vector<int64_t>>> pwc_variable_list() {
+  std::vector<std::pair<std::string, std::vector<int64_t>>> out;
+  auto conv = [&](const std::string& n, int ci, int co) {
+    out.push_back({n + "/kernel", {3, 3, ci, co}});
+    out.push_back({n + "/bias", {co}});
+  };
+  const int real[7] = {3, 16, 32, 64, 96, 128, 196};
+  for (int l = 1; l <= PWC_LVLS; ++l) {
+    const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
+    conv(p + "a", real[l - 1], real[l]); conv(p + "aa", real[l], real[l]); conv(p + "b", real[l], real[l]);
+  }
+  for (int l = PWC_LVLS; l >= PWC_PRED; --l) {
+    int c = 81 + (l == PWC_LVLS ? 0 : real[l] + 4);
+    for (int i = 0; i < 5; ++i) { conv("pwcnet/predict_flow/conv" + std::to_string(l) + "_" + std::to_string(i), c, PWC_DENSE[i]); c += PWC_DENSE[i]; }
+    conv("pwcnet/predict_flow/flow" + std::to_string(l), c, 2);
+    int ci = c;
+    for (int i = 0; i < 7; ++i) { conv("pwcnet/ctxt/dc_conv" + std::to_string(l) + std::to_string(i + 1), ci, PWC_CTXT[i][0]); ci = PWC_CTXT[i][0]; }
+    if (l != PWC_PRED) {
+      out.push_back({"pwcnet/upsample/up_flow" + std::to_string(l) + "/kernel", {4, 4, 2, 2}});
+      out.push_back({"pwcnet/upsample/up_flow" + std::to_string(l) + "/bias", {2}});
+      out.push_back({"pwcnet/upsample/up_feat" + std::to_string(l) + "/kernel", {4, 4, 2, c}});
+      out.push_back({"pwcnet/upsample/up_feat" + std::to_string(l) + "/bias", {2}});
+    }
+  }
+  return out;
+}
+
+// pack HWIO [3,3,ci,co] for pwc_convg_kernel: [cin_buf8/8][CoutPad/64][9][64 rows][8 floats], LDS image; chmap[j] =
+// buffer channel (relative to the conv's first input channel) of TF input channel j
+int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>& chmap, int cin_buf, PwcConv& pc) {
+  const PwcVar& kw = ctx->vars[name + "/kernel"];
+  const PwcVar& kb = ctx->vars[name + "/bias"];
+  const int ci = (int)kw.shape[2], co = (int)kw.shape[3];
+  if ((int)chmap.size() != ci) return pfail(ctx, FISR_EINVAL, name + ": channel map size mismatch");
+  pc.cin_buf = cin_buf; pc.cout = co; pc.cout_pad = round_up(co, G_BN);
+  const int nch = (cin_buf + G_CH - 1) / G_CH, nb = pc.cout_pad / G_BN;
+  std::vector<float> wp((size_t)nch * nb * 9 * G_BN * 8, 0.f), bp(pc.cout_pad, 0.f);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int j = 0; j < ci; ++j) {
+      const int c = chmap[j], kc = c / G_CH, cc = c % G_CH, h = cc >> 2, e = cc & 3;
+      for (int n = 0; n < co; ++n) {
+        const int blk = n / G_BN, nl = n % G_BN, wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+        const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+        wp[((((size_t)kc * nb + blk) * 9 + tap) * G_BN + row) * 8 + ((h ^ ((row >> 3) & 1)) * 4) + e] =
+            kw.v[((size_t)tap * ci + j) * co + n];
+      }
+    }
+  for (int n = 0; n < co; ++n) bp[n] = kb.v[n];
+  HIP_OK(nullptr, hipMalloc((void**)&pc.d_w, wp.size() * 4));
+  HIP_OK(nullptr, hipMalloc((void**)&pc.d_b, bp.size() * 4));
+  HIP_OK(nullptr, hipMemcpy(pc.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(nullptr, hipMemcpy(pc.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int pwc_pack_deconv(fisr_pwc* ctx, const std::string& name, const std::vector<int>& chmap, int cin4, PwcDeconv& pd) {
+  const PwcVar& kw = ctx->vars[name + "/kernel"];   // [4,4,2,ci]
+  const PwcVar& kb = ctx->vars[name + "/bias"];
+  const int ci = (int)kw.shape[3];
+  if ((int)chmap.size() != ci) return pfail(ctx, FISR_EINVAL, name + ": channel map size mismatch");
+  pd.cin4 = cin4;
+  std::vector<float> wp((size_t)16 * 2 * cin4, 0.f);
+  for (int k = 0; k < 16; ++k)
+    for (int o = 0; o < 2; ++o)
+      for (int j = 0; j < ci; ++j) wp[((size_t)k * 2 + o) * cin4 + chmap[j]] = kw.v[((size_t)k * 2 + o) * ci + j];
+  HIP_OK(nullptr, hipMalloc((void**)&pd.d_w, wp.size() * 4));
+  HIP_OK(nullptr, hipMalloc((void**)&pd.d_b, 8));
+  HIP_OK(nullptr, hipMemcpy(pd.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(nullptr, hipMemcpy(pd.d_b, kb.v.data(), 8, hipMemcpyHostToDevice));
+  return 0;
+}
+
+std::vector<int> iota_map(int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; }
+
+struct PwcRunner {
+  fisr_pwc* ctx; hipStream_t st; Arena ar; int rc = 0;
+  float* falloc(size_t n) { return (float*)ar.alloc(n * sizeof(float)); }
+  void check(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  }
+  void zero(float* p, size_t n) { if (!ar.dry && !rc) (void)hipMemsetAsync(p, 0, n * sizeof(float), st); }
+  void conv(const std::string& name, const float* in, int in_cs, int in_co, float* out, int out_cs, int out_co,
+            int n, int h, int w, int stride, int dil, float slope, const float* add = nullptr, int add_cs = 0, int add_co = 0) {
+    if (rc || ar.dry) return;
+    const PwcConv& pc = ctx->convs[name];
+    static bool attr_done[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_convg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)convg_lds_bytes());
+      if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    ConvGArgs a;
+    a.in = in; a.in_cs = in_cs; a.in_co = in_co; a.Cin = pc.cin_buf; a.w = pc.d_w; a.bias = pc.d_b;
+    a.out = out; a.out_cs = out_cs; a.out_co = out_co; a.Cout = pc.cout; a.CoutPad = pc.cout_pad;
+    a.add = add; a.add_cs = add_cs; a.add_co = add_co;
+    a.N = n; a.H = h; a.W = w; a.stride = stride; a.dil = dil; a.slope = slope;
+    a.OH = (h + stride - 1) / stride; a.OW = (w + stride - 1) / stride;
+    const int tot_h = std::max((a.OH - 1) * stride + 2 * dil + 1 - h, 0), tot_w = std::max((a.OW - 1) * stride + 2 * dil + 1 - w, 0);
+    a.pad_t = tot_h / 2; a.pad_l = tot_w / 2;                      // TF 'SAME': the smaller half goes first
+    const int tiles = ((a.OW + TILE_W - 1) / TILE_W) * ((a.OH + TILE_H - 1) / TILE_H) * n;
+    hipLaunchKernelGGL(pwc_convg_kernel, dim3(tiles * (pc.cout_pad / G_BN)), dim3(256), convg_lds_bytes(), st, a);
+    check(name.c_str());
+  }
+  void deconv(const std::string& name, const float* in, int in_cs, int in_co, float* out, int out_cs, int out_co, int n, int h, int w) {
+    if (rc || ar.dry) return;
+    const PwcDeconv& pd = ctx->deconvs[name];
+    hipLaunchKernelGGL(pwc_deconv_kernel, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
+                       pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w);
+    check(name.c_str());
+  }
+
+  // model_pwcnet.py:1525-1593 on a pre-processed pair.  im: [2, H, W, 4] (image a, image b; RGB/255 + a zero channel),
+  // H, W multiples of 64.  flow2[d]: refined level-2 flow of direction d (0: a->b, 1: b->a), [H/4, W/4] x stride 4 floats.
+  // pyr_out[d][k] (nullable): refined flows of levels 6..2, [h_l, w_l, 2] dense.
+  int nn(const float* im, int H, int W, float* flow2[2], float* const* pyr_out) {
+    float* F[7];
+    F[0] = const_cast<float*>(im);
+    int hh[7], ww[7];
+    hh[0] = H; ww[0] = W;
+    for (int l = 1; l <= PWC_LVLS; ++l) {                            // extract_features :1012-1101, both images at once
+      hh[l] = hh[l - 1] / 2; ww[l] = ww[l - 1] / 2;
+      const size_t px = (size_t)2 * hh[l] * ww[l];
+      float* A = falloc(px * PWC_CH[l]); float* B = falloc(px * PWC_CH[l]); F[l] = falloc(px * PWC_CH[l]);
+      const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
+      conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, PWC_CH[l], 0, 2, hh[l - 1], ww[l - 1], 2, 1, 0.1f);
+      conv(p + "aa", A, PWC_CH[l], 0, B, PWC_CH[l], 0, 2, hh[l], ww[l], 1, 1, 0.1f);
+      conv(p + "b", B, PWC_CH[l], 0, F[l], PWC_CH[l], 0, 2, hh[l], ww[l], 1, 1, 0.1f);
+    }
+    for (int d = 0; d < 2; ++d) {
+      float* Dprev = nullptr; int prev_total = 0;
+      float* flow_prev = nullptr;
+      for (int l = PWC_LVLS; l >= PWC_PRED; --l) {
+        const DecLayout L(l);
+        const int h = hh[l], w = ww[l];
+        const size_t px = (size_t)h * w;
+        const float* c1 = F[l] + (size_t)d * px * PWC_CH[l];
+        const float* c2 = F[l] + (size_t)(1 - d) * px * PWC_CH[l];
+        float* D = falloc(px * L.total);
+        zero(D, px * L.total);                                       // channel padding must read as finite zeros
+        const std::string ls = std::to_string(l);
+        const float* cv2 = c2;
+        if (l != PWC_LVLS) {
+          // up-sampled flow / features of the level above land directly in this level's buffer (:1577-1578, :1424)
+          deconv("pwcnet/upsample/up_flow" + std::to_string(l + 1), flow_prev, 4, 0, D, L.total, L.off_upflow, 1, hh[l + 1], ww[l + 1]);
+          deconv("pwcnet/upsample/up_feat" + std::to_string(l + 1), Dprev, prev_total, 0, D, L.total, L.off_upfeat, 1, hh[l + 1], ww[l + 1]);
+          float* Wp = falloc(px * PWC_CH[l]);
+          if (!rc && !ar.dry) {
+            hipLaunchKernelGGL(pwc_warp_kernel, dim3(grid_for(px * PWC_CH[l] / 4)), dim3(256), 0, st, c2, PWC_CH[l], D, L.total,
+                               L.off_upflow, 20.f / (float)(1 << l), Wp, 1, h, w);      // :1560-1561
+            check("warp");
+            hipLaunchKernelGGL(pwc_copy_channels_kernel, dim3(grid_for(px * PWC_CH[l] / 4)), dim3(256), 0, st, c1, PWC_CH[l], D,
+                               L.total, L.off_c1, px);
+            check("copy c1");
+          }
+          cv2 = Wp;
+        }
+        if (!rc && !ar.dry) {
+          hipLaunchKernelGGL(pwc_costvol_kernel, dim3(grid_for(px * 9)), dim3(256), 0, st, c1, cv2, PWC_CH[l], D, L.total,
+                             L.off_corr, 1, h, w);                   // :1277 (leaky relu inside core_costvol)
+          check("cost volume");
+        }
+        for (int i = 0; i < 5; ++i)                                  // predict_flow :1426-1445 (dense connections)
+          conv("pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i), D, L.total, i == 0 ? L.off_corr : L.off_act[i - 1],
+               D, L.total, L.off_act[i], 1, h, w, 1, 1, 0.1f);
+        float* flow = falloc(px * 4); zero(flow, px * 4);
+        conv("pwcnet/predict_flow/flow" + ls, D, L.total, 0, flow, 4, 0, 1, h, w, 1, 1, 1.f);           // :1447
+        float* T1 = falloc(px * 128); float* T2 = falloc(px * 128);
+        const float* src = D; int src_cs = L.total;                  // refine_flow :1506-1521
+        for (int i = 0; i < 7; ++i) {
+          const std::string cn = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
+          float* dst = (i & 1) ? T2 : T1;
+          if (i < 6) {
+            conv(cn, src, src_cs, 0, dst, PWC_CTXT[i][0], 0, 1, h, w, 1, PWC_CTXT[i][1], 0.1f);
+            src = dst; src_cs = PWC_CTXT[i][0];
+          } else {
+            float* refined = falloc(px * 4); zero(refined, px * 4);
+            conv(cn, src, src_cs, 0, refined, 4, 0, 1, h, w, 1, 1, 1.f, flow, 4, 0);
+            flow_prev = refined;
+          }
+        }
+        if (pyr_out && pyr_out[d * 5 + (PWC_LVLS - l)] && !rc && !ar.dry)
+          hipLaunchKernelGGL(stitch_free_copy2_kernel, dim3(grid_for(px)), dim3(256), 0, st, flow_prev, pyr_out[d * 5 + (PWC_LVLS - l)], px);
+        Dprev = D; prev_total = L.total;
+      }
+      flow2[d] = flow_prev;
+    }
+    return rc;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int fisr_pwc_create(fisr_pwc** out, int device_id) {
+  if (!out) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_create: out is NULL");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+    return pfail(nullptr, FISR_EHIP, "fisr_pwc_create: no such HIP device");
+  fisr_pwc* c = new fisr_pwc();
+  c->dev = device_id;
+  for (auto& v : pwc_variable_list()) c->vars[v.first].shape = v.second;
+  *out = c;
+  return 0;
+}
+
+void fisr_pwc_destroy(fisr_pwc* c) {
+  if (!c) return;
+  DeviceGuard guard(c->dev);
+  for (auto& kv : c->convs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
+  for (auto& kv : c->deconvs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
+  delete c;
+}
+
+const char* fisr_pwc_last_error(const fisr_pwc* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int fisr_pwc_num_variables(void) { return (int)pwc_variable_list().size(); }
+
+// name / shape of variable i (for hosts that enumerate what a checkpoint must hold); returns rank or < 0
+int fisr_pwc_variable(int i, const char** name, int64_t* shape4) {
+  static const auto list = pwc_variable_list();
+  if (i < 0 || i >= (int)list.size() || !name || !shape4) return FISR_EINVAL;
+  *name = list[i].first.c_str();
+  for (size_t k = 0; k < list[i].second.size(); ++k) shape4[k] = list[i].second[k];
+  return (int)list[i].second.size();
+}
+
+int fisr_pwc_set_weight(fisr_pwc* c, const char* name, const float* host, const int64_t* shape, int rank) {
+  if (!c || !name || !host || !shape) return pfail(c, FISR_EINVAL, "fisr_pwc_set_weight: null argument");
+  std::string s(name);
+  const size_t colon = s.rfind(':');
+  if (colon != std::string::npos) s = s.substr(0, colon);
+  auto it = c->vars.find(s);
+  if (it == c->vars.end()) return 1;                     // not ours (optimizer slots, global step, ...)
+  PwcVar& v = it->second;
+  size_t n = 1;
+  if (rank != (int)v.shape.size()) return pfail(c, FISR_EINVAL, s + ": wrong rank");
+  for (int k = 0; k < rank; ++k) { if (shape[k] != v.shape[k]) return pfail(c, FISR_EINVAL, s + ": wrong shape"); n *= (size_t)shape[k]; }
+  v.v.assign(host, host + n);
+  v.have = true;
+  c->finalized = false;
+  return 0;
+}
+
+int fisr_pwc_finalize(fisr_pwc* c) {
+  if (!c) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_finalize: ctx is NULL");
+  for (auto& kv : c->vars) if (!kv.second.have) return pfail(c, FISR_EMISSING, "missing variable " + kv.first);
+  DeviceGuard guard(c->dev);
+  HIP_OK(nullptr, guard.err);
+  int rc = 0;
+  const int real[7] = {3, 16, 32, 64, 96, 128, 196};
+  for (int l = 1; l <= PWC_LVLS && !rc; ++l) {
+    const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
+    rc = pwc_pack_conv(c, p + "a", iota_map(real[l - 1]), PWC_CH[l - 1], c->convs[p + "a"]);
+    if (!rc) rc = pwc_pack_conv(c, p + "aa", iota_map(real[l]), PWC_CH[l], c->convs[p + "aa"]);
+    if (!rc) rc = pwc_pack_conv(c, p + "b", iota_map(real[l]), PWC_CH[l], c->convs[p + "b"]);
+  }
+  for (int l = PWC_LVLS; l >= PWC_PRED && !rc; --l) {
+    const DecLayout L(l);
+    const std::string ls = std::to_string(l);
+    for (int i = 0; i < 5 && !rc; ++i) {
+      const int first = i == 0 ? L.off_corr : L.off_act[i - 1];
+      std::vector<int> m = L.map_from(i == 0 ? 5 : i - 1);
+      for (int& x : m) x -= first;
+      const std::string n = "pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i);
+      rc = pwc_pack_conv(c, n, m, L.total - first, c->convs[n]);
+    }
+    if (!rc) rc = pwc_pack_conv(c, "pwcnet/predict_flow/flow" + ls, L.map_from(4), L.total, c->convs["pwcnet/predict_flow/flow" + ls]);
+    int ci = 0;
+    for (int i = 0; i < 7 && !rc; ++i) {
+      const std::string n = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
+      rc = i == 0 ? pwc_pack_conv(c, n, L.map_from(4), L.total, c->convs[n]) : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n]);
+      ci = PWC_CTXT[i][0];
+    }
+    if (l != PWC_PRED && !rc) {
+      rc = pwc_pack_deconv(c, "pwcnet/upsample/up_flow" + ls, iota_map(2), 4, c->deconvs["pwcnet/upsample/up_flow" + ls]);
+      if (!rc) rc = pwc_pack_deconv(c, "pwcnet/upsample/up_feat" + ls, L.map_from(4), L.total, c->deconvs["pwcnet/upsample/up_feat" + ls]);
+    }
+  }
+  if (rc) return rc;
+  c->finalized = true;
+  return 0;
+}
+
+static size_t pwc_ws(fisr_pwc* c, int H, int W, bool with_prep) {
+  PwcRunner r; r.ctx = c; r.st = nullptr; r.ar.dry = true;
+  if (with_prep) r.falloc((size_t)2 * H * W * 4);
+  float* f2[2];
+  r.nn(nullptr, H, W, f2, nullptr);
+  return r.ar.peak + 256;
+}
+
+// The network alone on a prepared pair: im [2, H, W, 4] device (RGB/255 + zero channel; H, W multiples of 64).
+// flow_pred [2, H, W, 2] (direction 0: a->b, 1: b->a) = x4 bilinear * 4 of the level-2 flow (nullable);
+// pyr[10] (nullable, entries nullable): refined flows of levels 6..2 for direction 0 then direction 1, [h_l, w_l, 2].
+size_t fisr_pwc_nn_workspace_bytes(const fisr_pwc* c, int H, int W) {
+  if (!c || !c->finalized || H < 64 || W < 64 || H % 64 || W % 64) return 0;
+  return pwc_ws(const_cast<fisr_pwc*>(c), H, W, false);
+}
+
+int fisr_pwc_nn(fisr_pwc* c, const float* im, int H, int W, float* flow_pred, float* const* pyr, void* ws, size_t ws_bytes, void* stream) {
+  if (!c || !c->finalized) return pfail(c, FISR_ESTATE, "fisr_pwc_nn: weights not finalized");
+  if (!im || !ws || H < 64 || W < 64 || H % 64 || W % 64) return pfail(c, FISR_EINVAL, "fisr_pwc_nn: H and W must be multiples of 64");
+  if (ws_bytes < fisr_pwc_nn_workspace_bytes(c, H, W)) return pfail(c, FISR_ENOMEM, "fisr_pwc_nn: workspace too small");
+  DeviceGuard guard(c->dev);
+  HIP_OK(nullptr, guard.err);
+  PwcRunner r; r.ctx = c; r.st = (hipStream_t)stream; r.ar.base = (char*)ws; r.ar.cap = ws_bytes;
+  float* f2[2] = {nullptr, nullptr};
+  int rc = r.nn(im, H, W, f2, pyr);
+  if (rc) return rc;
+  if (flow_pred)
+    for (int d = 0; d < 2; ++d) {
+      hipLaunchKernelGGL(pwc_upsample4_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, r.st, f2[d], 4, 0, H / 4, W / 4,
+                         flow_pred + (size_t)d * H * W * 2);
+      HIP_OK(nullptr, hipGetLastError());
+    }
+  return 0;
+}
+
+// One iteration of the reference script's loop (:118-140): two YUV uint8 frames [h, w, 3] on the device ->
+// flows a->b and b->a in LR pixels, [h, w, 2] float32 each (what the script writes into pred[fr, 0] and pred[fr, 1]).
+size_t fisr_pwc_flow_workspace_bytes(const fisr_pwc* c, int h, int w) {
+  if (!c || !c->finalized || h < 8 || w < 8) return 0;
+  return pwc_ws(const_cast<fisr_pwc*>(c), round_up(2 * h, 64), round_up(2 * w, 64), true);
+}
+
+int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, int h, int w, float* flow_ab, float* flow_ba,
+                       void* ws, size_t ws_bytes, void* stream) {
+  if (!c || !c->finalized) return pfail(c, FISR_ESTATE, "fisr_pwc_flow_pair: weights not finalized");
+  if (!yuv_a || !yuv_b || !flow_ab || !flow_ba || !ws || h < 8 || w < 8) return pfail(c, FISR_EINVAL, "fisr_pwc_flow_pair: bad argument");
+  if (ws_bytes < fisr_pwc_flow_workspace_bytes(c, h, w)) return pfail(c, FISR_ENOMEM, "fisr_pwc_flow_pair: workspace too small");
+  DeviceGuard guard(c->dev);
+  HIP_OK(nullptr, guard.err);
+  static const ColorConsts cc = make_color_consts();
+  const int H = round_up(2 * h, 64), W = round_up(2 * w, 64);
+  PwcRunner r; r.ctx = c; r.st = (hipStream_t)stream; r.ar.base = (char*)ws; r.ar.cap = ws_bytes;
+  float* im = r.falloc((size_t)2 * H * W * 4);
+  hipLaunchKernelGGL(pwc_prep_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, r.st, yuv_a, h, w, im, H, W, cc);
+  hipLaunchKernelGGL(pwc_prep_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, r.st, yuv_b, h, w, im + (size_t)H * W * 4, H, W, cc);
+  HIP_OK(nullptr, hipGetLastError());
+  float* f2[2] = {nullptr, nullptr};
+  int rc = r.nn(im, H, W, f2, nullptr);
+  if (rc) return rc;
+  float* outs[2] = {flow_ab, flow_ba};
+  for (int d = 0; d < 2; ++d) {
+    hipLaunchKernelGGL(pwc_flow_out_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, r.st, f2[d], 4, 0, H / 4, W / 4, outs[d], h, w);
+    HIP_OK(nullptr, hipGetLastError());
+  }
+  return 0;
+}
+
+// test hooks for the two pre/post-processing kernels
+int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream) {
+  if (!yuv || !out || PH < 2 * h || PW < 2 * w) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_prep: bad argument");
+  static const ColorConsts cc = make_color_consts();
+  DeviceGuard guard(device_of(out));
+  hipLaunchKernelGGL(pwc_prep_kernel, dim3(grid_for((size_t)PH * PW)), dim3(256), 0, (hipStream_t)stream, yuv, h, w, out, PH, PW, cc);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream) {
+  if (!flow2 || !out || 4 * FH < 2 * h || 4 * FW < 2 * w) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_flow_out: bad argument");
+  DeviceGuard guard(device_of(out));
+  hipLaunchKernelGGL(pwc_flow_out_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, (hipStream_t)stream, flow2, 2, 0, FH, FW, out, h, w);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

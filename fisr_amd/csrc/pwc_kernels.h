@@ -1,0 +1,356 @@
+// On-GPU optical flow for `--phase FISR_for_video` (cfg5 of BASELINE.json): the kernels of PWC-Net-large as the
+// reference runs it (FISR_tfoptflow/model_pwcnet.py:1525-1593, options of
+// FISR_for_video_pwcnet_predict_from_img_test.py:96-100) plus the script's own pre/post-processing (:118-140).
+// All fp32, NHWC.  Channel groups inside the concatenated feature buffers are padded to multiples of 4 channels
+// (zero weights on the padding), so every access is a 16-byte vector.
+//
+//   pwc_convg_kernel      tf.layers.conv2d 3x3 'same', stride 1|2, dilation d, + bias (+ add) + leaky relu, reading a
+//                         channel RANGE of a wider NHWC buffer and writing into a channel range of another: the dense
+//                         blocks' tf.concat([act, x]) (model_pwcnet.py:1428-1445) never materialise.  Implicit GEMM on
+//                         v_mfma_f32_32x32x2_f32, 8x32 output pixels x 64 channels per workgroup, K chunks of 8 input
+//                         channels with all 9 tap-shifted pixel blocks staged in LDS (stride / dilation / padding are
+//                         resolved by the loader, the MFMA loop is the same for every layer).
+//   pwc_deconv_kernel     tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196)
+//   pwc_costvol_kernel    core_costvol.cost_volume: 81 displacements, mean over channels, leaky relu (:1277)
+//   pwc_warp_kernel       core_warp.dense_image_warp: bilinear sample at (x + u, y + v), clamped (:1178)
+//   pwc_prep_kernel       script :121-131 + adapt_x (:399-411): YUV uint8 -> RGB (double), x2 up-resize as
+//                         scikit-image does it, uint8 truncation, / 255, zero pad to a multiple of 64
+//   pwc_flow_out_kernel   :1587-1590 + script :139: x4 legacy bilinear * 4, crop, anti-aliased /2 down-resize as
+//                         scikit-image does it (Gaussian sigma 0.5, 'mirror'), / 2
+#pragma once
+#include "glue_kernels.h"
+
+namespace fisr {
+
+constexpr int G_CH = 8;                 // input channels per K chunk
+constexpr int G_REC = 32;               // bytes per LDS record
+constexpr int G_PX = 256;               // output pixels per workgroup (8 x 32)
+constexpr int G_BN = 64;                // output channels per workgroup
+constexpr size_t convg_lds_bytes() { return (size_t)9 * G_PX * G_REC + (size_t)9 * G_BN * G_REC; }
+
+struct ConvGArgs {
+  const float* in;  int in_cs, in_co, Cin;      // input buffer: pixel stride (floats), first channel, channels read
+  const float* w;                                // packed [Cin8/8][9][CoutPad][8], LDS image (halves swizzled by row bit 3)
+  const float* bias;                             // [CoutPad]
+  float* out;       int out_cs, out_co, Cout, CoutPad;
+  const float* add; int add_cs, add_co;          // optional: out = act(conv + bias) + add   (refine_flow, :1521)
+  int N, H, W, OH, OW, stride, dil, pad_t, pad_l;
+  float slope;                                   // leaky relu slope (1 = linear)
+};
+
+__global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sIn = smem;                               // [tap 9][px 256][32 B]
+  char* const sW = smem + 9 * G_PX * G_REC;             // [tap 9][row 64][32 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int pxh = wave & 1, coh = wave >> 1;            // wave = 128 pixels (4 rows) x 32 channels
+
+  const int tiles_x = (p.OW + TILE_W - 1) / TILE_W, tiles_y = (p.OH + TILE_H - 1) / TILE_H;
+  const int nblocks = p.CoutPad / G_BN;
+  int t = blockIdx.x / nblocks;
+  const int nblk = blockIdx.x - t * nblocks;
+  const int tx_ = t % tiles_x; t /= tiles_x;
+  const int ty_ = t % tiles_y;
+  const int nb = t / tiles_y;
+  const int x0 = tx_ * TILE_W, y0 = ty_ * TILE_H;
+  const int nch = (p.Cin + G_CH - 1) / G_CH;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // loader geometry: unit u = tid + 256*i, i < 18: half = u & 1, pixel = (u >> 1) & 255, tap = u >> 9
+  const int l_half = tid & 1, l_px = tid >> 1;          // + 128*(i & 1) pixels, tap = i >> 1
+  const int f_off = li * G_REC + ((kh ^ ((li >> 3) & 1)) * 16);
+
+  for (int kc = 0; kc < nch; ++kc) {
+    __syncthreads();                                    // previous chunk's fragments are consumed
+    const int c0 = kc * G_CH + 4 * l_half;
+    const bool c_ok = c0 < p.Cin;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const int px = l_px + 128 * (i & 1), tap = i >> 1;
+      const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+      const int iy = oy * p.stride - p.pad_t + (tap / 3) * p.dil, ix = ox * p.stride - p.pad_l + (tap % 3) * p.dil;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(nb * p.H + iy) * p.W + ix) * p.in_cs + p.in_co + c0);
+      *reinterpret_cast<f32x4*>(sIn + (tap * G_PX + px) * G_REC + ((l_half ^ ((px >> 3) & 1)) * 16)) = v;
+    }
+    {
+      const char* g = (const char*)p.w + ((size_t)kc * nblocks + nblk) * (9 * G_BN * G_REC);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int u = tid + 256 * i;
+        if (u < 9 * G_BN * 2) *reinterpret_cast<uint4*>(sW + u * 16) = *reinterpret_cast<const uint4*>(g + (size_t)u * 16);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sW + (tap * G_BN + 32 * coh) * G_REC + f_off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sIn + (tap * G_PX + 32 * (4 * pxh + j)) * G_REC + f_off);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: lane (li, kh) of block j owns pixel (y0 + 4*pxh + j, x0 + li), channels cb + r, r = 0..15
+  const int cb = nblk * G_BN + 32 * coh + 16 * kh;
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = p.bias[cb + r];
+  const int ox = x0 + li;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = y0 + 4 * pxh + j;
+    if (oy >= p.OH || ox >= p.OW || cb >= p.Cout) continue;
+    const size_t pix = (size_t)(nb * p.OH + oy) * p.OW + ox;
+    float* ob = p.out + pix * p.out_cs + p.out_co + cb;
+    const float* ab = p.add ? p.add + pix * p.add_cs + p.add_co + cb : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = acc[j][4 * q + e] + bv[4 * q + e];
+        v[e] = s >= 0.f ? s : s * p.slope;
+      }
+      if (cb + 4 * q + 3 < p.Cout) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (ab) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + 4 * q); o += a4; }
+        *reinterpret_cast<f32x4*>(ob + 4 * q) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + 4 * q + e < p.Cout) ob[4 * q + e] = v[e] + (ab ? ab[4 * q + e] : 0.f);
+      }
+    }
+  }
+}
+
+// tf.layers.conv2d_transpose(x, 2, 4, 2, 'same'): out[2*i + k - 1] += in[i] * kernel[k]  (two output channels).
+// One thread per output pixel; weights [ky][kx][o][Cin4] in global (L1/L2 resident), 16-byte loads.
+__global__ void pwc_deconv_kernel(const float* __restrict__ in, int in_cs, int in_co, int Cin4, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ out, int out_cs, int out_co,
+                                  int N, int H, int W) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((size_t)OW * OH));
+    float a0 = bias[0], a1 = bias[1];
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+      const int ky = ((oy + 1) & 1) + 2 * ty, iy = (oy + 1 - ky) / 2;
+      if ((oy + 1 - ky) < 0 || iy >= H) continue;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int kx = ((ox + 1) & 1) + 2 * tx, ix = (ox + 1 - kx) / 2;
+        if ((ox + 1 - kx) < 0 || ix >= W) continue;
+        const f32x4* src = reinterpret_cast<const f32x4*>(in + ((size_t)(n * H + iy) * W + ix) * in_cs + in_co);
+        const f32x4* w0 = reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 0) * Cin4);
+        const f32x4* w1 = reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 1) * Cin4);
+        for (int c = 0; c < Cin4 / 4; ++c) {
+          const f32x4 v = src[c], k0 = w0[c], k1 = w1[c];
+          a0 += v.x * k0.x + v.y * k0.y + v.z * k0.z + v.w * k0.w;
+          a1 += v.x * k1.x + v.y * k1.y + v.z * k1.z + v.w * k1.w;
+        }
+      }
+    }
+    float* o = out + i * out_cs + out_co;
+    o[0] = a0; o[1] = a1;
+  }
+}
+
+// cost volume: out[px][(dy+4)*9 + (dx+4)] = leaky_relu(mean_c c1[px][c] * w2[px + (dy, dx)][c], 0.1), zero outside.
+// One thread per (pixel, dy): nine running sums over dx.
+__global__ void pwc_costvol_kernel(const float* __restrict__ c1, const float* __restrict__ w2, int C, float* __restrict__ out,
+                                   int out_cs, int out_co, int N, int H, int W) {
+  const size_t total = (size_t)N * H * W * 9;
+  const float inv = 1.f / (float)C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int dyi = (int)(i % 9);
+    const size_t pix = i / 9;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+    const int yy = y + dyi - 4;
+    float s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.f;
+    if (yy >= 0 && yy < H) {
+      const f32x4* a = reinterpret_cast<const f32x4*>(c1 + pix * C);
+      for (int c = 0; c < C / 4; ++c) {
+        const f32x4 av = a[c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int xx = x + k - 4;
+          if (xx >= 0 && xx < W) {
+            const f32x4 bv = reinterpret_cast<const f32x4*>(w2 + ((size_t)(n * H + yy) * W + xx) * C)[c];
+            s[k] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
+          }
+        }
+      }
+    }
+    float* o = out + pix * out_cs + out_co + dyi * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const float v = s[k] * inv; o[k] = v >= 0.f ? v : 0.1f * v; }
+  }
+}
+
+// dense_image_warp: out[px][c] = bilinear(img, x + scale*u, y + scale*v); floor index clamped to [0, size-2], weight
+// clamped to [0, 1] (tf.contrib.image); evaluation order top = ax*(tr - tl) + tl, ... as tf.contrib's.
+__global__ void pwc_warp_kernel(const float* __restrict__ img, int C, const float* __restrict__ flow, int f_cs, int f_co,
+                                float scale, float* __restrict__ out, int N, int H, int W) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+    const float qx = (float)x + flow[pix * f_cs + f_co] * scale, qy = (float)y + flow[pix * f_cs + f_co + 1] * scale;
+    const float fx = fminf(fmaxf(floorf(qx), 0.f), (float)(W - 2)), fy = fminf(fmaxf(floorf(qy), 0.f), (float)(H - 2));
+    const float ax = fminf(fmaxf(qx - fx, 0.f), 1.f), ay = fminf(fmaxf(qy - fy, 0.f), 1.f);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const f32x4* b = reinterpret_cast<const f32x4*>(img + (size_t)n * H * W * C) + c;
+    const f32x4 tl = b[((size_t)y0 * W + x0) * C4], tr = b[((size_t)y0 * W + x0 + 1) * C4];
+    const f32x4 bl = b[((size_t)(y0 + 1) * W + x0) * C4], br = b[((size_t)(y0 + 1) * W + x0 + 1) * C4];
+    const f32x4 top = ax * (tr - tl) + tl, bot = ax * (br - bl) + bl;
+    reinterpret_cast<f32x4*>(out)[i] = ay * (bot - top) + top;
+  }
+}
+
+// copy a channel range (feature level c1 into the decoder's concatenated buffer)
+__global__ void pwc_copy_channels_kernel(const float* __restrict__ src, int C, float* __restrict__ dst, int d_cs, int d_co, size_t npix) {
+  const int C4 = C / 4;
+  const size_t total = npix * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / C4;
+    const int c = (int)(i % C4);
+    *reinterpret_cast<f32x4*>(dst + pix * d_cs + d_co + 4 * c) = reinterpret_cast<const f32x4*>(src)[i];
+  }
+}
+
+// Pre-processing of one frame: YUV uint8 [h, w, 3] -> network input [PH, PW, 4] (RGB / 255, channel 3 = 0, zero padding
+// below / right of the 2h x 2w image).  Double maths up to the uint8 truncation, as the reference's numpy / skimage do.
+__global__ void pwc_prep_kernel(const uint8_t* __restrict__ yuv, int h, int w, float* __restrict__ out, int PH, int PW,
+                                const ColorConsts cc) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)PH * PW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int X = (int)(i % PW), Y = (int)(i / PW);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (Y < 2 * h && X < 2 * w) {
+      // skimage resize x2, order 1, half-pixel centres, mode 'reflect' (= ndimage 'mirror'): even outputs take
+      // 0.25*in[i-1] + 0.75*in[i], odd ones 0.75*in[i] + 0.25*in[i+1]; in[-1] = in[1], in[n] = in[n-2]; rows first.
+      const int yi = Y >> 1, xi = X >> 1;
+      int ya = (Y & 1) ? yi : yi - 1, yb = (Y & 1) ? yi + 1 : yi;      // lower / upper source rows
+      int xa = (X & 1) ? xi : xi - 1, xb = (X & 1) ? xi + 1 : xi;
+      const double wya = (Y & 1) ? 0.75 : 0.25, wxa = (X & 1) ? 0.75 : 0.25;
+      if (ya < 0) ya = 1; if (yb >= h) yb = h - 2;
+      if (xa < 0) xa = 1; if (xb >= w) xb = w - 2;
+      double p[2][2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint8_t* s = yuv + ((size_t)(r ? yb : ya) * w + (c ? xb : xa)) * 3;
+          const float f[3] = {(float)s[0], (float)s[1], (float)s[2]};
+          yuv2rgb_d(cc, f, p[r][c]);
+        }
+      float rgb[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        // rows (axis 0) first, then columns, as the restated skimage passes do
+        const double ca = wya * p[0][0][k] + (1.0 - wya) * p[1][0][k];
+        const double cb = wya * p[0][1][k] + (1.0 - wya) * p[1][1][k];
+        const double v = wxa * ca + (1.0 - wxa) * cb;
+        rgb[k] = (float)(uint8_t)v / 255.f;                          // np.array(.., dtype=uint8) truncation; adapt_x / 255
+      }
+      o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// Post-processing: flow2 [FH, FW] (level-2 flow, channels at f_co of a buffer with pixel stride f_cs) -> out [h, w, 2]:
+// flow_pred = legacy bilinear x4 * 4 (model_pwcnet.py:1587-1590), cropped to 2h x 2w, skimage anti-aliased resize to
+// h x w (Gaussian sigma 0.5 radius 2 'mirror' on both axes, then the mean of samples 2i, 2i+1), / 2 (script :139).
+__global__ void pwc_flow_out_kernel(const float* __restrict__ f2, int f_cs, int f_co, int FH, int FW, float* __restrict__ out,
+                                    int h, int w) {
+  // effective 6-tap kernel of "Gaussian then average of two neighbours": e[t] = (g[t] + g[t-1]) / 2, t = -2..3
+  const double gk[5] = {3.3546262790251185e-04, 1.3533528323661270e-01, 1.0, 1.3533528323661270e-01, 3.3546262790251185e-04};
+  const double gs = gk[0] + gk[1] + gk[2] + gk[3] + gk[4];
+  float e[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) e[t] = (float)(0.5 * ((t < 5 ? gk[t] : 0.0) + (t > 0 ? gk[t - 1] : 0.0)) / gs);
+  const int H2 = 2 * h, W2 = 2 * w;
+  const size_t total = (size_t)h * w;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)(i / w);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 6; ++ty) {
+      int Y = 2 * y + ty - 2;
+      Y = Y < 0 ? -Y : (Y >= H2 ? 2 * H2 - 2 - Y : Y);
+      const float sy = (float)Y * 0.25f;
+      const int y0 = (int)sy, y1 = min(y0 + 1, FH - 1);
+      const float fy = sy - (float)y0;
+      float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+      for (int tx = 0; tx < 6; ++tx) {
+        int X = 2 * x + tx - 2;
+        X = X < 0 ? -X : (X >= W2 ? 2 * W2 - 2 - X : X);
+        const float sx = (float)X * 0.25f;
+        const int x0 = (int)sx, x1 = min(x0 + 1, FW - 1);
+        const float fx = sx - (float)x0;
+        const float* tl = f2 + ((size_t)y0 * FW + x0) * f_cs + f_co; const float* tr = f2 + ((size_t)y0 * FW + x1) * f_cs + f_co;
+        const float* bl = f2 + ((size_t)y1 * FW + x0) * f_cs + f_co; const float* br = f2 + ((size_t)y1 * FW + x1) * f_cs + f_co;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float top = tl[k] + (tr[k] - tl[k]) * fx, bot = bl[k] + (br[k] - bl[k]) * fx;
+          const float v = (top + (bot - top) * fy) * 4.f;
+          if (k == 0) r0 += e[tx] * v; else r1 += e[tx] * v;
+        }
+      }
+      a0 += e[ty] * r0; a1 += e[ty] * r1;
+    }
+    out[i * 2] = a0 * 0.5f;
+    out[i * 2 + 1] = a1 * 0.5f;
+  }
+}
+
+// flow buffer (pixel stride 4) -> dense [px, 2]
+__global__ void stitch_free_copy2_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t npix) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    dst[2 * i] = src[4 * i];
+    dst[2 * i + 1] = src[4 * i + 1];
+  }
+}
+
+// flow_pred = tf.image.resize_bilinear(flow2, x4) * 4 (model_pwcnet.py:1587-1590), TF-1.13 legacy kernel
+__global__ void pwc_upsample4_kernel(const float* __restrict__ f2, int f_cs, int f_co, int FH, int FW, float* __restrict__ out) {
+  const int H = 4 * FH, W = 4 * FW;
+  const size_t total = (size_t)H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W), Y = (int)(i / W);
+    const float sy = (float)Y * 0.25f, sx = (float)X * 0.25f;
+    const int y0 = (int)sy, y1 = min(y0 + 1, FH - 1), x0 = (int)sx, x1 = min(x0 + 1, FW - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float tl = f2[((size_t)y0 * FW + x0) * f_cs + f_co + k], tr = f2[((size_t)y0 * FW + x1) * f_cs + f_co + k];
+      const float bl = f2[((size_t)y1 * FW + x0) * f_cs + f_co + k], br = f2[((size_t)y1 * FW + x1) * f_cs + f_co + k];
+      const float top = tl + (tr - tl) * fx, bot = bl + (br - bl) * fx;
+      out[i * 2 + k] = (top + (bot - top) * fy) * 4.f;
+    }
+  }
+}
+
+}  // namespace fisr

@@ -27,6 +27,9 @@ EXPORTS = [
     "fisr_op_upsample2", "fisr_bench_conv",
     "fisr_comm_unique_id", "fisr_comm_init", "fisr_comm_rank", "fisr_comm_size", "fisr_comm_allgather",
     "fisr_comm_sendrecv", "fisr_comm_destroy",
+    "fisr_pwc_create", "fisr_pwc_destroy", "fisr_pwc_last_error", "fisr_pwc_num_variables", "fisr_pwc_variable",
+    "fisr_pwc_set_weight", "fisr_pwc_finalize", "fisr_pwc_flow_workspace_bytes", "fisr_pwc_flow_pair",
+    "fisr_pwc_nn_workspace_bytes", "fisr_pwc_nn", "fisr_pwc_prep", "fisr_pwc_flow_out",
 ]
 COMM_ID_BYTES = 128
 
@@ -113,6 +116,22 @@ def lib():
     L.fisr_comm_sendrecv.argtypes = [vp, vp, vp, c_size_t, c_int, vp]
     L.fisr_comm_destroy.argtypes = [vp]
     L.fisr_comm_destroy.restype = None
+    L.fisr_pwc_create.argtypes = [POINTER(vp), c_int]
+    L.fisr_pwc_destroy.argtypes = [vp]
+    L.fisr_pwc_destroy.restype = None
+    L.fisr_pwc_last_error.argtypes = [vp]
+    L.fisr_pwc_last_error.restype = c_char_p
+    L.fisr_pwc_variable.argtypes = [c_int, POINTER(c_char_p), POINTER(c_int64)]
+    L.fisr_pwc_set_weight.argtypes = [vp, c_char_p, POINTER(c_float), POINTER(c_int64), c_int]
+    L.fisr_pwc_finalize.argtypes = [vp]
+    L.fisr_pwc_flow_workspace_bytes.argtypes = [vp, c_int, c_int]
+    L.fisr_pwc_flow_workspace_bytes.restype = c_size_t
+    L.fisr_pwc_flow_pair.argtypes = [vp, vp, vp, c_int, c_int, vp, vp, vp, c_size_t, vp]
+    L.fisr_pwc_nn_workspace_bytes.argtypes = [vp, c_int, c_int]
+    L.fisr_pwc_nn_workspace_bytes.restype = c_size_t
+    L.fisr_pwc_nn.argtypes = [vp, vp, c_int, c_int, vp, POINTER(vp), vp, c_size_t, vp]
+    L.fisr_pwc_prep.argtypes = [vp, c_int, c_int, vp, c_int, c_int, vp]
+    L.fisr_pwc_flow_out.argtypes = [vp, c_int, c_int, vp, c_int, c_int, vp]
     _lib = L
     return L
 

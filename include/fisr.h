@@ -190,6 +190,39 @@ int fisr_comm_allgather(fisr_comm* comm, const void* send, void* recv, size_t by
 int fisr_comm_sendrecv(fisr_comm* comm, const void* send, void* recv, size_t bytes, int peer, void* stream);
 void fisr_comm_destroy(fisr_comm* comm);
 
+/* ---- on-GPU optical flow (cfg5 of BASELINE.json): PWC-Net-large as
+ * `FISR_for_video_Compute_Flow` runs it before FISRnet (main.py:207-211;
+ * FISR_tfoptflow/FISR_for_video_pwcnet_predict_from_img_test.py:84-147 over FISR_tfoptflow/model_pwcnet.py:1525-1593 with
+ * use_dense_cx, use_res_cx, pyr_lvls 6, flow_pred_lvl 2).  Weight seam: the TF variable names of the reference graph
+ * ('pwcnet/featpyr/conv1a/kernel' [3,3,3,16] HWIO, '.../bias', 'pwcnet/predict_flow/conv6_0/kernel', 'pwcnet/ctxt/dc_conv21/kernel',
+ * 'pwcnet/upsample/up_feat3/kernel' [4,4,2,Cin], ...): what `pwcnet.ckpt-595000` (script :31) holds. ---- */
+typedef struct fisr_pwc fisr_pwc;
+int fisr_pwc_create(fisr_pwc** out, int device_id);
+void fisr_pwc_destroy(fisr_pwc* ctx);
+const char* fisr_pwc_last_error(const fisr_pwc* ctx);
+/* the 182 variables the inference graph needs: count, then name/shape of variable i (returns the rank) */
+int fisr_pwc_num_variables(void);
+int fisr_pwc_variable(int i, const char** name, int64_t* shape4);
+/* host float32 tensor in TF layout; unknown names (optimizer slots, ...) are ignored with return 1 */
+int fisr_pwc_set_weight(fisr_pwc* ctx, const char* tf_var_name, const float* host, const int64_t* shape, int rank);
+int fisr_pwc_finalize(fisr_pwc* ctx);   /* FISR_EMISSING names the first absent variable */
+/* One iteration of the script's loop (:118-140): two YUV uint8 frames [h,w,3] (device) -> YUV->RGB, x2 scikit-image
+ * up-resize, uint8 truncation, /255, pad to 64 (adapt_x, model_pwcnet.py:371-411), the network in both directions,
+ * x4 bilinear * 4 (:1587-1590), crop, anti-aliased scikit-image down-resize, / 2 -> flow_ab, flow_ba [h,w,2] float32
+ * LR pixels (device): pred[fr, 0] and pred[fr, 1] of the script's 5-D .flo. */
+size_t fisr_pwc_flow_workspace_bytes(const fisr_pwc* ctx, int h, int w);
+int fisr_pwc_flow_pair(fisr_pwc* ctx, const uint8_t* yuv_a, const uint8_t* yuv_b, int h, int w, float* flow_ab,
+                       float* flow_ba, void* workspace, size_t workspace_bytes, void* stream);
+/* The network alone (model_pwcnet.py:1525-1593) on a prepared pair: im [2,H,W,4] device float32 (image a, image b;
+ * RGB/255 and a zero 4th channel; H, W multiples of 64).  flow_pred [2,H,W,2] (a->b, b->a; nullable); pyr: 10 nullable
+ * device pointers, refined flows of levels 6..2 [H/2^l, W/2^l, 2] for a->b then b->a (nullable). */
+size_t fisr_pwc_nn_workspace_bytes(const fisr_pwc* ctx, int H, int W);
+int fisr_pwc_nn(fisr_pwc* ctx, const float* im, int H, int W, float* flow_pred, float* const* pyr, void* workspace,
+                size_t workspace_bytes, void* stream);
+/* the two pre/post-processing kernels on their own (parity tests): yuv [h,w,3] -> out [PH,PW,4]; flow2 [FH,FW,2] -> out [h,w,2] */
+int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream);
+int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

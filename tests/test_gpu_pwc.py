@@ -1,0 +1,140 @@
+"""GPU parity of the on-GPU optical flow (PWC-Net-large, cfg5 of BASELINE.json; run with `-m gpu`): the HIP path through
+the `fisr_pwc_*` C-ABI against the CPU oracle (oracle/pwcnet_oracle.py, float64) on seeded synthetic weights.
+"Parity unpinned" for the network arithmetic (TensorFlow, core_warp, core_costvol and the checkpoint are absent; see
+the oracle's header); the two scikit-image resizes are pinned against scikit-image 0.18.3 fixtures."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import pwcnet_oracle as P  # noqa: E402
+from fisr_amd import lib as flib  # noqa: E402
+from fisr_amd import pwcnet  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def pwc():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    W = pwcnet.synthetic_weights(595000, flow_gain=3.0)
+    net = pwcnet.PWCNet("cuda:0")
+    net.set_weights(W)
+    yield net, W
+    net.close()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_variable_inventory_matches_oracle():
+    assert list(pwcnet.variable_shapes().items()) == list(P.variable_shapes().items())
+    assert len(pwcnet.variable_shapes()) == 182
+
+
+def test_prep_kernel_vs_oracle(gold_dir):
+    """YUV uint8 -> RGB -> x2 scikit-image resize -> uint8 truncation -> /255 -> zero pad to 64 (script :121-131,
+    adapt_x model_pwcnet.py:399-411).  The truncation makes a value within rounding of an integer flip by 1/255:
+    allowed on at most 1e-4 of the samples."""
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    key = [k for k in g.files if g[k].ndim == 4 and g[k].dtype == np.uint8][0]
+    yuv = g[key][0]                                           # [96, 96, 3] uint8
+    rng = np.random.default_rng(3)
+    for frame in (yuv, rng.integers(0, 256, (40, 72, 3), dtype=np.uint8)):
+        h, w = frame.shape[:2]
+        PH, PW = -(-2 * h // 64) * 64, -(-2 * w // 64) * 64
+        out = torch.full((PH, PW, 4), float("nan"), device="cuda")
+        flib.check(flib.lib().fisr_pwc_prep(ctypes.c_void_p(torch.from_numpy(frame).cuda().data_ptr()), h, w,
+                                            ctypes.c_void_p(out.data_ptr()), PH, PW, _stream()))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        exp = np.zeros((PH, PW, 4), np.float32)
+        exp[:2 * h, :2 * w, :3] = np.array(P.resize_up2_skimage(P.yuv2rgb(frame.astype(np.float32))), dtype=np.uint8).astype(np.float32) / 255.0
+        d = np.abs(got - exp)
+        assert not np.isnan(got).any()
+        assert d.max() <= 1.0 / 255 + 1e-7 and (d > 1e-7).mean() <= 1e-4, (d.max(), (d > 1e-7).mean())
+        assert not got[2 * h:].any() and not got[:, 2 * w:].any() and not got[..., 3].any()
+
+
+def test_flow_out_kernel_vs_oracle():
+    """x4 legacy bilinear * 4 (model_pwcnet.py:1587-1590), crop to 2h x 2w, scikit-image anti-aliased /2 resize, / 2."""
+    rng = np.random.default_rng(4)
+    for (h, w) in ((40, 72), (96, 160)):
+        FH, FW = -(-2 * h // 64) * 16, -(-2 * w // 64) * 16
+        f2 = (rng.standard_normal((FH, FW, 2)) * 3).astype(np.float32)
+        out = torch.empty((h, w, 2), device="cuda")
+        flib.check(flib.lib().fisr_pwc_flow_out(ctypes.c_void_p(torch.from_numpy(f2).cuda().data_ptr()), FH, FW,
+                                                ctypes.c_void_p(out.data_ptr()), h, w, _stream()))
+        torch.cuda.synchronize()
+        up = P.resize_bilinear_legacy(torch.from_numpy(f2).double().permute(2, 0, 1)[None], 4) * 4
+        up = up[0].permute(1, 2, 0).numpy()[None, :2 * h, :2 * w]
+        exp = P.resize_down2_skimage_aa(up)[0] / 2.0
+        assert np.abs(out.cpu().numpy() - exp).max() < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(64, 128), (128, 192)])
+def test_pwcnet_nn_vs_oracle(pwc, shape):
+    """The network alone, both directions, every pyramid level and the final x4 flow against the float64 oracle."""
+    net, W = pwc
+    H, Wd = shape
+    rng = np.random.default_rng(H)
+    base = rng.random((H // 8 + 2, Wd // 8 + 2, 3))
+    img = np.kron(base, np.ones((8, 8, 1)))                   # blocky texture ...
+    a = img[4:4 + H, 4:4 + Wd] * 0.8 + rng.random((H, Wd, 3)) * 0.2
+    b = img[2:2 + H, 7:7 + Wd] * 0.8 + rng.random((H, Wd, 3)) * 0.2      # ... shifted: a real displacement to find
+    im = np.zeros((2, H, Wd, 4), np.float32)
+    im[0, ..., :3], im[1, ..., :3] = a, b
+    pairs = np.stack([np.stack([im[0, ..., :3], im[1, ..., :3]]), np.stack([im[1, ..., :3], im[0, ..., :3]])])
+    taps = {}
+    ref_pred, ref_pyr = P.nn(torch.from_numpy(pairs).double(), W, taps)
+    got_pred, got_pyr = net.nn(torch.from_numpy(im).cuda(), want_pyramid=True)
+    torch.cuda.synchronize()
+    for d in range(2):
+        for k, lvl in enumerate(range(6, 1, -1)):
+            exp = ref_pyr[k][d].permute(1, 2, 0).numpy()
+            got = got_pyr[d][k].cpu().numpy()
+            err = np.abs(got - exp).max()
+            print(f"dir {d} flow{lvl}: max|err| {err:.2e}  (|flow| max {np.abs(exp).max():.3f})")
+            assert err < 3e-4, (d, lvl, err)
+        err = np.abs(got_pred[d].cpu().numpy() - ref_pred[d].numpy()).max()
+        print(f"dir {d} flow_pred: max|err| {err:.2e} (|flow| max {np.abs(ref_pred[d].numpy()).max():.3f})")
+        assert err < 1.5e-3
+
+
+def test_flow_pair_end_to_end_vs_oracle(pwc, gold_dir):
+    """One iteration of the reference script's loop on two real LR frames (scene1 crop): YUV uint8 in, LR-pixel flows
+    in both directions out."""
+    net, W = pwc
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    key = [k for k in g.files if g[k].ndim == 4 and g[k].dtype == np.uint8][0]
+    fa, fb = g[key][0], g[key][1]
+    exp = P.compute_flow_pair(fa, fb, W)
+    ab, ba = net.flow_pair(torch.from_numpy(fa), torch.from_numpy(fb))
+    torch.cuda.synchronize()
+    for name, got, e in (("a->b", ab, exp[0]), ("b->a", ba, exp[1])):
+        err = np.abs(got.cpu().numpy() - e).max()
+        print(f"{name}: max|err| {err:.2e}, |flow| max {np.abs(e).max():.3f}")
+        # a uint8 flip in the pre-processing (see test_prep_kernel_vs_oracle) moves the flow by ~1e-3 at most
+        assert err < 5e-3
+    flows = net.compute_flow([torch.from_numpy(g[key][k]) for k in range(3)])
+    assert tuple(flows.shape) == (2, 2, 96, 96, 2) and torch.isfinite(flows).all()
+    assert torch.equal(flows[0, 0], ab) and torch.equal(flows[0, 1], ba)
+
+
+def test_pwc_errors(pwc):
+    net, W = pwc
+    with pytest.raises(ValueError):
+        net.nn(torch.zeros((2, 64, 64, 3)))
+    with pytest.raises(Exception):
+        net.nn(torch.zeros((2, 96, 64, 4)))              # not a multiple of 64
+    bad = dict(W)
+    bad.pop("pwcnet/ctxt/dc_conv27/bias")
+    n2 = pwcnet.PWCNet("cuda:0")
+    with pytest.raises(KeyError):
+        n2.set_weights(bad)
+    n2.close()

@@ -233,3 +233,35 @@ def test_torch_cpu_twin_matches_numpy_oracle(syn_weights):
     for a, b in zip(got, ref):
         assert a.shape == b.shape
         assert np.abs(a - b).max() < 1e-12
+
+
+def test_pwc_oracle_resizes_pinned_to_scikit_image(gold_dir):
+    """The two scikit-image resizes of the reference's flow script (FISR_for_video_pwcnet_predict_from_img_test.py
+    :129-130, :139) as restated in oracle/pwcnet_oracle.py against outputs of a real scikit-image 0.18.3
+    (oracle/make_golden_pwc.py, run with the anaconda interpreter of the build image)."""
+    pytest.importorskip("torch")
+    import pwcnet_oracle as P
+    g = np.load(os.path.join(gold_dir, "pwc_resize.npz"))
+    assert np.abs(P.resize_up2_skimage(g["rgb"]) - g["up"]).max() < 1e-9
+    assert np.abs(P.resize_down2_skimage_aa(g["flow"]) - g["down"]).max() < 2e-6     # skimage returns float32 here
+    # the script's YUV2RGB is the warp script's (pinned to the imported reference function in ref_utils.npz)
+    yuv = np.random.default_rng(2).integers(0, 256, (7, 9, 3)).astype(np.float32)
+    assert np.abs(P.yuv2rgb(yuv) - O.yuv2rgb_matlab(yuv)).max() < 1e-9      # same constants as utils.py:106-115 (pinned)
+
+
+def test_pwc_oracle_network_smoke():
+    """Shapes / structure of the PWC-Net restatement: 182 variables, 14.08 M parameters, flows of levels 6..2 and a
+    full-resolution prediction; flipping the pair negates nothing by construction but must change the result."""
+    torch = pytest.importorskip("torch")
+    import pwcnet_oracle as P
+    shapes = P.variable_shapes()
+    assert len(shapes) == 182 and sum(int(np.prod(s)) for s in shapes.values()) == 14079050
+    assert shapes["pwcnet/predict_flow/conv6_0/kernel"] == (3, 3, 81, 128)
+    assert shapes["pwcnet/predict_flow/conv2_4/kernel"] == (3, 3, 81 + 32 + 4 + 128 + 128 + 96 + 64, 32)
+    assert shapes["pwcnet/upsample/up_feat3/kernel"] == (4, 4, 2, 81 + 64 + 4 + 448)
+    W = P.synthetic_weights()
+    x = torch.from_numpy(np.random.default_rng(0).random((1, 2, 64, 64, 3)))
+    pred, pyr = P.nn(x, W)
+    assert tuple(pred.shape) == (1, 64, 64, 2) and [tuple(p.shape[2:]) for p in pyr] == [(1, 1), (2, 2), (4, 4), (8, 8), (16, 16)]
+    pred2, _ = P.nn(torch.flip(x, dims=[1]), W)
+    assert float((pred - pred2).abs().max()) > 1e-6
