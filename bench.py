@@ -308,6 +308,50 @@ def time_warp(net, wl, reps=8):
     return rec
 
 
+def time_flow_pipeline(net, wl, torch, local_rank, reps=2):
+    """cfg5 of BASELINE.json ("FISR_for_video end-to-end: on-GPU PWC-Net flow + warp + FISRnet"): the same 5-frame stack
+    with NOTHING pre-made -- PWC-Net-large in both directions for the 4 frame pairs (fp32, fisr_amd/pwcnet.py), the 8
+    frame warps, then the timed step of this engine.  Seeded stand-in PWC-Net weights (no checkpoint in the reference tree)."""
+    from fisr_amd import pwcnet
+    pwc = pwcnet.PWCNet(f"cuda:{local_rank}")
+    pwc.set_weights(pwcnet.synthetic_weights(595000))
+    dev = wl.dev
+
+    def flows():
+        out = []
+        for p in range(4):
+            ab, ba = pwc.flow_pair(wl.frames[p], wl.frames[p + 1])
+            out += [ab, ba]
+        return out
+
+    fl = flows()
+    torch.cuda.synchronize(dev)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    for _ in range(reps):
+        fl = flows()
+    e[1].record()
+    keep_flows, keep_warps = wl.flows, wl.warps
+    wl.flows = fl
+    for _ in range(reps):
+        wl.premake_warps(net)
+    e[2].record()
+    for _ in range(reps):
+        wl.step(net)
+    e[3].record()
+    torch.cuda.synchronize(dev)
+    wl.flows, wl.warps = keep_flows, keep_warps
+    pwc.close()
+    t_flow, t_warp, t_net = (e[i].elapsed_time(e[i + 1]) / reps for i in range(3))
+    tot = t_flow + t_warp + t_net
+    # 182-variable PWC-Net-large at 2176x3840 (x2 up-scaled, padded to 64): ~3.5 TFLOP per direction
+    return {"what": "5-frame 1080p stack, flow (4 pairs x 2 directions, PWC-Net-large on the x2 up-scaled frames, fp32) + "
+                    "8 warps + the timed FISRnet step",
+            "flow_ms": round(t_flow, 2), "warp_ms": round(t_warp, 3), "fisrnet_ms": round(t_net, 2),
+            "value": round(UNIQUE_PER_STACK / (tot * 1e-3), 3), "unit": "frames/s", "flow_dtype": "f32",
+            "weights": "synthetic seeded (PWC-Net checkpoint absent from the reference tree)"}
+
+
 def oracle_tile_check(net, torch):
     """One 544x992 reference tile through this engine against the fp64-oracle values committed on a sparse
     grid (tests/golden/model_544x992_sparse.npz, made by oracle/make_golden_fullsize.py), with the PSNR
@@ -424,6 +468,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle-tile checks (profiling runs: keeps the "
                     "per-kernel averages of rocprofv3 free of the small one-tile launches)")
     ap.add_argument("--no-gather", action="store_true", help="frame-parallel: skip the RCCL gather of the output frames")
+    ap.add_argument("--no-flow", action="store_true", help="skip the cfg5 measurement (on-GPU PWC-Net flow + warp + FISRnet)")
     args = ap.parse_args()
     patch = tuple(int(v) for v in args.patch.strip("()").split(","))
 
@@ -506,6 +551,12 @@ def main():
 
     parity_oracle = None
     other = {}
+    cfg5 = None
+    if solo and not args.no_flow:
+        try:
+            cfg5 = time_flow_pipeline(net, wl, torch, local_rank)
+        except Exception as e:                                      # noqa: BLE001 -- must not kill the headline line
+            cfg5 = {"error": repr(e)}
     if solo:
         parity_oracle = None if args.no_parity else oracle_tile_check(net, torch)
         wl.step(net)
@@ -578,7 +629,7 @@ def main():
                        "forwards_per_s": round(stacks * 3 * args.steps / elapsed, 3),
                        "achieved_tflops_whole_step": round(stacks * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
             "roofline": roofline, "cpu_baseline": cpu_port, "cpu_baseline_onednn": cpu_onednn,
-            "parity_vs_oracle": parity_oracle, "other_precisions": other or None,
+            "parity_vs_oracle": parity_oracle, "cfg5_flow_pipeline": cfg5, "other_precisions": other or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -81,6 +81,39 @@ def warp_img(net, frame_paths, flow, out_path=None):
     return pred
 
 
+def compute_flow(net, args):
+    """`FISR_for_video_Compute_Flow(args)` (FISR_tfoptflow/FISR_for_video_pwcnet_predict_from_img_test.py:84-147) on the
+    GPU: the first frame_num YUV frames of the folder, PWC-Net-large in both directions per consecutive pair, written
+    as the reference's 5-D .flo `<folder>/<folder name>_test_ss1_fr<frame_num>.flo` [frame_num-1, 2, h, w, 2].
+    Returns the file name."""
+    import torch
+    from . import pwcnet
+    paths = sorted_pngs(args.frame_folder_path)
+    h, w = args.FISR_input_size
+    num_fr = args.frame_num
+    if len(paths) < num_fr:
+        raise FileNotFoundError(f"{args.frame_folder_path}: {len(paths)} frames, need {num_fr}")
+    pwc = pwcnet.PWCNet(str(net.device))
+    try:
+        if getattr(args, "synthetic_weights", None) is not None:
+            pwc.set_weights(pwcnet.synthetic_weights(595000 + int(args.synthetic_weights)))
+        else:
+            ck = getattr(args, "pwc_ckpt", None)
+            if not ck or not (os.path.isfile(ck) or os.path.isfile(ck + ".index")):
+                raise FileNotFoundError(f"PWC-Net weights not found at {ck!r} (the reference downloads them separately, "
+                                        "script :31); pass --pwc_ckpt, --flow_file or --synthetic_weights")
+            pwc.load(ck)
+        frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[:num_fr]]
+        pred = pwc.compute_flow(frames).cpu().numpy()
+    finally:
+        pwc.close()
+    print(pred.shape)
+    folder = args.frame_folder_path.rstrip("/")
+    name = os.path.join(folder, os.path.basename(folder) + "_test_ss{}_fr{}.flo".format(1, num_fr))
+    fio.write_flow(pred, name)
+    return name
+
+
 def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_test_in_seq, H, W, num_patch):
     """Device tensors for one 3-frame window (FISRnet.py:803-843)."""
     import torch

@@ -9,8 +9,11 @@ Differences from the reference, all deliberate:
     "(2,2)" into integer tuples (the reference's `type=tuple` turns a CLI string into a tuple of
     characters, main.py:89-103); `--scale_factor` is an int (main.py:29 makes 2.0).
   * `--phase train` is out of scope (inference-only build) and exits with an error.
-  * `--phase FISR_for_video` needs a pre-computed flow file (`--flow_file`): the PWC-Net flow
-    estimator (main.py:210) is a "next" row; the frame warp (main.py:213) runs on the GPU.
+  * `--phase FISR_for_video` computes the optical flow on the GPU like the reference (main.py:210): PWC-Net-large
+    (fisr_amd/pwcnet.py), weights from `--pwc_ckpt` (TF bundle prefix or .npz; the reference hard-codes
+    './models/pwcnet-lg-6-2-multisteps-chairsthingsmix/pwcnet.ckpt-595000') or seeded stand-ins with
+    `--synthetic_weights`; the flow is written as the reference's 5-D `.flo` next to the frames.  `--flow_file` skips
+    the estimator and uses a pre-computed file.  The frame warp (main.py:213) runs on the GPU too.
   * extra flags: `--precision {fp32,bf16x3,f16f8,fp16}` (default fp32, the reference's arithmetic),
     `--device`, `--synthetic_weights SEED`, `--no_batch_tiles` (one tile per forward, the reference's
     schedule: smallest workspace).
@@ -71,7 +74,9 @@ def parse_args(argv=None):
                         "'frame' = windows round-robin over the GPUs; 'tile' = the test_patch tiles of a window on "
                         "different GPUs with an RCCL all-gather of the 32-px halos and of the uint8 output tiles "
                         "(N must be a multiple of the tile count: 8 GPUs = 2 windows x 2x2 tiles)")
-    p.add_argument("--flow_file", type=str, default=None, help="pre-computed 5-D .flo for FISR_for_video")
+    p.add_argument("--flow_file", type=str, default=None, help="pre-computed 5-D .flo for FISR_for_video (default: PWC-Net on the GPU)")
+    p.add_argument("--pwc_ckpt", type=str, default="./models/pwcnet-lg-6-2-multisteps-chairsthingsmix/pwcnet.ckpt-595000",
+                   help="PWC-Net weights: TF checkpoint-V2 bundle prefix or .npz keyed by the TF variable names")
     p.add_argument("--warp_file", type=str, default=None, help="pre-computed warp (.mat/.npy); default: warp on the GPU")
     p.add_argument("--synthetic_weights", type=int, default=None, metavar="SEED",
                    help="use seeded stand-in weights instead of a checkpoint (no checkpoint ships with the reference)")
@@ -120,16 +125,18 @@ def main(argv=None):
         print(" [*] Test finished!")
         return 0
     # FISR_for_video (main.py:207-235)
-    if not args.flow_file:
-        print("FISR_for_video needs --flow_file (the on-GPU PWC-Net flow estimator is a 'next' row)", file=sys.stderr)
-        return 2
+    flow_file = args.flow_file
+    if not flow_file:
+        # FISR_for_video_Compute_Flow (main.py:210): PWC-Net-large on the GPU, both directions of every frame pair
+        flow_file = harness.compute_flow(net, args)
+        print("[*] Flow file saved!")
     warp_file = args.warp_file
     if warp_file is None:
-        flow = fio.read_flo_file_5dim(args.flow_file)
+        flow = fio.read_flo_file_5dim(flow_file)
         frames = harness.sorted_pngs(args.frame_folder_path)
         warp_file = harness.warp_img(net, frames, flow)          # ndarray, stays in memory
         print("[*] Warp done on the GPU")
-    net.FISR_for_video(args.flow_file, warp_file)
+    net.FISR_for_video(flow_file, warp_file)
     print(" [*] FISR finished!")
     return 0
 

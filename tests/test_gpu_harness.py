@@ -119,6 +119,39 @@ def test_phase_fisr_for_video(scene):
     assert (yuv != exp).mean() < 0.02
 
 
+def test_phase_fisr_for_video_with_on_gpu_flow(scene):
+    """cfg5 of BASELINE.json end to end, as the reference's main.py:207-235 runs it: no pre-computed flow -- PWC-Net on
+    the GPU (both directions per pair, reference .flo written next to the frames), GPU warp, FISRnet, PNGs.  PWC-Net
+    weights: seeded stand-ins, or an .npz / TF bundle through --pwc_ckpt (the reference's checkpoint is not in its
+    tree).  The written .flo must be what the flow oracle computes from the same frames and weights."""
+    import pwcnet_oracle as P
+    from fisr_amd import pwcnet
+    r = scene["root"]
+    ck = r / "pwc.npz"
+    Wp = pwcnet.synthetic_weights(595000)
+    np.savez(str(ck), **Wp)
+    rc = fmain.main(["--phase", "FISR_for_video", "--frame_folder_path", str(r / "LR_LFR"), "--pwc_ckpt", str(ck),
+                     "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(r / "test_img_dir"),
+                     "--text_dir", str(r / "text_dir"), "--log_dir", str(r / "logdir"),
+                     "--FISR_test_patch", "1,1", "--FISR_input_size", "96,96", "--frame_num", "5", "--precision", "fp32"])
+    assert rc == 0
+    flo = r / "LR_LFR" / "LR_LFR_test_ss1_fr5.flo"
+    assert flo.is_file()
+    flow = fio.read_flo_file_5dim(str(flo))
+    assert flow.shape == (4, 2, 96, 96, 2)
+    frames = scene["g"]["frames"]
+    exp = P.compute_flow_pair(frames[1], frames[2], Wp)
+    assert np.abs(flow[1] - exp).max() < 5e-3
+    out_dir = r / "LR_LFR" / "FISR_frames"
+    assert sorted(os.listdir(out_dir)) == sorted([f"pred_{k}.png" for k in range(7)] + [f"pred_YUV_{k}.png" for k in range(7)])
+    # without weights the phase must fail loudly, not fall back to anything
+    with pytest.raises(FileNotFoundError):
+        fmain.main(["--phase", "FISR_for_video", "--frame_folder_path", str(r / "LR_LFR"), "--pwc_ckpt", str(r / "nope"),
+                    "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(r / "test_img_dir"),
+                    "--text_dir", str(r / "text_dir"), "--log_dir", str(r / "logdir"),
+                    "--FISR_test_patch", "1,1", "--FISR_input_size", "96,96", "--frame_num", "5"])
+
+
 def test_phase_test_full_size_precisions_agree(tmp_path_factory, syn_weights):
     """cfg2/cfg3 plumbing at full size: `--phase test` on one synthetic 1080x1920 5-frame scene with the
     reference's default 2x2 tiling (crop to 1024x1920, four 544x992 tiles, 2048x3840 outputs).  The exact
