@@ -101,3 +101,73 @@ def test_full_size_tile_second_scene_spec_weights(gold_dir):
         print(f"spec weights, scene 2, {engine}: max|err| {err:.3e} dPSNR {shift:.2e} dB")
         assert err <= rel_tol * max(1.0, float(np.abs(exp).max())), (engine, err)
         assert shift <= db_tol, (engine, shift)
+
+
+def test_full_size_ten_scenes_fast_engines_vs_fp32(syn_weights):
+    """cfg3 of BASELINE.json at FULL size (the data set is absent: ten synthetic 1080x1920 scenes, crop 1024x1920, the
+    reference's 2x2 tiles with 32-px halo, 3 windows each = 30 windows of 2048x3840x9), engine level (no PNG files, so
+    the test stays in seconds): the exact-fp32 engine is the reference, pseudo ground truth = its prediction + Gaussian
+    noise at the published operating point (README.md:97); the shipped fp32 (Winograd) engine and the split-precision
+    engines must score within +-0.02 dB PSNR / 1e-3 SSIM of it on every window (PSNR: 3 YUV channels of a frame jointly,
+    FISRnet.py:883-889; SSIM: the SSIM_PIL restatement on the uint8 frames, on the GPU)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import math
+    dev = torch.device("cuda:0")
+    ref = FISRnet(device="cuda:0", precision="fp32d")
+    ref.set_weights(syn_weights)
+    engines = {}
+    for p in ("fp32", "bf16x3", "f16f8"):
+        engines[p] = FISRnet(device="cuda:0", precision=p)
+        engines[p].set_weights(syn_weights)
+    gen = torch.Generator(device=dev).manual_seed(2024)
+    worst = {p: [0.0, 0.0] for p in engines}
+    sig = (10 ** (-37.86 / 20), 10 ** (-48.07 / 20), 10 ** (-37.86 / 20))
+    for sc in range(10):
+        # a 5-frame scene: smooth random content moving by a few pixels per frame, smooth flows, GPU-warped neighbours
+        coarse = torch.rand((1, 3, 1080 // 8 + 8, 1920 // 8 + 8), generator=gen, device=dev)
+        big = torch.nn.functional.interpolate(coarse, scale_factor=8, mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+        frames = []
+        for k in range(5):
+            f = big[8 + 3 * k:8 + 3 * k + 1080, 16 + 5 * k:16 + 5 * k + 1920] + 0.02 * torch.randn((1080, 1920, 3), generator=gen, device=dev)
+            frames.append((f.clamp(0, 1) * 255).to(torch.uint8).contiguous())
+        fc = torch.randn((8, 2, 1080 // 32 + 2, 1920 // 32 + 2), generator=gen, device=dev) * 4
+        flows = torch.nn.functional.interpolate(fc, scale_factor=32, mode="bilinear", align_corners=False)[:, :, :1080, :1920].permute(0, 2, 3, 1).contiguous()
+        warps = []
+        for p in range(4):
+            warps.append(ref.warp(frames[p + 1], flows[2 * p]))
+            warps.append(ref.warp(frames[p], flows[2 * p + 1]))
+        for s in range(3):
+            inp = ref.pack_input(frames[s:s + 3], list(flows[2 * s:2 * s + 4]), warps[2 * s:2 * s + 4], 1024, 1920)
+            base = ref.forward_tiled(inp, (2, 2)).clamp(0, 1)
+            noise = torch.randn(base.shape, generator=gen, device=dev)
+            gt = base.clone()
+            for f in range(3):
+                gt[..., 3 * f:3 * f + 3] += sig[f] * noise[..., 3 * f:3 * f + 3]
+            gt_u8 = (gt.clamp(0, 1) * 255).to(torch.uint8)
+            gtf = gt_u8.float() / 255
+
+            def score(pred):
+                pred = pred.clamp(0, 1)
+                yuv, _ = ref.unpack_output(pred, want_rgb=False)
+                out = []
+                for f in range(3):
+                    mse = float(((pred[..., 3 * f:3 * f + 3] - gtf[..., 3 * f:3 * f + 3]).double() ** 2).mean())
+                    out.append((10 * math.log10(1.0 / mse), ref.ssim_u8(yuv, gt_u8, coff=3 * f)))
+                return out
+
+            s_ref = score(base)
+            for p, eng in engines.items():
+                got = score(eng.forward_tiled(inp, (2, 2)))
+                for (pa, sa), (pb, sb) in zip(got, s_ref):
+                    worst[p][0] = max(worst[p][0], abs(pa - pb))
+                    worst[p][1] = max(worst[p][1], abs(sa - sb))
+            del base, gt, gtf, noise
+        torch.cuda.empty_cache()
+    for p, (dp, ds) in worst.items():
+        print(f"10 scenes x 3 windows x 3 frames at 2048x3840, {p} vs exact fp32: max |dPSNR| {dp:.2e} dB, max |dSSIM| {ds:.2e}")
+        assert dp <= 0.02 and ds <= 1e-3, (p, dp, ds)
+    assert 36.5 < s_ref[0][0] < 39 and 46 < s_ref[1][0] < 50.5      # the ground truth sits at the published operating point
+    ref.close()
+    for e in engines.values():
+        e.close()
