@@ -160,9 +160,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs p)
   const float sgn = t_rh ? -1.f : 1.f;
   const int t_roff = ((2 * t_ty) * HALO_W + 2 * t_tx) * W_REC + t_cq * 16;
   const int t_voff = ((8 * t_rh) * 64 + t_w) * W_REC + ((t_cq ^ ((t_w >> 3) & 1)) * 16);
+  // One v_max_f32 per value (fmaxf() costs two: it canonicalises its operand first) and packed fp32 adds
+  // (v_pk_add_f32: two values per instruction): on this pipe every VALU instruction of a SIMD is time the fp32
+  // MFMAs do not get (they run on the same lanes), so the transform is written for instruction count.
   auto relu4 = [&](f32x4 f) {
-    if constexpr (RELU_IN) { f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f); f.z = fmaxf(f.z, 0.f); f.w = fmaxf(f.w, 0.f); }
+    if constexpr (RELU_IN) {
+      asm("v_max_f32 %0, 0, %0" : "+v"(f.x)); asm("v_max_f32 %0, 0, %0" : "+v"(f.y));
+      asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
+    }
     return f;
+  };
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  auto sub4 = [&](f32x4 a, f32x4 b) {
+    f32x2_ lo, hi;
+    const f32x2_ alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+  };
+  const f32x2_ sgn2 = {sgn, sgn};
+  auto fma4_sgn = [&](f32x4 z, f32x4 y) {          // y + sgn * z
+    f32x2_ lo, hi;
+    const f32x2_ zlo = {z.x, z.y}, zhi = {z.z, z.w}, ylo = {y.x, y.y}, yhi = {y.z, y.w};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(zlo), "v"(sgn2), "v"(ylo));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(zhi), "v"(sgn2), "v"(yhi));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+  };
+  auto add4 = [&](f32x4 a, f32x4 b) {
+    f32x2_ lo, hi;
+    const f32x2_ alo = {a.x, a.y}, ahi = {a.z, a.w}, blo = {b.x, b.y}, bhi = {b.z, b.w};
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
   };
   f32x4 txa[2], tza[2], tyb[2], tzb[2], TA[4], TB[4];
   auto tr_read = [&](int slot, int cpair) {
@@ -179,17 +208,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(const ConvArgs p)
   auto tr_rows = [&](int cpair) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      TA[2 * cpair + k] = relu4(txa[k]) - relu4(tza[k]);
-      TB[2 * cpair + k] = relu4(tyb[k]) + sgn * relu4(tzb[k]);
+      TA[2 * cpair + k] = sub4(relu4(txa[k]), relu4(tza[k]));
+      TB[2 * cpair + k] = fma4_sgn(relu4(tzb[k]), relu4(tyb[k]));
     }
   };
   auto tr_cols = [&](int vbuf, int which) {
     char* vw = sV + vbuf * W_SLAB + t_voff + which * 4 * 64 * W_REC;
     const f32x4* T = which ? TB : TA;
-    *reinterpret_cast<f32x4*>(vw + 0 * 64 * W_REC) = T[0] - T[2];
-    *reinterpret_cast<f32x4*>(vw + 1 * 64 * W_REC) = T[1] + T[2];
-    *reinterpret_cast<f32x4*>(vw + 2 * 64 * W_REC) = T[2] - T[1];
-    *reinterpret_cast<f32x4*>(vw + 3 * 64 * W_REC) = T[1] - T[3];
+    *reinterpret_cast<f32x4*>(vw + 0 * 64 * W_REC) = sub4(T[0], T[2]);
+    *reinterpret_cast<f32x4*>(vw + 1 * 64 * W_REC) = add4(T[1], T[2]);
+    *reinterpret_cast<f32x4*>(vw + 2 * 64 * W_REC) = sub4(T[2], T[1]);
+    *reinterpret_cast<f32x4*>(vw + 3 * 64 * W_REC) = sub4(T[1], T[3]);
   };
 
   // =========================== MFMA side (all waves) ==========================================================
