@@ -18,7 +18,7 @@
 
 #include "../../include/fisr.h"
 #include "conv3x3.h"
-#include "conv3x3_wino8.h"
+#include "conv3x3_wino8p.h"
 #include "glue_kernels.h"
 
 using namespace fisr;
@@ -253,10 +253,10 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
 // the kernel's LDS image (conv3x3_wino.h): [Cin/8][Cout/64][position 16][row 64][32-byte record], the two 16-byte
 // halves of a record swapped when bit 3 of the row is set; rows in the MFMA row order of pack_weights.
 inline bool wino_eligible(int ci, int co) { (void)ci; return co >= W_BN && co % W_BN == 0; }
-// the kernel addresses its input tensors with 32-bit byte offsets
-inline bool wino_fits(int n, int h, int w, int c0, int c1) {
+// the kernel addresses its input tensors, and 16 pixel rows of its output, with 32-bit byte offsets
+inline bool wino_fits(int n, int h, int w, int c0, int c1, int co) {
   const double px = (double)n * h * w;
-  return px * std::max(c0, c1) * 4.0 < 4294967296.0;
+  return px * std::max(c0, c1) * 4.0 < 4294967296.0 && 16.0 * w * co * 4.0 < 4294967296.0;
 }
 void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
@@ -351,29 +351,46 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Winograd kernels (fp32 only; a.wpk = the conv's d_wu).  Default: the 8-wave kernel (conv3x3_wino8.h);
-// FISR_WINO_VARIANT=4 selects the 4-wave one (conv3x3_wino.h) for A/B runs.
+// Winograd kernels (fp32 only; a.wpk = the conv's d_wu).  Default: the persistent 8-wave kernel (conv3x3_wino8p.h) for
+// Cin >= 32, the one-item-per-workgroup 8-wave kernel (conv3x3_wino8.h) below that; FISR_WINO_VARIANT=8 forces the
+// latter, =4 the 4-wave kernel (conv3x3_wino.h), for A/B runs.
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
-  static const int variant = [] { const char* e = getenv("FISR_WINO_VARIANT"); return e && e[0] == '4' ? 4 : 8; }();
+  static const int variant = [] { const char* e = getenv("FISR_WINO_VARIANT"); return e ? atoi(e) : 0; }();
   static bool attr_done[64] = {};
+  static int n_cu[64] = {};
   constexpr size_t lds = wino_lds_bytes();
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-    const void* kerns[3] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    const void* kerns[5] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
                             reinterpret_cast<const void*>(conv3x3_wino8_kernel<false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>)};
+                            reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true>)};
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    attr_done[dev] = true;
   }
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
-  dim3 grid(tiles * (a.CoutPad / W_BN));
-  if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(256), lds, st, a);
-  else if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8_kernel<true>, grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(conv3x3_wino8_kernel<false>, grid, dim3(512), lds, st, a);
+  const int items = tiles * (a.CoutPad / W_BN);
+  const int nch = (a.C0 + a.C1) / W_CH;
+  if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(items), dim3(256), lds, st, a);
+  else if (variant == 8 || nch < 4) {
+    if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8_kernel<true>, dim3(items), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(conv3x3_wino8_kernel<false>, dim3(items), dim3(512), lds, st, a);
+  } else {
+    // one workgroup per CU (the kernel needs all of a CU's LDS and half its registers), a multiple of 8 so that the
+    // items of a workgroup stay on one XCD
+    const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
+    if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8p_kernel<true>, dim3(grid), dim3(512), lds, st, a, items);
+    else hipLaunchKernelGGL(conv3x3_wino8p_kernel<false>, dim3(grid), dim3(512), lds, st, a, items);
+  }
   return hipGetLastError();
 }
 
@@ -519,7 +536,7 @@ struct Runner {
     a.out_cstride = cstride ? cstride : cw.co;
     a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr; a.wexp = cw.wexp;
     const double px = (double)n * h * w;
-    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1);
+    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
     char cls[96];
     if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8<f32w,%s>", a.relu_in ? "relu_in" : "plain");
@@ -939,7 +956,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.b.assign(b_host, b_host + cout);
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1);
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cout);
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
@@ -1011,7 +1028,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_fits(n, h, w, cin, 0);
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_fits(n, h, w, cin, 0, cout);
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
   HIP_OK(nullptr, hipMalloc(&d_out, out_b));

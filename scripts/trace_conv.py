@@ -18,4 +18,6 @@ t0, tm, te, tf, e1, e2, e3 = a[:, 0], a[:, 1], a[:, 2], a[:, 4], a[:, 5], a[:, 6
 med = lambda x: float(np.median(x))
 clk = (te - t0) / np.maximum(e2 - e1, 1) * 100.0   # s_memtime ticks per 100 MHz s_memrealtime tick -> MHz
 print(f"shader clock while the kernel runs: median {med(clk):.0f} MHz (10%..90%: {np.percentile(clk,10):.0f}..{np.percentile(clk,90):.0f})")
+if (a[:, 3] > tm).all():   # persistent kernel: the exchange barrier of the traced item
+    print(f"epilogue up to the exchange barrier {med(a[:, 3] - tm):.0f}")
 print(f"blocks {len(a)}  life {med(te - t0):.0f}  prologue {med(tf - t0):.0f}  main(after prologue) {med(tm - tf):.0f}  epilogue {med(te - tm):.0f}")
