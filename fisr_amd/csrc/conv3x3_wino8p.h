@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       int u = ct + 256 * i;
       asm volatile("" : "+v"(u));               // recompute per call: hoisted, the halo coordinates would be spilled
       const int pix = min(u >> 1, HALO_PIX - 1);
-      const int py = pix / HALO_W, px = pix - py * HALO_W;
+      const int py = pix / HALO_W, ix = pix - py * HALO_W;
+      const int px = ix < HALO_W / 2 ? 2 * ix : 2 * (ix - HALO_W / 2) + 1;     // even columns first, then the odd ones
       const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
       raw_gp[i] = (unsigned)((it.nb * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(max(gx, 0), p.W - 1));
     }
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       int u = ct + 256 * i;
       asm volatile("" : "+v"(u));
       const int pix = min(u >> 1, HALO_PIX - 1);
-      const int py = pix / HALO_W, px = pix - py * HALO_W;
+      const int py = pix / HALO_W, ix = pix - py * HALO_W;
+      const int px = ix < HALO_W / 2 ? 2 * ix : 2 * (ix - HALO_W / 2) + 1;     // even columns first, then the odd ones
       const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
       fix_ok[i] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) || u >= W_RAW_UNITS;
       fix_any = fix_any || !fix_ok[i];
@@ -125,7 +127,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
                    : [keep] "=&s"(keep) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1) : "memory", "scc");
     }
   };
-  auto fix_raw = [&](int slot) {
+  // A landed raw chunk is finished in place by the threads that requested it: relu (RELU_IN: once per element here,
+  // instead of once per tile that reads it -- four times -- in the transform waves, whose VALU time is the K loop's
+  // critical path), zeros for the padding pixels.  In the K loop the relu is split into a read and a write half with a
+  // stage of MFMAs in between (a wave issues in order: waiting for the ds_read would stall its MFMAs).
+  f32x4 rl[3];
+  auto relu_read = [&](int slot) {
+    if constexpr (RELU_IN) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (ct + 256 * i < W_RAW_UNITS) rl[i] = *reinterpret_cast<const f32x4*>(sR + slot * W_RAW + (ct + 256 * i) * 16);
+    }
+  };
+  auto relu_write = [&](int slot) {
+    if constexpr (RELU_IN) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (ct + 256 * i < W_RAW_UNITS) {
+          f32x4 f = rl[i];
+          asm("v_max_f32 %0, 0, %0" : "+v"(f.x)); asm("v_max_f32 %0, 0, %0" : "+v"(f.y));
+          asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
+          *reinterpret_cast<f32x4*>(sR + slot * W_RAW + (ct + 256 * i) * 16) = f;
+        }
+    }
+  };
+  auto zero_padding = [&](int slot) {
     if (fix_any) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -133,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
         if (!fix_ok[i]) *reinterpret_cast<f32x4*>(sR + slot * W_RAW + (ct + 256 * i) * 16) = z;
     }
   };
+  auto fix_raw = [&](int slot) { relu_read(slot); relu_write(slot); zero_padding(slot); };
   const size_t u_stride = (size_t)nblocks * W_SLAB;
   const unsigned u_lds0 = (unsigned)(size_t)(lds_ptr_t)sU + (unsigned)cw * 1024u;
   const unsigned u_voff = (unsigned)ct * 16u;
@@ -168,15 +195,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
   const int t_ty = t_w >> 4, t_tx = t_w & 15;
   const int ra_x = t_rh ? 2 : 0, ra_z = t_rh ? 1 : 2, rb_z = t_rh ? 3 : 2;
   const float sgn = t_rh ? -1.f : 1.f;
-  const int t_roff = ((2 * t_ty) * HALO_W + 2 * t_tx) * W_REC + t_cq * 16;
+  const int t_roff = ((2 * t_ty) * HALO_W + t_tx) * W_REC + t_cq * 16;      // (column c of the tile: see tr_read)
   const int t_voff = ((8 * t_rh) * 64 + t_w) * W_REC + ((t_cq ^ ((t_w >> 3) & 1)) * 16);
-  auto relu4 = [&](f32x4 f) {
-    if constexpr (RELU_IN) {
-      asm("v_max_f32 %0, 0, %0" : "+v"(f.x)); asm("v_max_f32 %0, 0, %0" : "+v"(f.y));
-      asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
-    }
-    return f;
-  };
+  auto relu4 = [&](f32x4 f) { return f; };            // (the relu of RELU_IN is applied in LDS: fix_raw)
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   auto sub4 = [&](f32x4 a, f32x4 b) {
     f32x2_ lo, hi;
@@ -210,10 +231,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
         asm volatile("" : "=v"(txa[k]), "=v"(tza[k]), "=v"(tyb[k]), "=v"(tzb[k]));
         continue;
       }
-      txa[k] = *reinterpret_cast<const f32x4*>(rb + (ra_x * HALO_W + c) * W_REC);
-      tza[k] = *reinterpret_cast<const f32x4*>(rb + (ra_z * HALO_W + c) * W_REC);
-      tyb[k] = *reinterpret_cast<const f32x4*>(rb + (1 * HALO_W + c) * W_REC);
-      tzb[k] = *reinterpret_cast<const f32x4*>(rb + (rb_z * HALO_W + c) * W_REC);
+      // halo column 2 tx + c sits at index (c & 1) * 17 + tx + (c >> 1) of its row (even columns first): the 16 lanes
+      // of one ds_read_b128 phase -- 8 neighbouring tiles x 2 halves -- then read 256 contiguous bytes, every bank once
+      // (with the columns in natural order the tiles are 64 B apart and the phase hits every other bank twice)
+      const int cc = (c & 1) * (HALO_W / 2) + (c >> 1);
+      txa[k] = *reinterpret_cast<const f32x4*>(rb + (ra_x * HALO_W + cc) * W_REC);
+      tza[k] = *reinterpret_cast<const f32x4*>(rb + (ra_z * HALO_W + cc) * W_REC);
+      tyb[k] = *reinterpret_cast<const f32x4*>(rb + (1 * HALO_W + cc) * W_REC);
+      tzb[k] = *reinterpret_cast<const f32x4*>(rb + (rb_z * HALO_W + cc) * W_REC);
     }
   };
   auto tr_rows = [&](int cpair) {
@@ -342,9 +367,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     for (int pp = 0; pp < 4; ++pp) {
       if (pp < 3) frag_load(par, pp + 1, (pp + 1) & 1);
       if constexpr (FIRST) { FISR_W8_STAGE0(pp) } else { FISR_W8_STAGE(pp) }
+      if (pp == 1) {
+        // raw(g+2), requested an iteration ago, is older than this iteration's 8 + 3 (2) copies: finish it now, under
+        // the MFMAs, not in front of the barrier
+        if (!(FISR_WABL & 2)) {
+          if (cw < 3) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+          else        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        }
+        relu_read(slot2);
+      }
+      if (pp == 2) { relu_write(slot2); zero_padding(slot2); }
     }
-    if (!(FISR_WABL & 2)) wait_copies_keep_youngest_raw();      // U(g+1) and raw(g+2) landed; raw(g+3) stays in flight
-    fix_raw(slot2);
+    if (!(FISR_WABL & 2)) wait_copies_keep_youngest_raw();      // U(g+1) landed too; raw(g+3) stays in flight
     lds_barrier();
     const int s_ = slot1; slot1 = slot2; slot2 = slot3; slot3 = s_;
     par ^= 1;
