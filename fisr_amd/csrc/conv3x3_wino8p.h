@@ -322,28 +322,53 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
   const int tr_item = max(2, (n_items / (int)gridDim.x) >> 1);     // the item whose timeline is traced (mid-run)
   unsigned long long t_it0 = 0, t_it1 = 0, t_it2 = 0, t_itk = 0, t_bar = 0;
 
-  // one K iteration of a transform wave: chunk kc is multiplied, chunk kc+1 (chunk 0 of the next item behind the last
-  // one) is transformed into V[par ^ 1]
+  // The MFMAs of a chunk are skewed by one stage against the barriers: an iteration runs stage 3 of the PREVIOUS chunk
+  // (its fragments were loaded into registers before the barrier) and stages 0-2 of its own chunk, and leaves its own
+  // stage 3 pending.  A wave issues in order, so without the skew every iteration opens with both waves of a SIMD
+  // waiting for their first fragments and the matrix pipe idle for an LDS round trip; with it that round trip hides
+  // under eight MFMAs.  The last chunk's stage 3 runs behind the loop (flush_stage3); the first iteration of an item
+  // has nothing pending and zeroes the stage-3 accumulators instead (stages 0-2 start from C = 0).
+  //
+  // slot s of an iteration:  fragments of stage s -> register buffer s & 1;  then the MFMAs of stage (s + 3) & 3 from
+  // the other buffer.
+#define FISR_W8_SLOT_MMA(S)                                                       \
+  if constexpr (FIRST) {                                                          \
+    if ((S) == 1) { FISR_W8_STAGE0(0) }                                           \
+    if ((S) == 2) { FISR_W8_STAGE0(1) }                                           \
+    if ((S) == 3) { FISR_W8_STAGE0(2) }                                           \
+  } else {                                                                        \
+    if ((S) == 0) { FISR_W8_STAGE(3) }                                            \
+    if ((S) == 1) { FISR_W8_STAGE(0) }                                            \
+    if ((S) == 2) { FISR_W8_STAGE(1) }                                            \
+    if ((S) == 3) { FISR_W8_STAGE(2) }                                            \
+  }
+  auto zero_stage3 = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[6][r] = 0.f; acc[7][r] = 0.f; }
+  };
+  auto flush_stage3 = [&]() { FISR_W8_STAGE(3) };
+
+  // one K iteration of a transform wave: chunk kc is multiplied (see above), chunk kc+1 (chunk 0 of the next item behind
+  // the last one) is transformed into V[par ^ 1]
   auto iter_transform = [&](auto first_tag) {
     constexpr bool FIRST = decltype(first_tag)::value;
-    frag_load(par, 0, 0);
     if (!(FISR_WABL & 1)) tr_read(slot1, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FIRST) zero_stage3();
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-      if (pp < 3) frag_load(par, pp + 1, (pp + 1) & 1);
+    for (int sl = 0; sl < 4; ++sl) {
+      frag_load(par, sl, sl & 1);
       if (!(FISR_WABL & 1)) {
-        if (pp == 0) { tr_rows(0); tr_read(slot1, 1); }
-        if (pp == 1) tr_rows(1);
+        if (sl == 0) { tr_rows(0); tr_read(slot1, 1); }
+        if (sl == 1) tr_rows(1);
         if (!(FISR_WABL & 1024)) {
-          if (pp == 2) tr_cols(par ^ 1, 0);
-          if (pp == 3) tr_cols(par ^ 1, 1);
-        } else if (pp >= 2) {
+          if (sl == 2) tr_cols(par ^ 1, 0);
+          if (sl == 3) tr_cols(par ^ 1, 1);
+        } else if (sl >= 2) {
           asm volatile("" :: "v"(TA[0]), "v"(TA[1]), "v"(TA[2]), "v"(TA[3]), "v"(TB[0]), "v"(TB[1]), "v"(TB[2]), "v"(TB[3]));
         }
       }
-      if constexpr (FIRST) { FISR_W8_STAGE0(pp) } else { FISR_W8_STAGE(pp) }
-      FISR_W8_INTERLEAVE(4)
+      FISR_W8_SLOT_MMA(sl)
+      if (!FIRST || sl > 0) { FISR_W8_INTERLEAVE(4) }
       __builtin_amdgcn_sched_barrier(0);
     }
     lds_barrier();
@@ -363,20 +388,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       copy_u(kc + 1 < nch ? kc + 1 : (has_next ? 0 : kc), par ^ 1);
       copy_raw(kc + 3 < nch ? kc + 3 : (has_next ? kc + 3 - nch : nch - 1), slot3);
     }
+    if constexpr (FIRST) zero_stage3();
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-      if (pp < 3) frag_load(par, pp + 1, (pp + 1) & 1);
-      if constexpr (FIRST) { FISR_W8_STAGE0(pp) } else { FISR_W8_STAGE(pp) }
-      if (pp == 1) {
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl > 0) frag_load(par, sl, sl & 1);
+      FISR_W8_SLOT_MMA(sl)
+      if (sl == 1) {
         // raw(g+2), requested an iteration ago, is older than this iteration's 8 + 3 (2) copies: finish it now, under
-        // the MFMAs, not in front of the barrier
+        // the MFMAs, not in front of the barrier (read and write halves apart: see relu_read)
         if (!(FISR_WABL & 2)) {
           if (cw < 3) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
           else        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         }
         relu_read(slot2);
       }
-      if (pp == 2) { relu_write(slot2); zero_padding(slot2); }
+      if (sl == 2) { relu_write(slot2); zero_padding(slot2); }
     }
     if (!(FISR_WABL & 2)) wait_copies_keep_youngest_raw();      // U(g+1) landed too; raw(g+3) stays in flight
     lds_barrier();
@@ -451,6 +477,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       if (p.trace && n_done == tr_item) t_itk = __builtin_readcyclecounter();
       for (int kc = 1; kc < nch; ++kc) iter_copy(rest_t{}, kc);
     }
+    // residual records of this wave's output row: requested before the last chunk's pending stage, which hides a
+    // part of their latency.  (Hoisted further, into the last K iteration, these 32 registers make the compiler spill
+    // inside the K loop.)
+    uint4 rres[2][4];
+    load_res(ph, rres);
+    __builtin_amdgcn_sched_barrier(0);
+    flush_stage3();                                // the last chunk's pending stage
     if (p.trace) { t_main = __builtin_readcyclecounter(); if (n_done == tr_item) t_it1 = t_main; }
 
     // ---- epilogue: Y = A^T M A per winograd tile, + bias, + residual, relu, store.  Wave ph = 0 of a pair holds the M
@@ -468,9 +501,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     //      In-place residual (res == out): every record is read before the barrier or by the wave that later writes it.
     const int rel = par ^ 1;
     const int xoff = rel * W_SLAB + (wave & 3) * 8192 + lane * 16;
-    uint4 rres[2][4];
-    load_res(ph, rres);                          // (hoisted into the copy waves' last K iteration, these 32 registers
-                                                 //  make the compiler spill inside the K loop)
     const Geo geo = geometry();
     const int ty = geo.ty, txq = geo.txq, c0 = geo.c0;
     const bool c_ok = geo.c_ok;
@@ -572,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
 #undef FISR_W8_PAIR
 #undef FISR_W8_COL
 #undef FISR_W8_MMA0
+#undef FISR_W8_SLOT_MMA
 #undef FISR_W8_STAGE0
 #undef FISR_W8_MMA
 #undef FISR_W8_STAGE
