@@ -416,6 +416,10 @@ struct ConvArgs {
   // channel scatter of the direct store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
   int out_cstride, out_coff, out_split, out_gap;
   int wexp;          // f16f8: wh8 = fp8(w_h * 2^wexp), wl8 = fp8(w_l * 2^(wexp+11)) (per conv, host-chosen)
+  // Winograd kernel only (conv3x3_wino8p.h; the PWC-Net decoder reads and writes channel ranges of one wide buffer):
+  int in0_cs, in1_cs;   // pixel strides of in0 / in1 in elements (>= C0 / C1)
+  int rec_cs, rec_co;   // pixel stride and first channel of the (non-d2s) output and of the residual (Cout, 0 otherwise)
+  float slope;          // relu_out with slope != 0: leaky relu, max(v, slope * v)
   // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
   unsigned long long* trace;
 };

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     const int c0 = kc * W_CH;
     const bool first = c0 < p.C0;
     const char* g = first ? (const char*)p.in0 + (size_t)c0 * 4 : (const char*)p.in1 + (size_t)(c0 - p.C0) * 4;
-    const unsigned cs = (unsigned)(first ? p.C0 : p.C1) * 4u, ho = (unsigned)(ct & 1) * 16u;
+    const unsigned cs = (unsigned)(first ? p.in0_cs : p.in1_cs) * 4u, ho = (unsigned)(ct & 1) * 16u;
     const unsigned o0 = raw_gp[0] * cs + ho, o1 = raw_gp[1] * cs + ho, o2 = raw_gp[2] * cs + ho;
     const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)W_RAW;
     unsigned keep;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     // quad's four pixels, 64 contiguous bytes per quad and instruction)
     auto load_res = [&](int row, uint4 (&rres)[2][4]) {      // rres[output column j][pixel k of the quad]
       const Geo g = geometry();
-      const char* const res_base = (const char*)p.res + (size_t)(cur.nb * p.H + cur.y0) * p.W * p.Cout * 4;
+      const char* const res_base = (const char*)p.res + ((size_t)(cur.nb * p.H + cur.y0) * p.W * p.rec_cs + p.rec_co) * 4;
       const int oy = cur.y0 + 2 * g.ty + row;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
           rres[j][k] = make_uint4(0u, 0u, 0u, 0u);
           if (!(FISR_WABL & 256) && p.res != nullptr && g.c_ok && oy < p.H && x < p.W)
             rres[j][k] = *reinterpret_cast<const uint4*>(
-                res_base + ((unsigned)((2 * g.ty + row) * p.W + x) * (unsigned)p.Cout + (unsigned)(g.c0 + 4 * (lane & 3))) * 4u);
+                res_base + ((unsigned)((2 * g.ty + row) * p.W + x) * (unsigned)p.rec_cs + (unsigned)(g.c0 + 4 * (lane & 3))) * 4u);
         }
     };
 
@@ -539,13 +539,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       const int cq_shift = p.d2s_shift;
       // element offset of the record of pixel (y0 + dy, xc) from the item's first row (8 or 16 rows: fits 32 bits)
       char* const out_base = (char*)p.out + (p.d2s ? ((size_t)(cur.nb * 2 * p.H + 2 * cur.y0) * (2 * p.W) << cq_shift) * 4
-                                                   : (size_t)(cur.nb * p.H + cur.y0) * p.W * p.Cout * 4);
+                                                   : ((size_t)(cur.nb * p.H + cur.y0) * p.W * p.rec_cs + p.rec_co) * 4);
       auto record = [&](int dy, int xc) -> unsigned {
         if (p.d2s) {
           const int sub = c0 >> cq_shift, c = c0 & ((1 << cq_shift) - 1);
           return ((unsigned)((2 * dy + (sub >> 1)) * (2 * p.W) + 2 * xc + (sub & 1)) << cq_shift) + (unsigned)c;
         }
-        return (unsigned)(dy * p.W + xc) * (unsigned)p.Cout + (unsigned)c0;
+        return (unsigned)(dy * p.W + xc) * (unsigned)p.rec_cs + (unsigned)c0;
       };
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -567,10 +567,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
             o0[e] = y0.x; o0[e + 1] = y0.y; o1[e] = y1.x; o1[e + 1] = y1.y;
           }
           if (p.relu_out) {
+            if (p.slope != 0.f) {                // leaky relu (0 < slope < 1)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              asm("v_max_f32 %0, 0, %0" : "+v"(o0[e]));
-              asm("v_max_f32 %0, 0, %0" : "+v"(o1[e]));
+              for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], p.slope * o0[e]); o1[e] = fmaxf(o1[e], p.slope * o1[e]); }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                asm("v_max_f32 %0, 0, %0" : "+v"(o0[e]));
+                asm("v_max_f32 %0, 0, %0" : "+v"(o1[e]));
+              }
             }
           }
           rec[0][k] = __builtin_bit_cast(uint4, o0);

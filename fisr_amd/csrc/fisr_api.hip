@@ -258,9 +258,10 @@ inline bool wino_fits(int n, int h, int w, int c0, int c1, int co) {
   const double px = (double)n * h * w;
   return px * std::max(c0, c1) * 4.0 < 4294967296.0 && 16.0 * w * co * 4.0 < 4294967296.0;
 }
+// (co need not be a multiple of the 64-channel block: the last block is zero padded, the kernel skips the stores)
 void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
   static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-  const int nb = co / W_BN, nch = cin_pad / W_CH;
+  const int nb = (co + W_BN - 1) / W_BN, nch = cin_pad / W_CH;
   wp.assign((size_t)nch * nb * W_SLAB, 0);
   for (int c = 0; c < ci; ++c)
     for (int n = 0; n < co; ++n) {
@@ -380,6 +381,9 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   const int items = tiles * (a.CoutPad / W_BN);
   const int nch = (a.C0 + a.C1) / W_CH;
+  // channel-range input / output and leaky relu exist in the persistent kernel only
+  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f;
+  if (!plain && (variant == 4 || variant == 8 || nch < 4)) return hipErrorInvalidValue;
   if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(items), dim3(256), lds, st, a);
   else if (variant == 8 || nch < 4) {
     if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8_kernel<true>, dim3(items), dim3(512), lds, st, a);
@@ -529,6 +533,7 @@ struct Runner {
     ConvArgs a;
     a.in0 = in0; a.in1 = in1; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
     a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cw.co; a.CoutPad = cw.cout_pad;
+    a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cw.co; a.rec_co = 0; a.slope = 0.f;
     a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
     a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
     a.d2s = (flags & FISR_CONV_D2S) != 0;
@@ -960,6 +965,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
+  a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
@@ -1049,6 +1055,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   ConvArgs a;
   a.in0 = d_in; a.in1 = nullptr; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = d_res; a.out = d_out;
   a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
+  a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;

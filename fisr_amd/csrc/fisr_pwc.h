@@ -14,7 +14,7 @@ const int PWC_CTXT[7][2] = {{128, 1}, {128, 2}, {128, 4}, {96, 8}, {64, 16}, {32
 inline int pad4(int c) { return (c + 3) & ~3; }
 
 // Channel layout of the decoder buffer D[lvl] (tf.concat order of model_pwcnet.py:1424, 1428-1445, every group padded
-// to a multiple of 4): [act4 32 | act3 64 | act2 96 | act1 128 | act0 128 | corr 81(84) | c1 C | up_flow 2(4) | up_feat 2(4)]
+// to a multiple of 4): [act4 32 | act3 64 | act2 96 | act1 128 | act0 128 | corr 81(88; 96 at the top level) | c1 C | up_flow 2(4) | up_feat 2(4)]
 struct DecLayout {
   int c1;                        // feature channels of the level (0 at the top level: x = corr only)
   int off_act[5];                // act0 .. act4
@@ -22,7 +22,9 @@ struct DecLayout {
   explicit DecLayout(int lvl) {
     c1 = lvl == PWC_LVLS ? 0 : PWC_CH[lvl];
     off_act[4] = 0; off_act[3] = 32; off_act[2] = 96; off_act[1] = 192; off_act[0] = 320;
-    off_corr = 448; off_c1 = off_corr + 84;
+    // 81 cost-volume channels in a block of 88 (96 at the top level, which has nothing behind it): with the 4 + 4 of
+    // the up-sampled flow / features every conv of the level then reads a channel range that is a multiple of 32
+    off_corr = 448; off_c1 = off_corr + (c1 ? 88 : 96);
     off_upflow = off_c1 + c1; off_upfeat = off_upflow + (c1 ? 4 : 0);
     total = off_upfeat + (c1 ? 4 : 0);
   }
@@ -47,6 +49,7 @@ struct PwcVar {
 
 struct PwcConv {                 // one packed convolution
   float* d_w = nullptr; float* d_b = nullptr;
+  char* d_wu = nullptr;          // Winograd slabs for conv3x3_wino8p_kernel (stride 1, dilation 1, Cout >= 32 only)
   int cin_buf = 0, cout = 0, cout_pad = 0;
 };
 struct PwcDeconv { float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0; };
@@ -95,7 +98,7 @@ std::vector<std::pair<std::string, std::vector<int64_t>>> pwc_variable_list() {
 
 // pack HWIO [3,3,ci,co] for pwc_convg_kernel: [cin_buf8/8][CoutPad/64][9][64 rows][8 floats], LDS image; chmap[j] =
 // buffer channel (relative to the conv's first input channel) of TF input channel j
-int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>& chmap, int cin_buf, PwcConv& pc) {
+int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>& chmap, int cin_buf, PwcConv& pc, bool wino = false) {
   const PwcVar& kw = ctx->vars[name + "/kernel"];
   const PwcVar& kb = ctx->vars[name + "/bias"];
   const int ci = (int)kw.shape[2], co = (int)kw.shape[3];
@@ -118,6 +121,19 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
   HIP_OK(nullptr, hipMalloc((void**)&pc.d_b, bp.size() * 4));
   HIP_OK(nullptr, hipMemcpy(pc.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(nullptr, hipMemcpy(pc.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  // The stride-1, dilation-1 layers with 32 or more output channels (the dense flow estimators, the first and sixth
+  // context convs: 85 % of the network's FLOPs) also get FISRnet's Winograd slabs: G g G^T of the kernel scattered to
+  // the buffer channels it reads.
+  if (wino && co >= 32 && co % 16 == 0 && cin_buf >= 32 && cin_buf % W_CH == 0) {
+    std::vector<float> dense((size_t)9 * cin_buf * co, 0.f);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int j = 0; j < ci; ++j)
+        for (int n = 0; n < co; ++n) dense[((size_t)tap * cin_buf + chmap[j]) * co + n] = kw.v[((size_t)tap * ci + j) * co + n];
+    std::vector<char> wu;
+    pack_weights_wino(dense.data(), cin_buf, co, cin_buf, wu);
+    HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu, wu.size()));
+    HIP_OK(nullptr, hipMemcpy(pc.d_wu, wu.data(), wu.size(), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -152,6 +168,21 @@ struct PwcRunner {
             int n, int h, int w, int stride, int dil, float slope, const float* add = nullptr, int add_cs = 0, int add_co = 0) {
     if (rc || ar.dry) return;
     const PwcConv& pc = ctx->convs[name];
+    static const bool no_wino = [] { const char* e = getenv("FISR_PWC_WINO"); return e && e[0] == '0'; }();
+    if (pc.d_wu && !no_wino && stride == 1 && dil == 1 && !add && (slope == 1.f || (slope > 0.f && slope < 1.f)) &&
+        wino_fits(n, h, w, in_cs, 0, out_cs)) {
+      // FISRnet's persistent Winograd kernel on a channel range of the buffer (fisr_api.hip: launch_conv_wino)
+      ConvArgs a;
+      a.in0 = in + in_co; a.in1 = nullptr; a.wpk = pc.d_wu; a.bias = pc.d_b; a.res = nullptr; a.out = out;
+      a.C0 = pc.cin_buf; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = pc.cout; a.CoutPad = round_up(pc.cout, W_BN);
+      a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
+      a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
+      a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = out_cs; a.rec_co = out_co; a.slope = slope != 1.f ? slope : 0.f;
+      a.trace = nullptr;
+      hipError_t e = launch_conv_wino(a, st);
+      if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (winograd): " + hipGetErrorString(e));
+      return;
+    }
     static bool attr_done[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
@@ -276,7 +307,7 @@ int fisr_pwc_create(fisr_pwc** out, int device_id) {
 void fisr_pwc_destroy(fisr_pwc* c) {
   if (!c) return;
   DeviceGuard guard(c->dev);
-  for (auto& kv : c->convs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
+  for (auto& kv : c->convs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); if (kv.second.d_wu) (void)hipFree(kv.second.d_wu); }
   for (auto& kv : c->deconvs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
   delete c;
 }
@@ -321,8 +352,8 @@ int fisr_pwc_finalize(fisr_pwc* c) {
   for (int l = 1; l <= PWC_LVLS && !rc; ++l) {
     const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
     rc = pwc_pack_conv(c, p + "a", iota_map(real[l - 1]), PWC_CH[l - 1], c->convs[p + "a"]);
-    if (!rc) rc = pwc_pack_conv(c, p + "aa", iota_map(real[l]), PWC_CH[l], c->convs[p + "aa"]);
-    if (!rc) rc = pwc_pack_conv(c, p + "b", iota_map(real[l]), PWC_CH[l], c->convs[p + "b"]);
+    if (!rc) rc = pwc_pack_conv(c, p + "aa", iota_map(real[l]), PWC_CH[l], c->convs[p + "aa"], true);
+    if (!rc) rc = pwc_pack_conv(c, p + "b", iota_map(real[l]), PWC_CH[l], c->convs[p + "b"], true);
   }
   for (int l = PWC_LVLS; l >= PWC_PRED && !rc; --l) {
     const DecLayout L(l);
@@ -332,13 +363,14 @@ int fisr_pwc_finalize(fisr_pwc* c) {
       std::vector<int> m = L.map_from(i == 0 ? 5 : i - 1);
       for (int& x : m) x -= first;
       const std::string n = "pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i);
-      rc = pwc_pack_conv(c, n, m, L.total - first, c->convs[n]);
+      rc = pwc_pack_conv(c, n, m, L.total - first, c->convs[n], true);
     }
     if (!rc) rc = pwc_pack_conv(c, "pwcnet/predict_flow/flow" + ls, L.map_from(4), L.total, c->convs["pwcnet/predict_flow/flow" + ls]);
     int ci = 0;
     for (int i = 0; i < 7 && !rc; ++i) {
       const std::string n = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
-      rc = i == 0 ? pwc_pack_conv(c, n, L.map_from(4), L.total, c->convs[n]) : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n]);
+      rc = i == 0 ? pwc_pack_conv(c, n, L.map_from(4), L.total, c->convs[n], true)
+                  : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n], PWC_CTXT[i][1] == 1);
       ci = PWC_CTXT[i][0];
     }
     if (l != PWC_PRED && !rc) {
