@@ -416,9 +416,9 @@ struct ConvArgs {
   // channel scatter of the direct store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
   int out_cstride, out_coff, out_split, out_gap;
   int wexp;          // f16f8: wh8 = fp8(w_h * 2^wexp), wl8 = fp8(w_l * 2^(wexp+11)) (per conv, host-chosen)
-  // Winograd kernel only (conv3x3_wino8p.h; the PWC-Net decoder reads and writes channel ranges of one wide buffer):
+  // (the PWC-Net decoder reads and writes channel ranges of one wide buffer)
   int in0_cs, in1_cs;   // pixel strides of in0 / in1 in elements (>= C0 / C1)
-  int rec_cs, rec_co;   // pixel stride and first channel of the (non-d2s) output and of the residual (Cout, 0 otherwise)
+  int rec_cs, rec_co;   // Winograd kernel only: pixel stride and first channel of the (non-d2s) output and of the residual
   float slope;          // relu_out with slope != 0: leaky relu, max(v, slope * v)
   // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
   unsigned long long* trace;
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       const T* src;
       int csrc, coff;
       const int c0 = (kc + 1) * CC;
-      if (c0 < p.C0) { src = (const T*)p.in0; csrc = p.C0; coff = c0; }
-      else           { src = (const T*)p.in1; csrc = p.C1; coff = c0 - p.C0; }
+      if (c0 < p.C0) { src = (const T*)p.in0; csrc = p.in0_cs; coff = c0; }
+      else           { src = (const T*)p.in1; csrc = p.in1_cs; coff = c0 - p.C0; }
 #pragma unroll
       for (int i = 0; i < NPIX_IT; ++i) {
         if constexpr (QUAD) {
@@ -873,6 +873,9 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   // C/D layout of the 32x32 MFMA: column (N = pixel) = lane & 31, row (M = packed channel row)
   // = (r&3) + 8*(r>>2) + 4*(lane>>5); with the host's row order register r is channel c0 + r.
   const float relu_floor = p.relu_out ? 0.f : -__builtin_huge_valf();
+  const float lk = p.slope;                       // != 0 (with relu_out): leaky relu, max(v, slope * v)
+  const bool leaky = p.relu_out && lk != 0.f;
+  auto act = [&](float v) { return fmaxf(v, leaky ? lk * v : relu_floor); };
   const int x = x0 + li;
   if constexpr (NT == 0) {
     // ---- 16-row variant: lane (pixel l&15 of column tile ct, K group kg) holds channels 4*kg + r ----
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = n0 + 4 * kg + r;
-          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = fmaxf(acc4[m][ct][r], relu_floor);
+          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = act(acc4[m][ct][r]);
         }
       }
     }
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = c0 + r;
-          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = fmaxf(acc[m][j][r], relu_floor);
+          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = act(acc[m][j][r]);
         }
       }
     }
@@ -935,7 +938,7 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         if (c0 >= p.Cout) continue;
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc[m][j][r], relu_floor);
+        for (int r = 0; r < 16; ++r) v[r] = act(acc[m][j][r]);
         uint4 q[R16::NV];
 #if (FISR_ABL & 32)   // ablation: no conversion, raw accumulator bits stored (same bytes)
 #pragma unroll

@@ -50,6 +50,8 @@ struct PwcVar {
 struct PwcConv {                 // one packed convolution
   float* d_w = nullptr; float* d_b = nullptr;
   char* d_wu = nullptr;          // Winograd slabs for conv3x3_wino8p_kernel (stride 1, dilation 1, Cout >= 32 only)
+  ConvW dw;                      // FISRnet's direct fp32 kernel (stride 1, dilation 1, Cout < 32: flow heads, level 1)
+  bool have_dw = false;
   int cin_buf = 0, cout = 0, cout_pad = 0;
 };
 struct PwcDeconv { float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0; };
@@ -124,15 +126,26 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
   // The stride-1, dilation-1 layers with 32 or more output channels (the dense flow estimators, the first and sixth
   // context convs: 85 % of the network's FLOPs) also get FISRnet's Winograd slabs: G g G^T of the kernel scattered to
   // the buffer channels it reads.
-  if (wino && co >= 32 && co % 16 == 0 && cin_buf >= 32 && cin_buf % W_CH == 0) {
+  const bool as_wino = wino && co >= 32 && co % 16 == 0 && cin_buf >= 32 && cin_buf % W_CH == 0;
+  // ... and the ones with fewer (the 2-channel flow heads, which the 64-wide generic kernel computes 32 times over,
+  // and the 16-channel level-1 features) the weights of FISRnet's direct kernel (16- and 32-wide N blocks).
+  const bool as_direct = wino && !as_wino && co < 32 && cin_buf % 16 == 0;
+  if (as_wino || as_direct) {
     std::vector<float> dense((size_t)9 * cin_buf * co, 0.f);
     for (int tap = 0; tap < 9; ++tap)
       for (int j = 0; j < ci; ++j)
         for (int n = 0; n < co; ++n) dense[((size_t)tap * cin_buf + chmap[j]) * co + n] = kw.v[((size_t)tap * ci + j) * co + n];
-    std::vector<char> wu;
-    pack_weights_wino(dense.data(), cin_buf, co, cin_buf, wu);
-    HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu, wu.size()));
-    HIP_OK(nullptr, hipMemcpy(pc.d_wu, wu.data(), wu.size(), hipMemcpyHostToDevice));
+    if (as_wino) {
+      std::vector<char> wu;
+      pack_weights_wino(dense.data(), cin_buf, co, cin_buf, wu);
+      HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu, wu.size()));
+      HIP_OK(nullptr, hipMemcpy(pc.d_wu, wu.data(), wu.size(), hipMemcpyHostToDevice));
+    } else {
+      pc.dw.ci = cin_buf; pc.dw.co = co; pc.dw.w = std::move(dense); pc.dw.b = kb.v;
+      int rc = upload_conv<float>(nullptr, pc.dw, false);
+      if (rc) return rc;
+      pc.have_dw = true;
+    }
   }
   return 0;
 }
@@ -181,6 +194,19 @@ struct PwcRunner {
       a.trace = nullptr;
       hipError_t e = launch_conv_wino(a, st);
       if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (winograd): " + hipGetErrorString(e));
+      return;
+    }
+    if (pc.have_dw && !no_wino && stride == 1 && dil == 1 && !add && (slope == 1.f || (slope > 0.f && slope < 1.f))) {
+      ConvArgs a;
+      a.in0 = in + in_co; a.in1 = nullptr; a.wpk = pc.dw.d_w; a.bias = pc.dw.d_b; a.res = nullptr; a.out = out;
+      a.C0 = pc.dw.cin_pad; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = pc.cout; a.CoutPad = pc.dw.cout_pad;
+      a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
+      a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
+      a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = pc.cout; a.rec_co = 0; a.slope = slope != 1.f ? slope : 0.f;
+      a.trace = nullptr;
+      const bool scatter = !(out_cs == pc.cout && out_co == 0);     // dense records, or per-channel fp32 stores
+      hipError_t e = launch_conv<float>(a, pc.dw.nt, scatter, st);
+      if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (direct): " + hipGetErrorString(e));
       return;
     }
     static bool attr_done[64] = {};
@@ -307,7 +333,8 @@ int fisr_pwc_create(fisr_pwc** out, int device_id) {
 void fisr_pwc_destroy(fisr_pwc* c) {
   if (!c) return;
   DeviceGuard guard(c->dev);
-  for (auto& kv : c->convs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); if (kv.second.d_wu) (void)hipFree(kv.second.d_wu); }
+  for (auto& kv : c->convs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
+    if (kv.second.dw.d_w) (void)hipFree(kv.second.dw.d_w); if (kv.second.dw.d_b) (void)hipFree(kv.second.dw.d_b); }
   for (auto& kv : c->deconvs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
   delete c;
 }
@@ -365,7 +392,7 @@ int fisr_pwc_finalize(fisr_pwc* c) {
       const std::string n = "pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i);
       rc = pwc_pack_conv(c, n, m, L.total - first, c->convs[n], true);
     }
-    if (!rc) rc = pwc_pack_conv(c, "pwcnet/predict_flow/flow" + ls, L.map_from(4), L.total, c->convs["pwcnet/predict_flow/flow" + ls]);
+    if (!rc) rc = pwc_pack_conv(c, "pwcnet/predict_flow/flow" + ls, L.map_from(4), L.total, c->convs["pwcnet/predict_flow/flow" + ls], true);
     int ci = 0;
     for (int i = 0; i < 7 && !rc; ++i) {
       const std::string n = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
