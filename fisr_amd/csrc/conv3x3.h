@@ -420,6 +420,7 @@ struct ConvArgs {
   int in0_cs, in1_cs;   // pixel strides of in0 / in1 in elements (>= C0 / C1)
   int rec_cs, rec_co;   // Winograd kernel only: pixel stride and first channel of the (non-d2s) output and of the residual
   float slope;          // relu_out with slope != 0: leaky relu, max(v, slope * v)
+  int dil;              // Winograd kernel only: dilation (1 otherwise)
   // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
   unsigned long long* trace;
 };

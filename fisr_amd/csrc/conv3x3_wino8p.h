@@ -23,7 +23,10 @@ namespace fisr {
 struct first_t { static constexpr bool value = true; };    // tags: first K iteration of a work item / the others
 struct rest_t { static constexpr bool value = false; };
 
-template <bool RELU_IN>
+// GENERAL = false: FISRnet (dense NHWC tensors, relu).  GENERAL = true: PWC-Net's layers as well -- channel ranges of a
+// wider buffer as input and output (in0_cs, rec_cs, rec_co), leaky relu (slope), dilation (dil).  A template flag because
+// the K loops have no register to spare: the extra kernel arguments alone make the compiler spill.
+template <bool RELU_IN, bool GENERAL>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p, const int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sV = smem;
@@ -39,15 +42,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
   const int nh = (wave >> 1) & 1;   // which 32 of the 64 output channels
   const int ph = wave >> 2;         // which 8 of the 16 transform positions
 
-  const int tiles_x = (p.W + TILE_W - 1) / TILE_W;
-  const int tiles_y = (p.H + TILE_H - 1) / TILE_H;
+  // Dilation d (PWC-Net's context network): the image is d x d interleaved sub-images (pixel (y, x) belongs to sub-image
+  // (y % d, x % d)) and a dilated 3x3 convolution is an ordinary one inside each of them -- zero padding included.  The
+  // tiles and all tile coordinates below live in a sub-image; only the addresses are scaled back.  d = 1: one sub-image.
+  const int dil = GENERAL ? p.dil : 1;                 // (a compile-time 1 for FISRnet: no index arithmetic is added)
+  const int in0_cs = GENERAL ? p.in0_cs : p.C0, in1_cs = GENERAL ? p.in1_cs : p.C1;
+  const int rec_cs = GENERAL ? p.rec_cs : p.Cout, rec_co = GENERAL ? p.rec_co : 0;
+  const float slope = GENERAL ? p.slope : 0.f;
+  const int tiles_x = ((p.W + dil - 1) / dil + TILE_W - 1) / TILE_W;
+  const int tiles_y = ((p.H + dil - 1) / dil + TILE_H - 1) / TILE_H;
   const int nblocks = p.CoutPad / W_BN;
   const int nch = (p.C0 + p.C1) / W_CH;
 
   // work item b (0 .. n_items-1) -> (x0, y0, nb, nblk): XCD-aware order as in conv3x3.h -- workgroup w runs on XCD
   // w % 8, gridDim.x is a multiple of 8, so all items of a workgroup stay on one XCD and each XCD walks a contiguous
   // range of virtual ids in which the N-blocks of one pixel tile are consecutive.
-  struct Item { int x0, y0, nb, nblk; };
+  struct Item { int x0, y0, nb, nblk, ry, rx; };       // (x0, y0): in sub-image (ry, rx)
   auto item_of = [&](int b) {
     const int q = n_items >> 3, r = n_items & 7;
     const int xcd = b & 7, loc = b >> 3;
@@ -56,8 +66,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     Item it;
     it.nblk = v - t * nblocks;
     const int tx_ = t % tiles_x; t /= tiles_x;
-    const int ty_ = t % tiles_y;
-    it.nb = t / tiles_y;
+    const int ty_ = t % tiles_y; t /= tiles_y;
+    const int sub = t % (dil * dil);
+    it.nb = t / (dil * dil);
+    it.ry = sub / dil; it.rx = sub - it.ry * dil;
     it.x0 = tx_ * TILE_W; it.y0 = ty_ * TILE_H;
     return it;
   };
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       const int pix = min(u >> 1, HALO_PIX - 1);
       const int py = pix / HALO_W, ix = pix - py * HALO_W;
       const int px = ix < HALO_W / 2 ? 2 * ix : 2 * (ix - HALO_W / 2) + 1;     // even columns first, then the odd ones
-      const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
+      const int gy = (it.y0 - 1 + py) * dil + it.ry, gx = (it.x0 - 1 + px) * dil + it.rx;
       raw_gp[i] = (unsigned)((it.nb * p.H + min(max(gy, 0), p.H - 1)) * p.W + min(max(gx, 0), p.W - 1));
     }
   };
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       const int pix = min(u >> 1, HALO_PIX - 1);
       const int py = pix / HALO_W, ix = pix - py * HALO_W;
       const int px = ix < HALO_W / 2 ? 2 * ix : 2 * (ix - HALO_W / 2) + 1;     // even columns first, then the odd ones
-      const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
+      const int gy = (it.y0 - 1 + py) * dil + it.ry, gx = (it.x0 - 1 + px) * dil + it.rx;
       fix_ok[i] = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) || u >= W_RAW_UNITS;
       fix_any = fix_any || !fix_ok[i];
     }
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     const int c0 = kc * W_CH;
     const bool first = c0 < p.C0;
     const char* g = first ? (const char*)p.in0 + (size_t)c0 * 4 : (const char*)p.in1 + (size_t)(c0 - p.C0) * 4;
-    const unsigned cs = (unsigned)(first ? p.in0_cs : p.in1_cs) * 4u, ho = (unsigned)(ct & 1) * 16u;
+    const unsigned cs = (unsigned)(first ? in0_cs : in1_cs) * 4u, ho = (unsigned)(ct & 1) * 16u;
     const unsigned o0 = raw_gp[0] * cs + ho, o1 = raw_gp[1] * cs + ho, o2 = raw_gp[2] * cs + ho;
     const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)W_RAW;
     unsigned keep;
@@ -453,17 +465,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     // quad's four pixels, 64 contiguous bytes per quad and instruction)
     auto load_res = [&](int row, uint4 (&rres)[2][4]) {      // rres[output column j][pixel k of the quad]
       const Geo g = geometry();
-      const char* const res_base = (const char*)p.res + ((size_t)(cur.nb * p.H + cur.y0) * p.W * p.rec_cs + p.rec_co) * 4;
-      const int oy = cur.y0 + 2 * g.ty + row;
+      const char* const res_base = (const char*)p.res + ((size_t)cur.nb * p.H * p.W * rec_cs + rec_co) * 4;
+      const int oy = (cur.y0 + 2 * g.ty + row) * dil + cur.ry;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int x = cur.x0 + 2 * (g.txq + k) + j;
+          const int x = (cur.x0 + 2 * (g.txq + k) + j) * dil + cur.rx;
           rres[j][k] = make_uint4(0u, 0u, 0u, 0u);
           if (!(FISR_WABL & 256) && p.res != nullptr && g.c_ok && oy < p.H && x < p.W)
             rres[j][k] = *reinterpret_cast<const uint4*>(
-                res_base + ((unsigned)((2 * g.ty + row) * p.W + x) * (unsigned)p.rec_cs + (unsigned)(g.c0 + 4 * (lane & 3))) * 4u);
+                res_base + ((unsigned)(oy * p.W + x) * (unsigned)rec_cs + (unsigned)(g.c0 + 4 * (lane & 3))) * 4u);
         }
     };
 
@@ -504,7 +516,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     const Geo geo = geometry();
     const int ty = geo.ty, txq = geo.txq, c0 = geo.c0;
     const bool c_ok = geo.c_ok;
-    const int oy0 = cur.y0 + 2 * ty;
     if (ph == 1) {
       float bv[16];
       {
@@ -537,15 +548,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     if (p.trace && n_done == tr_item) t_bar = __builtin_readcyclecounter();
     if (ph == 0) {
       const int cq_shift = p.d2s_shift;
-      // element offset of the record of pixel (y0 + dy, xc) from the item's first row (8 or 16 rows: fits 32 bits)
-      char* const out_base = (char*)p.out + (p.d2s ? ((size_t)(cur.nb * 2 * p.H + 2 * cur.y0) * (2 * p.W) << cq_shift) * 4
-                                                   : ((size_t)(cur.nb * p.H + cur.y0) * p.W * p.rec_cs + p.rec_co) * 4);
-      auto record = [&](int dy, int xc) -> unsigned {
+      // element offset of the record of pixel (y, xc) inside image nb (one image of the tensor: fits 32 bits)
+      char* const out_base = (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4
+                                                   : ((size_t)cur.nb * p.H * p.W * rec_cs + rec_co) * 4);
+      auto record = [&](int y, int xc) -> unsigned {
         if (p.d2s) {
           const int sub = c0 >> cq_shift, c = c0 & ((1 << cq_shift) - 1);
-          return ((unsigned)((2 * dy + (sub >> 1)) * (2 * p.W) + 2 * xc + (sub & 1)) << cq_shift) + (unsigned)c;
+          return ((unsigned)((2 * y + (sub >> 1)) * (2 * p.W) + 2 * xc + (sub & 1)) << cq_shift) + (unsigned)c;
         }
-        return (unsigned)(dy * p.W + xc) * (unsigned)p.rec_cs + (unsigned)c0;
+        return (unsigned)(y * p.W + xc) * (unsigned)rec_cs + (unsigned)c0;
       };
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -567,9 +578,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
             o0[e] = y0.x; o0[e + 1] = y0.y; o1[e] = y1.x; o1[e + 1] = y1.y;
           }
           if (p.relu_out) {
-            if (p.slope != 0.f) {                // leaky relu (0 < slope < 1)
+            if (slope != 0.f) {                // leaky relu (0 < slope < 1)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], p.slope * o0[e]); o1[e] = fmaxf(o1[e], p.slope * o1[e]); }
+              for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], slope * o0[e]); o1[e] = fmaxf(o1[e], slope * o1[e]); }
             } else {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -586,9 +597,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
           quad_transpose(rec[row], lane);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int x = cur.x0 + 2 * (txq + k) + j, oy = oy0 + row;
+            const int x = (cur.x0 + 2 * (txq + k) + j) * dil + cur.rx, oy = (cur.y0 + 2 * ty + row) * dil + cur.ry;
             if (!(FISR_WABL & 128) && c_ok && oy < p.H && x < p.W) {
-              u32x4_t* dst = reinterpret_cast<u32x4_t*>(out_base + (record(2 * ty + row, x) + 4u * (lane & 3)) * 4u);
+              u32x4_t* dst = reinterpret_cast<u32x4_t*>(out_base + (record(oy, x) + 4u * (lane & 3)) * 4u);
               __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, rec[row][k]), dst);
             }
           }

@@ -253,10 +253,10 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
 // the kernel's LDS image (conv3x3_wino.h): [Cin/8][Cout/64][position 16][row 64][32-byte record], the two 16-byte
 // halves of a record swapped when bit 3 of the row is set; rows in the MFMA row order of pack_weights.
 inline bool wino_eligible(int ci, int co) { (void)ci; return co >= W_BN && co % W_BN == 0; }
-// the kernel addresses its input tensors, and 16 pixel rows of its output, with 32-bit byte offsets
+// the kernel addresses its input tensors, and one image of its output, with 32-bit byte offsets
 inline bool wino_fits(int n, int h, int w, int c0, int c1, int co) {
   const double px = (double)n * h * w;
-  return px * std::max(c0, c1) * 4.0 < 4294967296.0 && 16.0 * w * co * 4.0 < 4294967296.0;
+  return px * std::max(c0, c1) * 4.0 < 4294967296.0 && (double)h * w * co * 4.0 < 4294967296.0;
 }
 // (co need not be a multiple of the 64-channel block: the last block is zero padded, the kernel skips the stores)
 void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
@@ -364,11 +364,12 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    const void* kerns[5] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
+    const void* kerns[6] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
                             reinterpret_cast<const void*>(conv3x3_wino8_kernel<false>),
                             reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true>)};
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true>)};
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
@@ -378,11 +379,14 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
     n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     attr_done[dev] = true;
   }
-  const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
+  const int d = a.dil;
+  const int tiles = (((a.W + d - 1) / d + TILE_W - 1) / TILE_W) * (((a.H + d - 1) / d + TILE_H - 1) / TILE_H) * d * d * a.N;
   const int items = tiles * (a.CoutPad / W_BN);
   const int nch = (a.C0 + a.C1) / W_CH;
-  // channel-range input / output and leaky relu exist in the persistent kernel only
-  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f;
+  // channel-range input / output, leaky relu and dilation exist in the persistent kernel only
+  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 &&
+                     a.slope == 0.f && d == 1;
+  if (d < 1 || (d > 1 && a.d2s)) return hipErrorInvalidValue;
   if (!plain && (variant == 4 || variant == 8 || nch < 4)) return hipErrorInvalidValue;
   if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(items), dim3(256), lds, st, a);
   else if (variant == 8 || nch < 4) {
@@ -392,8 +396,11 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
     // one workgroup per CU (the kernel needs all of a CU's LDS and half its registers), a multiple of 8 so that the
     // items of a workgroup stay on one XCD
     const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
-    if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8p_kernel<true>, dim3(grid), dim3(512), lds, st, a, items);
-    else hipLaunchKernelGGL(conv3x3_wino8p_kernel<false>, dim3(grid), dim3(512), lds, st, a, items);
+    if (!plain) {
+      if (a.relu_in) return hipErrorInvalidValue;      // (not instantiated: PWC-Net's activations come out of the producer)
+      hipLaunchKernelGGL((conv3x3_wino8p_kernel<false, true>), dim3(grid), dim3(512), lds, st, a, items);
+    } else if (a.relu_in) hipLaunchKernelGGL((conv3x3_wino8p_kernel<true, false>), dim3(grid), dim3(512), lds, st, a, items);
+    else hipLaunchKernelGGL((conv3x3_wino8p_kernel<false, false>), dim3(grid), dim3(512), lds, st, a, items);
   }
   return hipGetLastError();
 }
@@ -533,7 +540,7 @@ struct Runner {
     ConvArgs a;
     a.in0 = in0; a.in1 = in1; a.wpk = cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
     a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cw.co; a.CoutPad = cw.cout_pad;
-    a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cw.co; a.rec_co = 0; a.slope = 0.f;
+    a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cw.co; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
     a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
     a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
     a.d2s = (flags & FISR_CONV_D2S) != 0;
@@ -965,7 +972,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
-  a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f;
+  a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
@@ -1055,7 +1062,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   ConvArgs a;
   a.in0 = d_in; a.in1 = nullptr; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = d_res; a.out = d_out;
   a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
-  a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f;
+  a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;

@@ -182,7 +182,7 @@ struct PwcRunner {
     if (rc || ar.dry) return;
     const PwcConv& pc = ctx->convs[name];
     static const bool no_wino = [] { const char* e = getenv("FISR_PWC_WINO"); return e && e[0] == '0'; }();
-    if (pc.d_wu && !no_wino && stride == 1 && dil == 1 && !add && (slope == 1.f || (slope > 0.f && slope < 1.f)) &&
+    if (pc.d_wu && !no_wino && stride == 1 && !add && (slope == 1.f || (slope > 0.f && slope < 1.f)) &&
         wino_fits(n, h, w, in_cs, 0, out_cs)) {
       // FISRnet's persistent Winograd kernel on a channel range of the buffer (fisr_api.hip: launch_conv_wino)
       ConvArgs a;
@@ -191,7 +191,7 @@ struct PwcRunner {
       a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
       a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
       a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = out_cs; a.rec_co = out_co; a.slope = slope != 1.f ? slope : 0.f;
-      a.trace = nullptr;
+      a.dil = dil; a.trace = nullptr;
       hipError_t e = launch_conv_wino(a, st);
       if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (winograd): " + hipGetErrorString(e));
       return;
@@ -203,7 +203,7 @@ struct PwcRunner {
       a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
       a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
       a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = pc.cout; a.rec_co = 0; a.slope = slope != 1.f ? slope : 0.f;
-      a.trace = nullptr;
+      a.dil = 1; a.trace = nullptr;
       const bool scatter = !(out_cs == pc.cout && out_co == 0);     // dense records, or per-channel fp32 stores
       hipError_t e = launch_conv<float>(a, pc.dw.nt, scatter, st);
       if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (direct): " + hipGetErrorString(e));
@@ -397,7 +397,7 @@ int fisr_pwc_finalize(fisr_pwc* c) {
     for (int i = 0; i < 7 && !rc; ++i) {
       const std::string n = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
       rc = i == 0 ? pwc_pack_conv(c, n, L.map_from(4), L.total, c->convs[n], true)
-                  : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n], PWC_CTXT[i][1] == 1);
+                  : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n], i < 6);
       ci = PWC_CTXT[i][0];
     }
     if (l != PWC_PRED && !rc) {
