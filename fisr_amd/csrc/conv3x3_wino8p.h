@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
 
   int n_done = 0;
   const int tr_item = max(2, (n_items / (int)gridDim.x) >> 1);     // the item whose timeline is traced (mid-run)
-  unsigned long long t_it0 = 0, t_it1 = 0, t_it2 = 0, t_itk = 0, t_bar = 0;
+  unsigned long long t_it0 = 0, t_it1 = 0, t_it2 = 0, t_itk = 0, t_bar = 0, t_r0 = 0, t_r2 = 0;
 
   // The MFMAs of a chunk are skewed by one stage against the barriers: an iteration runs stage 3 of the PREVIOUS chunk
   // (its fragments were loaded into registers before the barrier) and stages 0-2 of its own chunk, and leaves its own
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
             : SUB(SUB(FISR_W8_PAIR((QB) + 1, R), FISR_W8_PAIR((QB) + 2, R)), FISR_W8_PAIR((QB) + 3, R)))
 
   for (;;) {                                            // ---- work items of this workgroup ----
-    if (p.trace && n_done == tr_item) t_it0 = __builtin_readcyclecounter();
+    if (p.trace && n_done == tr_item) { t_it0 = __builtin_readcyclecounter(); t_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     // Epilogue geometry of this item (see conv3x3_wino8.h): lane -> winograd tile (ty, tx), 16 channels from c0.
     // Output and residual are addressed as a per-item 64-bit base (the item's first pixel row) + 32-bit lane offsets.
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
         }
       }
     }
-    if (p.trace && n_done == tr_item) t_it2 = __builtin_readcyclecounter();
+    if (p.trace && n_done == tr_item) { t_it2 = __builtin_readcyclecounter(); t_r2 = __builtin_amdgcn_s_memrealtime(); }
     ++n_done;
     if (!has_next) break;
     lds_barrier();                               // the handed-over rows are read before the next item overwrites V / U
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     const bool third = n_done > tr_item;
     tr[0] = third ? t_it0 : t_start; tr[1] = third ? t_it1 : t_main; tr[2] = third ? t_it2 : __builtin_readcyclecounter();
     tr[3] = t_bar;
-    tr[4] = third ? t_itk : t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)n_done;
+    tr[4] = third ? t_itk : t_first; tr[5] = third ? t_r0 : t_real; tr[6] = third ? t_r2 : __builtin_amdgcn_s_memrealtime();
+    tr[7] = (unsigned long long)n_done;
   }
 }
 

@@ -551,7 +551,7 @@ struct Runner {
     const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
     char cls[96];
-    if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8<f32w,%s>", a.relu_in ? "relu_in" : "plain");
+    if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s>", a.relu_in ? "relu_in" : "plain");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
     std::string cname(cls);
     if (ctx->prof_mode == 2) {

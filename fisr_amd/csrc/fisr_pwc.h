@@ -281,7 +281,15 @@ struct PwcRunner {
           cv2 = Wp;
         }
         if (!rc && !ar.dry) {
-          hipLaunchKernelGGL(pwc_costvol_kernel, dim3(grid_for(px * 9)), dim3(256), 0, st, c1, cv2, PWC_CH[l], D, L.total,
+          static bool cv_attr[64] = {};
+          int dev = 0; (void)hipGetDevice(&dev);
+          if (dev >= 0 && dev < 64 && !cv_attr[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_costvol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)costvol_lds_bytes());
+            cv_attr[dev] = true;
+          }
+          const int cv_tiles = ((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H);
+          hipLaunchKernelGGL(pwc_costvol_kernel, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, cv2, PWC_CH[l], D, L.total,
                              L.off_corr, 1, h, w);                   // :1277 (leaky relu inside core_costvol)
           check("cost volume");
         }

@@ -11,7 +11,8 @@
 //                         channels with all 9 tap-shifted pixel blocks staged in LDS (stride / dilation / padding are
 //                         resolved by the loader, the MFMA loop is the same for every layer).
 //   pwc_deconv_kernel     tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196)
-//   pwc_costvol_kernel    core_costvol.cost_volume: 81 displacements, mean over channels, leaky relu (:1277)
+//   pwc_costvol_kernel    core_costvol.cost_volume: 81 displacements, mean over channels, leaky relu (:1277); w2 tiled
+//                         through LDS
 //   pwc_warp_kernel       core_warp.dense_image_warp: bilinear sample at (x + u, y + v), clamped (:1178)
 //   pwc_prep_kernel       script :121-131 + adapt_x (:399-411): YUV uint8 -> RGB (double), x2 up-resize as
 //                         scikit-image does it, uint8 truncation, / 255, zero pad to a multiple of 64
@@ -171,37 +172,74 @@ __global__ void pwc_deconv_kernel(const float* __restrict__ in, int in_cs, int i
 }
 
 // cost volume: out[px][(dy+4)*9 + (dx+4)] = leaky_relu(mean_c c1[px][c] * w2[px + (dy, dx)][c], 0.1), zero outside.
-// One thread per (pixel, dy): nine running sums over dx.
-__global__ void pwc_costvol_kernel(const float* __restrict__ c1, const float* __restrict__ w2, int C, float* __restrict__ out,
-                                   int out_cs, int out_co, int N, int H, int W) {
-  const size_t total = (size_t)N * H * W * 9;
-  const float inv = 1.f / (float)C;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int dyi = (int)(i % 9);
-    const size_t pix = i / 9;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
-    const int yy = y + dyi - 4;
-    float s[9];
+// One workgroup per 8x32 pixel tile, one thread per pixel with all 81 sums in registers; the (8+8) x (32+8) halo of w2
+// goes through LDS 16 channels at a time (80-byte records: a ds_read_b128 phase of 16 neighbouring pixels hits every
+// bank once), so w2 is read from HBM/L2 once per tile instead of 81 times per pixel through L1.
+constexpr int CV_CH = 16;
+constexpr int CV_REC = CV_CH * 4 + 16;
+constexpr int CV_HW = TILE_W + 8, CV_HH = TILE_H + 8;
+constexpr size_t costvol_lds_bytes() { return (size_t)CV_HH * CV_HW * CV_REC; }
+
+__global__ __launch_bounds__(256) void pwc_costvol_kernel(const float* __restrict__ c1, const float* __restrict__ w2, int C,
+                                                          float* __restrict__ out, int out_cs, int out_co, int N, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) char cv_smem[];
+  const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+  const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  int t = blockIdx.x;
+  const int tx_ = t % tiles_x; t /= tiles_x;
+  const int ty_ = t % tiles_y;
+  const int n = t / tiles_y;
+  const int x0 = tx_ * TILE_W, y0 = ty_ * TILE_H;
+  const int x = x0 + tx, y = y0 + ty;
+  const bool inside = x < W && y < H;
+  const size_t pix = ((size_t)n * H + min(y, H - 1)) * W + min(x, W - 1);
+  float s[81];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = 0.f;
-    if (yy >= 0 && yy < H) {
-      const f32x4* a = reinterpret_cast<const f32x4*>(c1 + pix * C);
-      for (int c = 0; c < C / 4; ++c) {
-        const f32x4 av = a[c];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const int xx = x + k - 4;
-          if (xx >= 0 && xx < W) {
-            const f32x4 bv = reinterpret_cast<const f32x4*>(w2 + ((size_t)(n * H + yy) * W + xx) * C)[c];
-            s[k] += av.x * bv.x + av.y * bv.y + av.z * bv.z + av.w * bv.w;
-          }
-        }
-      }
+  for (int k = 0; k < 81; ++k) s[k] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += CV_CH) {
+    const int nq = min(4, (C - c0) >> 2);                 // 16-byte quarters of this chunk that exist (C % 4 == 0)
+    for (int i = tid; i < CV_HH * CV_HW * 4; i += 256) {  // halo chunk of w2 -> LDS, zeros outside the image
+      const int hp = i >> 2, q = i & 3;
+      const int hy = hp / CV_HW, hx = hp - hy * CV_HW;
+      const int gy = y0 - 4 + hy, gx = x0 - 4 + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < nq && gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const f32x4*>(w2 + (((size_t)n * H + gy) * W + gx) * C + c0 + 4 * q);
+      *reinterpret_cast<f32x4*>(cv_smem + hp * CV_REC + q * 16) = v;
     }
-    float* o = out + pix * out_cs + out_co + dyi * 9;
+    f32x4 a[4];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { const float v = s[k] * inv; o[k] = v >= 0.f ? v : 0.1f * v; }
+    for (int q = 0; q < 4; ++q) {
+      a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < nq) a[q] = *reinterpret_cast<const f32x4*>(c1 + pix * C + c0 + 4 * q);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 9; ++dx) {
+        const char* r = cv_smem + ((ty + dy) * CV_HW + tx + dx) * CV_REC;
+        float acc = s[dy * 9 + dx];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(r + q * 16);
+          acc += a[q].x * b.x + a[q].y * b.y + a[q].z * b.z + a[q].w * b.w;
+        }
+        s[dy * 9 + dx] = acc;
+      }
+    __syncthreads();
   }
+  if (!inside) return;
+  const float inv = 1.f / (float)C;
+  float* o = out + pix * out_cs + out_co;
+#pragma unroll
+  for (int k = 0; k < 80; k += 4) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float m = s[k + e] * inv; v[e] = m >= 0.f ? m : 0.1f * m; }
+    *reinterpret_cast<f32x4*>(o + k) = v;
+  }
+  { const float m = s[80] * inv; o[80] = m >= 0.f ? m : 0.1f * m; }
 }
 
 // dense_image_warp: out[px][c] = bilinear(img, x + scale*u, y + scale*v); floor index clamped to [0, size-2], weight
