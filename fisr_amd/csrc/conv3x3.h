@@ -536,9 +536,16 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
   constexpr int NWT = (9 * BN * 4 + NTHR - 1) / NTHR;           // ... and for the weight slab
   constexpr int PIX_STEP = QUAD ? NTHR : (P::PAIR_LOAD ? NTHR / 2 : NTHR / 4);
   const int slot = QUAD ? 0 : (P::PAIR_LOAD ? (tid & 1) : (tid & 3));
-  const int pix_lo = QUAD ? tid : (P::PAIR_LOAD ? (tid >> 1) : (tid >> 2));
+  // Which record a thread stages: consecutive threads fill the slots of one record (one contiguous 64 bytes from
+  // global memory), but the records of the 16 lanes that share a ds_write_b128 phase are spread over their block of 16
+  // so that the phase hits every bank once -- records 80 B apart start at 16-byte unit 5 * rec: four neighbouring
+  // records x 4 slots collide on three units (0..3, 5..8, 10..13, 15..18 = 15, 0, 1, 2), records g, g+4, g+8, g+12 do
+  // not (0.., 4.., 8.., 12..); with two slots per thread (bsplit hi / lo halves) eight same-parity records do not.
+  auto spread4 = [](int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); };
+  auto spread2 = [](int r) { return (r & ~15) | ((r & 7) << 1) | ((r >> 3) & 1); };
+  const int pix_lo = QUAD ? tid : (P::PAIR_LOAD ? spread2(tid >> 1) : spread4(tid >> 2));
   const int wslot = tid & 3;
-  const int wrec_lo = tid >> 2;
+  const int wrec_lo = spread4(tid >> 2);
   int in_pix[NPIX_IT];  // linear pixel index in the source image, -1 = zero padding / no unit
 #pragma unroll
   for (int i = 0; i < NPIX_IT; ++i) {
