@@ -592,6 +592,10 @@ def main():
                                                    "all_conv_tflops") if k in rl} if rl else None,
                    "parity_vs_" + args.precision: compare(out_alt, out_main, f"{alt} vs the {args.precision} engine"),
                    "parity_vs_oracle": None if args.no_parity else oracle_tile_check(eng, torch)}
+            if cfg5 and "flow_ms" in cfg5:   # cfg5 of BASELINE.json names a 16-bit engine: the same flow + warps in front of THIS engine's step
+                tot = cfg5["flow_ms"] + cfg5["warp_ms"] + dt * 1e3
+                rec["cfg5_flow_pipeline"] = {"value": round(UNIQUE_PER_STACK / (tot * 1e-3), 3), "unit": "frames/s",
+                                             "flow_ms": cfg5["flow_ms"], "warp_ms": cfg5["warp_ms"], "fisrnet_ms": round(dt * 1e3, 2)}
             other[alt] = rec
             eng.close()
             del eng, out_alt

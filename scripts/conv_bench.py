@@ -19,6 +19,8 @@ SHAPES = [  # n, h, w, cin, cout, flags, res
     (12, 136, 248, 64, 64, 3, 1),
     (1, 544, 992, 64, 64, 3, 1),
 ]
+if os.environ.get("CONV_SHAPES"):   # "n,h,w,cin,cout,flags,res;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["CONV_SHAPES"].split(";")]
 PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}
 L = lib.lib()
 for prec in (sys.argv[1:] or ["bf16x3"]):
