@@ -295,6 +295,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
 
   // ---- prologue of the workgroup's FIRST item ----
   int b_cur = blockIdx.x;
+  // the copy waves go first where the two waves of a SIMD compete (measured: -2 % on the 256-channel layers, nothing
+  // on the 64-channel ones; the other way round: nothing)
+  if (ph == 1) __builtin_amdgcn_s_setprio(3);
   Item cur = item_of(b_cur);
   int b_nxt = b_cur + gridDim.x;
   bool has_next = valid(b_nxt);
