@@ -1111,3 +1111,4 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
 
 #include "fisr_comm.h"
 #include "fisr_pwc.h"
+#include "fisr_train.h"

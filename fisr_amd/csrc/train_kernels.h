@@ -1,0 +1,332 @@
+// Kernels of the training graph (FISRnet.py:175-497, ops.py:7-76 differentiated).  All fp32, NHWC.
+//
+//   train_pack_kernel      master weights (TF HWIO, device) -> the direct conv kernel's packed layout (conv3x3.h), either as
+//                          they are (forward) or with the taps rotated by 180 degrees and Ci / Co swapped (data gradient:
+//                          dx = conv(dy, rot180(w)^T), the same forward kernel then does the work)
+//   train_wgrad_kernel     dW[tap][ci][co] += sum over pixels of x[p + tap][ci] * g[p][co]: a GEMM whose K is the pixel
+//                          axis, on v_mfma_f32_32x32x2_f32 (A = 32 input channels x 2 pixels, B = 2 pixels x 32 output
+//                          channels, one accumulator per tap), halo tile of x and tile of g staged in LDS
+//   train_bgrad_kernel     db[co] += sum over pixels of g[p][co]
+//   relu_bwd, maxpool2_bwd, upsample2_bwd (adjoint of the legacy bilinear), space_to_depth (adjoint of depth_to_space),
+//   axpy, gather / scatter of channel ranges, the loss kernel (all seven terms of FISRnet.py:316-484 and their gradient
+//   with respect to the twelve predicted frames of a level), Adam (tf.train.AdamOptimizer, TF 1.13)
+#pragma once
+#include "conv3x3.h"
+
+namespace fisr {
+
+// ---- weights: HWIO -> packed rows of the direct fp32 kernel (pack_weights<float> in fisr_api.hip, on the device) ----
+// transpose = 0: src[tap][c][n]; transpose = 1: the conv has ci' = co, co' = ci and src'[tap][c'][n'] = src[8 - tap][n'][c'].
+__global__ void train_pack_kernel(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
+                                  int cin_pad, int cout_pad, float* __restrict__ out) {
+  const size_t total = (size_t)(cin_pad / 16) * 9 * cout_pad * 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i & 15);
+    size_t t = i >> 4;
+    const int row = (int)(t % cout_pad); t /= cout_pad;
+    const int tap = (int)(t % 9);
+    const int kc = (int)(t / 9);
+    // row -> channel n (inverse of row = (n & ~31) + (wr & 3) + 8 * (wr >> 2) + 4 * wk, wi = n & 31, wk = wi >> 4, wr = wi & 15)
+    int n;
+    if (cout_pad == 16) n = row;
+    else {
+      const int r5 = row & 31, wk = (r5 >> 2) & 1, wr = (r5 & 3) + 4 * (r5 >> 3);
+      n = (row & ~31) + 16 * wk + wr;
+    }
+    const int c = kc * 16 + cc;
+    float v = 0.f;
+    if (c < ci && n < co)
+      v = transpose ? w[((size_t)(8 - tap) * ci_src + n) * co_src + c] : w[((size_t)tap * ci_src + c) * co_src + n];
+    out[i] = v;
+  }
+}
+
+// ---- weight gradient ----
+struct WgradArgs {
+  const float* x0; const float* x1; int C0, C1;     // conv input: cat(x0, x1) along channels (x1 nullable), pixel strides C0, C1
+  const float* g;  int Cg;                          // gradient of the conv output [N,H,W,Cg] (dense)
+  float* dw;       int ci, co;                      // HWIO [3][3][ci][co], accumulated (ci <= C0 + C1, co <= Cg)
+  int N, H, W, relu_in, ksplit;
+};
+constexpr int WG_TH = 8, WG_TW = 32;
+constexpr size_t wgrad_lds_bytes() { return (size_t)((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4; }
+
+__global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+  float* const sX = reinterpret_cast<float*>(wg_smem);                       // [(8+2) x (32+2) px][32 ci]
+  float* const sG = sX + (WG_TH + 2) * (WG_TW + 2) * 32;                     // [8 x 32 px][32 co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int nci = (p.ci + 31) / 32, nco = (p.co + 31) / 32;
+  const int blk = blockIdx.x % (nci * nco), ks = blockIdx.x / (nci * nco);
+  const int cib = (blk / nco) * 32, cob = (blk % nco) * 32;
+  const int tiles_x = (p.W + WG_TW - 1) / WG_TW, tiles_y = (p.H + WG_TH - 1) / WG_TH;
+  const int ntiles = tiles_x * tiles_y * p.N;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int tile = ks; tile < ntiles; tile += p.ksplit) {
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int nb = t / tiles_y;
+    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
+    __syncthreads();
+    for (int i = tid; i < (WG_TH + 2) * (WG_TW + 2) * 8; i += 256) {      // x halo tile, 4 channels per thread
+      const int px = i >> 3, q = i & 7;
+      const int py = px / (WG_TW + 2), pxx = px - py * (WG_TW + 2);
+      const int gy = y0 - 1 + py, gx = x0 - 1 + pxx, c = cib + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        const size_t pix = ((size_t)nb * p.H + gy) * p.W + gx;
+        if (c < p.C0) v = *reinterpret_cast<const f32x4*>(p.x0 + pix * p.C0 + c);            // (C0 % 4 == 0)
+        else if (c < p.C0 + p.C1) v = *reinterpret_cast<const f32x4*>(p.x1 + pix * p.C1 + (c - p.C0));
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      *reinterpret_cast<f32x4*>(sX + px * 32 + 4 * q) = v;
+    }
+    for (int i = tid; i < WG_TH * WG_TW * 8; i += 256) {                   // g tile
+      const int px = i >> 3, q = i & 7;
+      const int py = px / WG_TW, pxx = px - py * WG_TW;
+      const int gy = y0 + py, gx = x0 + pxx, c = cob + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < p.H && gx < p.W) {
+        const float* src = p.g + (((size_t)nb * p.H + gy) * p.W + gx) * p.Cg + c;
+        if (c + 3 < p.Cg) v = *reinterpret_cast<const f32x4*>(src);                          // (Cg % 4 == 0 or a ragged tail)
+        else { if (c < p.Cg) v.x = src[0]; if (c + 1 < p.Cg) v.y = src[1]; if (c + 2 < p.Cg) v.z = src[2]; }
+      }
+      *reinterpret_cast<f32x4*>(sG + px * 32 + 4 * q) = v;
+    }
+    __syncthreads();
+    // wave w: tile rows 2w, 2w+1; K steps of two neighbouring pixels
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wave + rr;
+#pragma unroll 2
+      for (int col = 0; col < WG_TW; col += 2) {
+        const float b = sG[(row * WG_TW + col + kh) * 32 + li];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float a = sX[((row + tap / 3) * (WG_TW + 2) + col + kh + tap % 3) * 32 + li];
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D layout: column (co) = lane & 31, row (ci) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int n = cob + li;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = cib + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (c < p.ci && n < p.co) unsafeAtomicAdd(p.dw + ((size_t)tap * p.ci + c) * p.co + n, acc[tap][r]);
+    }
+}
+
+// db[c] += sum_p g[p][c]   (grid (pixel blocks, ceil(C / 64)); 256 threads = 64 channels x 4 pixel phases)
+__global__ void train_bgrad_kernel(const float* __restrict__ g, int C, size_t npix, float* __restrict__ db, int co) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  if (c >= C) return;
+  float s = 0.f;
+  for (size_t pix = (size_t)blockIdx.x * 4 + sub; pix < npix; pix += (size_t)gridDim.x * 4) s += g[pix * C + c];
+  if (c < co) unsafeAtomicAdd(db + c, s);
+}
+
+// g_out = g_in * (ref > 0)    (in place allowed)
+__global__ void train_relu_bwd_kernel(const float* __restrict__ g_in, const float* __restrict__ ref, float* __restrict__ g_out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(g_in)[i], r = reinterpret_cast<const f32x4*>(ref)[i];
+    f32x4 o;
+    o.x = r.x > 0.f ? g.x : 0.f; o.y = r.y > 0.f ? g.y : 0.f; o.z = r.z > 0.f ? g.z : 0.f; o.w = r.w > 0.f ? g.w : 0.f;
+    reinterpret_cast<f32x4*>(g_out)[i] = o;
+  }
+}
+
+// y += a * x
+__global__ void train_axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 o = reinterpret_cast<f32x4*>(y)[i];
+    o.x += a * v.x; o.y += a * v.y; o.z += a * v.z; o.w += a * v.w;
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
+// 2x2 max-pool backward (ops.py:54): the gradient of a window goes to its first maximum in row-major order.
+// x [N,H,W,C], dpool [N,H/2,W/2,C] -> dx [N,H,W,C] (every element written)
+__global__ void train_maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dp, float* __restrict__ dx,
+                                          int N, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2, C4 = C / 4;
+  const size_t total = (size_t)N * OH * OW * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t t = i / C4;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const size_t base = (((size_t)n * H + 2 * oy) * W + 2 * ox) * C + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + base), b = *reinterpret_cast<const f32x4*>(x + base + C);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(x + base + (size_t)W * C), e = *reinterpret_cast<const f32x4*>(x + base + (size_t)W * C + C);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dp + (((size_t)n * OH + oy) * OW + ox) * C + c);
+    f32x4 ga, gb, gd, ge;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float m = fmaxf(fmaxf(a[k], b[k]), fmaxf(d[k], e[k]));
+      const int w = a[k] == m ? 0 : (b[k] == m ? 1 : (d[k] == m ? 2 : 3));
+      ga[k] = w == 0 ? g[k] : 0.f; gb[k] = w == 1 ? g[k] : 0.f; gd[k] = w == 2 ? g[k] : 0.f; ge[k] = w == 3 ? g[k] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dx + base) = ga; *reinterpret_cast<f32x4*>(dx + base + C) = gb;
+    *reinterpret_cast<f32x4*>(dx + base + (size_t)W * C) = gd; *reinterpret_cast<f32x4*>(dx + base + (size_t)W * C + C) = ge;
+  }
+}
+
+// Adjoint of the legacy x2 bilinear (ops.py:69; glue_kernels.h upsample2): out[2i] = x[i], out[2i+1] = x[i] + (x[i'] - x[i]) / 2,
+// i' = min(i + 1, last), along W first and then along H.  Hence per axis dx[i] = d[2i] + d[2i+1] / 2 + d[2i-1] / 2 (i >= 1)
+// and the last sample also keeps the second half of its own odd neighbour.  dy [N,2H,2W,C] -> dx [N,H,W,C].
+__global__ void train_upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    // weights of the (up to) 3 contributing fine samples per axis: fine index 2i-1, 2i, 2i+1
+    float wy[3] = {y > 0 ? 0.5f : 0.f, 1.f, y == H - 1 ? 1.f : 0.5f};
+    float wx[3] = {x > 0 ? 0.5f : 0.f, 1.f, x == W - 1 ? 1.f : 0.5f};
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (wy[a] == 0.f) continue;
+      const int fy = 2 * y - 1 + a;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        if (wx[b] == 0.f) continue;
+        const int fx = 2 * x - 1 + b;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((size_t)n * 2 * H + fy) * (2 * W) + fx) * C + c);
+        const float w = wy[a] * wx[b];
+        s.x += w * v.x; s.y += w * v.y; s.z += w * v.z; s.w += w * v.w;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + (((size_t)n * H + y) * W + x) * C + c) = s;
+  }
+}
+
+// adjoint of tf.depth_to_space(x, 2) (FISRnet.py:99): out[h, w, (2i + j) * C + c] = g[2h + i, 2w + j, c]
+__global__ void train_s2d_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int H, int W, int C) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)N * H * W * 4 * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t t = i / C4;
+    const int sub = (int)(t & 3); t >>= 2;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + (((size_t)n * 2 * H + 2 * y + (sub >> 1)) * (2 * W) + 2 * x + (sub & 1)) * C + c);
+    *reinterpret_cast<f32x4*>(out + (((size_t)n * H + y) * W + x) * 4 * C + sub * C + c) = v;
+  }
+}
+
+// dst[p][dco + k] (op)= src[p][sco + k], k < nc   (channel ranges of NHWC tensors; add != 0 accumulates)
+__global__ void train_copy_channels_kernel(const float* __restrict__ src, int scs, int sco, float* __restrict__ dst, int dcs, int dco,
+                                           int nc, size_t npix, int add) {
+  const size_t total = npix * nc;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % nc);
+    const size_t pix = i / nc;
+    const float v = src[pix * scs + sco + k];
+    float* d = dst + pix * dcs + dco + k;
+    *d = add ? *d + v : v;
+  }
+}
+
+// ---- the seven loss terms of one level and their gradients (FISRnet.py:316-484) ----
+// pred[k], k = 0..2: the three stride-1 windows' outputs [B,h,w,9]; pred[3]: the stride-2 window's; gt [B,h,w,21].
+// Per element (pixel, colour c): p[3k + f] = pred[k][3f + c] (nine stride-1 frames), q[f] = pred[3][3f + c], t[f] = gt[3f + c].
+// L2_loss = mean over ITS tensor: n3 = B*h*w*9 for three-frame terms, n1 = B*h*w*3 for one-frame terms.
+// sums[0..6] += raw squared sums of recn, tm, tmm, td, recn_ss2, td_ss2, tm_ss2 (host applies the 1/n, level scale, lambdas).
+struct LossArgs {
+  const float* pred[4]; const float* gt; float* grad[4]; float* sums; size_t npix;
+  float k_recn, k_tm, k_tmm, k_td, k_recn2, k_td2, k_tm2;      // lambda * level scale * 2 / n of each term
+};
+__global__ void train_loss_kernel(const LossArgs a) {
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const size_t total = a.npix * 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 3);
+    const size_t pix = i / 3;
+    float p[9], q[3], t[7], gp[9], gq[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) p[3 * k + f] = a.pred[k][pix * 9 + 3 * f + c];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) q[f] = a.pred[3][pix * 9 + 3 * f + c];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) t[f] = a.gt[pix * 21 + 3 * f + c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gp[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gq[k] = 0.f;
+    // type 1: window k, frame f against GT frame 2k + f
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) { const float d = p[3 * k + f] - t[2 * k + f]; acc[0] += d * d; gp[3 * k + f] += a.k_recn * d; }
+    // types 2, 3: the overlapped frames p[3k+2], p[3k+3] and GT frame 2(k+1)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float d = p[3 * k + 2] - p[3 * k + 3];
+      acc[1] += d * d; gp[3 * k + 2] += a.k_tm * d; gp[3 * k + 3] -= a.k_tm * d;
+      const float m = (p[3 * k + 2] + p[3 * k + 3]) * 0.5f - t[2 * (k + 1)];
+      acc[2] += m * m; gp[3 * k + 2] += a.k_tmm * 0.5f * m; gp[3 * k + 3] += a.k_tmm * 0.5f * m;
+    }
+    // Groups2Ovlp (ops.py:119-144) and its adjoint
+    float o[7] = {p[0], p[1], (p[2] + p[3]) * 0.5f, p[4], (p[5] + p[6]) * 0.5f, p[7], p[8]}, go[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // type 4: temporal differences of the overlapped sequence
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const float d = (o[k + 1] - o[k]) - (t[k + 1] - t[k]); acc[3] += d * d; go[k + 1] += a.k_td * d; go[k] -= a.k_td * d; }
+    // stride 2: q against GT frames 1, 3, 5 (type 5), its differences (type 6), against the overlapped frames 1, 3, 5 (type 7)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const float d = q[f] - t[2 * f + 1]; acc[4] += d * d; gq[f] += a.k_recn2 * d;
+      const float e = q[f] - o[2 * f + 1]; acc[6] += e * e; gq[f] += a.k_tm2 * e; go[2 * f + 1] -= a.k_tm2 * e;
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float d = (q[f + 1] - q[f]) - (t[2 * f + 3] - t[2 * f + 1]); acc[5] += d * d; gq[f + 1] += a.k_td2 * d; gq[f] -= a.k_td2 * d;
+    }
+    gp[0] += go[0]; gp[1] += go[1]; gp[2] += 0.5f * go[2]; gp[3] += 0.5f * go[2]; gp[4] += go[3];
+    gp[5] += 0.5f * go[4]; gp[6] += 0.5f * go[4]; gp[7] += go[5]; gp[8] += go[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) a.grad[k][pix * 9 + 3 * f + c] = gp[3 * k + f];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) a.grad[3][pix * 9 + 3 * f + c] = gq[f];
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    float v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(a.sums + k, v);
+  }
+}
+
+// tf.train.AdamOptimizer (TF 1.13 training/adam.py): m, v, var updated in place; lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) from the host
+__global__ void train_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                  size_t n, float lr_t, float b1, float b2, float eps) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace fisr

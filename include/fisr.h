@@ -223,6 +223,36 @@ int fisr_pwc_nn(fisr_pwc* ctx, const float* im, int H, int W, float* flow_pred, 
 int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream);
 int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream);
 
+/* ---- training graph: the ops the reference gets from TensorFlow's autodiff and optimizer ----
+ * FISRnet.build_model (FISRnet.py:175-497) builds forward passes, seven loss terms and tf.train.AdamOptimizer in Python;
+ * tf.gradients supplies the backward ops.  fisr_amd/train.py keeps that structure (a Python tape over these entry
+ * points); each entry is one HIP kernel launch on device pointers.  All tensors fp32 NHWC, weights TF HWIO.
+ * In reference terms: fisr_train_conv3x3 = ops.py:7-11 Conv2d (+ fused relu / residual / depth_to_space) and, with
+ * weights packed `transpose`d, its Conv2DBackpropInput; fisr_train_wgrad / _bgrad = Conv2DBackpropFilter / BiasAddGrad;
+ * _relu_bwd = ReluGrad; _maxpool2_bwd = MaxPoolGrad (ops.py:54); _upsample2_bwd = ResizeBilinearGrad (ops.py:69);
+ * _s2d = the gradient of tf.depth_to_space (FISRnet.py:99); _copy_channels = the gradients of tf.concat / tf.split /
+ * tf.slice; _loss = FISRnet.py:316-484 for one level (values and gradients); _adam = tf.train.AdamOptimizer
+ * (FISRnet.py:490-491). */
+size_t fisr_train_packed_bytes(int ci, int co, int transpose);
+int fisr_train_pack(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
+int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed, const float* d_bias,
+                       int cout, const float* res, float* out, int n, int h, int w, int flags, int out_cstride,
+                       int out_coff, int out_split, int out_gap, void* stream);
+int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw,
+                     int ci, int co, int n, int h, int w, void* stream);
+int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream);
+int fisr_train_relu_bwd(const float* g_in, const float* ref, float* g_out, size_t count, void* stream);
+int fisr_train_axpy(const float* x, float a, float* y, size_t count, void* stream);
+int fisr_train_maxpool2_bwd(const float* x, const float* dpool, float* dx, int n, int h, int w, int c, void* stream);
+int fisr_train_upsample2_bwd(const float* dy, float* dx, int n, int h, int w, int c, void* stream);
+int fisr_train_s2d(const float* g, float* out, int n, int h, int w, int c, void* stream);
+int fisr_train_copy_channels(const float* src, int scs, int sco, float* dst, int dcs, int dco, int nc, size_t npix,
+                             int add, void* stream);
+int fisr_train_loss(const float* const* pred4, const float* gt, float* const* grad4, float* sums, size_t npix,
+                    const float* k7, void* stream);
+int fisr_train_adam(float* w, const float* g, float* m, float* v, size_t count, float lr_t, float b1, float b2,
+                    float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
