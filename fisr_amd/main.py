@@ -8,7 +8,9 @@ Differences from the reference, all deliberate:
   * `--test_patch`, `--test_input_size`, `--FISR_input_size`, `--FISR_test_patch` parse "2,2" /
     "(2,2)" into integer tuples (the reference's `type=tuple` turns a CLI string into a tuple of
     characters, main.py:89-103); `--scale_factor` is an int (main.py:29 makes 2.0).
-  * `--phase train` is out of scope (inference-only build) and exits with an error.
+  * `--phase train` runs the reference's training graph on the GPU (fisr_amd/train.py, train_harness.py: the four
+    weight-sharing passes, seven loss terms, Adam, the lr schedules, validation, checkpoints; no TensorBoard).  The
+    reference's pre-made training files are not in its tree: `--synthetic_train N` substitutes N seeded samples.
   * `--phase FISR_for_video` computes the optical flow on the GPU like the reference (main.py:210): PWC-Net-large
     (fisr_amd/pwcnet.py), weights from `--pwc_ckpt` (TF bundle prefix or .npz; the reference hard-codes
     './models/pwcnet-lg-6-2-multisteps-chairsthingsmix/pwcnet.ckpt-595000') or seeded stand-ins with
@@ -49,6 +51,12 @@ def parse_args(argv=None):
     p.add_argument("--fraction_gpu", type=float, default=1.0, help="accepted for compatibility; unused")
     p.add_argument("--phase", type=str, default="FISR_for_video", choices=["train", "test", "FISR_for_video"])
     p.add_argument("--scale_factor", type=int, default=2)
+    p.add_argument("--train_data_path", type=str, default="./data/train/LR_LFR/LR_Surfing_SlamDunk_5seq.mat")
+    p.add_argument("--train_flow_data_path", type=str, default="./data/train/flow/LR_Surfing_SlamDunk_5seq_ss1.flo")
+    p.add_argument("--train_flow_ss2_data_path", type=str, default="./data/train/flow/LR_Surfing_SlamDunk_5seq_ss2.flo")
+    p.add_argument("--train_warped_data_path", type=str, default="./data/train/warped/LR_Surfing_SlamDunk_5seq_ss1_warp.mat")
+    p.add_argument("--train_wapred_ss2_data_path", type=str, default="./data/train/warped/LR_Surfing_SlamDunk_5seq_ss2_warp.mat")
+    p.add_argument("--train_label_path", type=str, default="./data/train/HR_HFR/HR_Surfing_SlamDunk_5seq.mat")
     p.add_argument("--test_data_path", type=str, default="./data/test/LR_LFR")
     p.add_argument("--test_flow_data_path", type=str, default="./data/test/flow/LR_Surfing_SlamDunk_test_ss1.flo")
     p.add_argument("--test_warped_data_path", type=str, default="./data/test/warped/LR_Surfing_SlamDunk_test_ss1_warp.mat")
@@ -58,6 +66,26 @@ def parse_args(argv=None):
     p.add_argument("--checkpoint_dir", type=str, default="./checkpoint_dir")
     p.add_argument("--log_dir", type=str, default="./logdir")
     p.add_argument("--exp_num", type=int, default=1)
+    # training hyper-parameters (main.py:64-85)
+    p.add_argument("--epoch", type=int, default=100)
+    p.add_argument("--freq_display", type=int, default=100)
+    p.add_argument("--init_lr", type=float, default=0.0001)
+    p.add_argument("--lr_type", type=str, default="stair_decay", choices=["linear_decay", "stair_decay", "no_decay"])
+    p.add_argument("--lr_stair_decay_points", type=int, nargs="+", default=[80, 90])
+    p.add_argument("--lr_decreasing_factor", type=float, default=0.1)
+    p.add_argument("--lr_linear_decay_point", type=int, default=50)
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("--n_train_img_showed", type=int, default=3, help="accepted for compatibility (TensorBoard images); unused")
+    p.add_argument("--val_batch_size", type=int, default=2)
+    p.add_argument("--val_data_size", type=int, default=320)
+    p.add_argument("--recn_lambda", type=float, default=1.0)
+    p.add_argument("--tm1_lambda", type=float, default=1.0)
+    p.add_argument("--tm2_lambda", type=float, default=0.1)
+    p.add_argument("--tmm_lambda", type=float, default=1.0)
+    p.add_argument("--td_lambda", type=float, default=0.1)
+    p.add_argument("--ss2_lambda", type=float, default=1.0)
+    p.add_argument("--synthetic_train", type=int, default=0, metavar="N",
+                   help="train on N seeded synthetic samples (the reference's pre-made training .mat/.flo files are not in its tree)")
     p.add_argument("--test_patch", type=_tuple2, default=(2, 2))
     p.add_argument("--test_input_size", type=_tuple2, default=(1080, 1920))
     p.add_argument("--frame_folder_path", type=str, default="./FISR_test_folder/scene1")
@@ -94,8 +122,12 @@ def check_args(args):
 def main(argv=None):
     args = parse_args(argv)
     if args.phase == "train":
-        print("--phase train is out of scope of the MI355X inference build (see DESIGN.md)", file=sys.stderr)
-        return 2
+        from . import train_harness
+        if args.device is None:
+            args.device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        train_harness.run_train(args)
+        print(" [*] Training finished!")
+        return 0
     from . import io as fio
     from . import harness, weights
     from .fisrnet import FISRnet

@@ -65,6 +65,8 @@ class TrainNet:
         self.zero_bias = torch.zeros(1024, dtype=f32, device=self.device)
         self.step_count = 0
         self.tape = []
+        self.keep_preds = False        # loss_and_grads() then leaves the four passes' predictions in last_preds
+        self.last_preds = None
         self.repack()
 
     # ------------------------------------------------------------------ plumbing
@@ -341,6 +343,7 @@ class TrainNet:
             pred_grads += list(zip(ps, gs))
         total = (lam["recn"] * terms[0] + lam["tm1"] * terms[1] + lam["tmm"] * terms[2] + lam["td"] * terms[3]
                  + lam["ss2"] * (lam["recn"] * terms[4] + lam["td"] * terms[5] + lam["tm2"] * terms[6]))
+        self.last_preds = preds if self.keep_preds else None
         self.backward(pred_grads)
         names = ("recn", "tm", "tmm", "td", "recn_ss2", "td_ss2", "tm_ss2")
         return float(total), dict(zip(names, terms.tolist()))

@@ -165,3 +165,39 @@ def test_adam_step_vs_oracle(env, small_case):
     # and a second step keeps going down the same loss
     l2, _ = net.train_step(train.to_device_batch(batch), lr=1e-4)
     assert np.isfinite(l2)
+
+
+def test_repeated_steps_reduce_the_loss(env):
+    torch, L, lib = env
+    import fisr_train_oracle as fo
+    from fisr_amd import train, weights
+    net = train.TrainNet(weights.synthetic_weights(2020))
+    batch = train.to_device_batch(fo.synthetic_batch(3, 2, 32, 32))
+    losses = [net.train_step(batch, lr=1e-4)[0] for _ in range(8)]
+    print("losses", [round(v, 4) for v in losses])
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.9 * losses[0]
+
+
+def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp_path):
+    """main.py --phase train (FISRnet.py:583-745) on synthetic samples: two epochs, validation, checkpoint; then the
+    inference engine restores that checkpoint the way FISRnet.load does."""
+    torch, L, lib = env
+    from fisr_amd import main, weights
+    from fisr_amd.fisrnet import FISRnet
+    d = str(tmp_path)
+    argv = ["--phase", "train", "--synthetic_train", "6", "--epoch", "2", "--batch_size", "2", "--val_data_size", "2",
+            "--val_batch_size", "2", "--freq_display", "1", "--lr_type", "no_decay",
+            "--checkpoint_dir", d + "/ck", "--text_dir", d + "/tx", "--log_dir", d + "/lg", "--test_img_dir", d + "/ti"]
+    assert main.main(argv) == 0
+    path, kind, step = weights.find_checkpoint(d + "/ck", "FISRnet_exp1")
+    assert kind == "npz" and step == 4
+    W = weights.load_weights(path, kind)
+    W0 = weights.synthetic_weights(2020)
+    assert any(not np.array_equal(W[k], W0[k]) for k in W)
+    net = FISRnet(device="cuda:0", precision="fp32")
+    net.set_weights(W)
+    x = torch.rand(1, 32, 32, 29, device="cuda:0")
+    p1, p2, p3 = net.model(x)
+    assert torch.isfinite(p3).all()
+    net.close()
