@@ -59,10 +59,10 @@ int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const
   return 0;
 }
 
-/* dw[3][3][ci][co] += sum_pixels [relu](cat(x0, x1))[p + tap][ci] * g[p][co];  c0 + c1 >= ci (padded channels are read and
- * dropped), cg >= co, c0 % 4 == c1 % 4 == cg % 4 == 0 */
-int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, int ci,
-                     int co, int n, int h, int w, void* stream) {
+/* dw[3][3][ci][co] += sum_pixels [relu](cat(x0, x1))[p + tap][ci] * g[p][co], and (db != NULL) db[co] += sum_pixels g[p][co];
+ * c0 + c1 >= ci (padded channels are read and dropped), cg >= co, c0 % 4 == c1 % 4 == cg % 4 == 0 */
+int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
+                     int ci, int co, int n, int h, int w, void* stream) {
   if (!x0 || !g || !dw || c0 <= 0 || c1 < 0 || (c0 % 4) || (c1 % 4) || (cg % 4) || ci > c0 + c1 || co > cg || (c1 && !x1) || n <= 0)
     return fail(nullptr, FISR_EINVAL, "fisr_train_wgrad: bad argument");
   DeviceGuard guard(device_of(dw));
@@ -75,7 +75,7 @@ int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_
     attr_done[dev] = true;
   }
   WgradArgs a;
-  a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.g = g; a.Cg = cg; a.dw = dw; a.ci = ci; a.co = co;
+  a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.g = g; a.Cg = cg; a.dw = dw; a.db = db; a.ci = ci; a.co = co;
   a.N = n; a.H = h; a.W = w; a.relu_in = relu_in;
   const int blocks = ((ci + 31) / 32) * ((co + 31) / 32);
   const int ntiles = ((w + WG_TW - 1) / WG_TW) * ((h + WG_TH - 1) / WG_TH) * n;

@@ -46,6 +46,7 @@ struct WgradArgs {
   const float* x0; const float* x1; int C0, C1;     // conv input: cat(x0, x1) along channels (x1 nullable), pixel strides C0, C1
   const float* g;  int Cg;                          // gradient of the conv output [N,H,W,Cg] (dense)
   float* dw;       int ci, co;                      // HWIO [3][3][ci][co], accumulated (ci <= C0 + C1, co <= Cg)
+  float* db;                                        // nullable: db[co] += sum over pixels of g (done by the first ci block)
   int N, H, W, relu_in, ksplit;
 };
 constexpr int WG_TH = 8, WG_TW = 32;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;                                   // bias gradient: every g value passes through a lane as operand B
   for (int tile = ks; tile < ntiles; tile += p.ksplit) {
     int t = tile;
     const int tx = t % tiles_x; t /= tiles_x;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
 #pragma unroll 2
       for (int col = 0; col < WG_TW; col += 2) {
         const float b = sG[(row * WG_TW + col + kh) * 32 + li];
+        bsum += b;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const float a = sX[((row + tap / 3) * (WG_TW + 2) + col + kh + tap % 3) * 32 + li];
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
   }
   // D layout: column (co) = lane & 31, row (ci) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int n = cob + li;
+  if (p.db != nullptr && cib == 0 && n < p.co) unsafeAtomicAdd(p.db + n, bsum);
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll

@@ -140,7 +140,7 @@ def lib():
     L.fisr_train_pack.argtypes = [vp, c_int, c_int, c_int, vp, vp]
     L.fisr_train_conv3x3.argtypes = [vp, c_int, vp, c_int, vp, vp, c_int, vp, vp, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, vp]
-    L.fisr_train_wgrad.argtypes = [vp, c_int, vp, c_int, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_train_wgrad.argtypes = [vp, c_int, vp, c_int, c_int, vp, c_int, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_train_bgrad.argtypes = [vp, c_int, c_size_t, vp, c_int, vp]
     L.fisr_train_relu_bwd.argtypes = [vp, vp, vp, c_size_t, vp]
     L.fisr_train_axpy.argtypes = [vp, c_float, vp, c_size_t, vp]

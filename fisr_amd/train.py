@@ -244,9 +244,8 @@ class TrainNet:
                     if res is not None:
                         self._acc(grads, res, g)
                 cg = g.shape[3]
-                self._ck(L.fisr_train_bgrad(self._p(g), cg, n * h * w, self._p(c.gb), c.co, self._st()))
                 self._ck(L.fisr_train_wgrad(self._p(x0), c0, self._p(x1), c1, 1 if flags & RELU_IN else 0, self._p(g), cg,
-                                            self._p(c.gw), c.ci, c.co, n, h, w, self._st()))
+                                            self._p(c.gw), self._p(c.gb), c.ci, c.co, n, h, w, self._st()))      # weight + bias gradient
                 if not getattr(x0, "_fisr_needs_grad", True):
                     continue
                 # data gradient: the same conv with rotated taps, input g (cg channels, cg % 16 == 0), output c0 + c1 channels

@@ -239,7 +239,7 @@ int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const
                        int cout, const float* res, float* out, int n, int h, int w, int flags, int out_cstride,
                        int out_coff, int out_split, int out_gap, void* stream);
 int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw,
-                     int ci, int co, int n, int h, int w, void* stream);
+                     float* db /* nullable */, int ci, int co, int n, int h, int w, void* stream);
 int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream);
 int fisr_train_relu_bwd(const float* g_in, const float* ref, float* g_out, size_t count, void* stream);
 int fisr_train_axpy(const float* x, float a, float* y, size_t count, void* stream);

@@ -61,10 +61,12 @@ def test_wgrad_bgrad_dgrad_vs_autograd(env, n, h, w, c0, c1, ci, co, cg, relu_in
     gd = _dev(torch, g)
     dw = torch.zeros(3, 3, ci, co, device="cuda:0")
     db = torch.zeros(co, device="cuda:0")
-    assert L.fisr_train_wgrad(_ptr(x0), c0, _ptr(x1), c1, relu_in, _ptr(gd), cg, _ptr(dw), ci, co, n, h, w, None) == 0
+    db2 = torch.zeros(co, device="cuda:0")
+    assert L.fisr_train_wgrad(_ptr(x0), c0, _ptr(x1), c1, relu_in, _ptr(gd), cg, _ptr(dw), _ptr(db2), ci, co, n, h, w, None) == 0
     assert L.fisr_train_bgrad(_ptr(gd), cg, n * h * w, _ptr(db), co, None) == 0
     assert _rel(dw.cpu().numpy(), dw_ref) < 2e-5
     assert _rel(db.cpu().numpy(), db_ref) < 2e-5
+    assert _rel(db2.cpu().numpy(), db_ref) < 2e-5          # the bias gradient fused into the weight-gradient kernel
     if cg % 16 == 0:      # data gradient = the forward conv with the transposed packing
         wd = _dev(torch, wt)
         pk = torch.empty(L.fisr_train_packed_bytes(ci, co, 1) // 4, device="cuda:0")

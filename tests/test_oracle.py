@@ -265,3 +265,38 @@ def test_pwc_oracle_network_smoke():
     assert tuple(pred.shape) == (1, 64, 64, 2) and [tuple(p.shape[2:]) for p in pyr] == [(1, 1), (2, 2), (4, 4), (8, 8), (16, 16)]
     pred2, _ = P.nn(torch.flip(x, dims=[1]), W)
     assert float((pred - pred2).abs().max()) > 1e-6
+
+
+def test_training_oracle_gradients_vs_finite_differences(syn_weights):
+    """oracle/fisr_train_oracle.py (the four-pass loss of FISRnet.py:283-485) has no TensorFlow to be pinned to: its
+    analytic gradients are checked against central differences of the restated loss, and the loss terms against a
+    direct numpy evaluation of two of them."""
+    import torch
+    import fisr_train_oracle as fo
+    W = syn_weights
+    batch = fo.synthetic_batch(11, 1, 32, 32)
+    loss, terms, grads = fo.loss_and_grads(W, batch)
+    assert np.isfinite(loss) and set(grads) == set(W)
+    args = [fo.to_nchw(batch[k]) for k in ("data15", "label21", "flow16", "warp24", "flow_ss2", "warp_ss2")]
+
+    def total(Wd):
+        Wt = {k: (torch.from_numpy(v).double().permute(3, 2, 0, 1).contiguous() if k.endswith("/w") else torch.from_numpy(v).double())
+              for k, v in Wd.items()}
+        with torch.no_grad():
+            return float(fo.total_loss(Wt, *args)[0])
+
+    for name, idx in (("FISRnet/level_3/SR/conv/2/b", (1,)), ("FISRnet/level_2/FI-SR/conv/2/w", (1, 1, 7, 4)),
+                      ("FISRnet/level_3/dec/level_0/conv/0/w", (0, 2, 70, 3))):
+        Wd = {k: np.array(v, np.float64) for k, v in W.items()}
+        eps = 1e-5
+        Wd[name][idx] += eps
+        lp = total(Wd)
+        Wd[name][idx] -= 2 * eps
+        lm = total(Wd)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - grads[name][idx]) <= 2e-3 * abs(fd) + 1e-7, (name, fd, grads[name][idx])
+    # total = s1 + ss2 * s2 with the default lambdas (FISRnet.py:389-391, 481-485)
+    lam = fo.LAMBDAS
+    s1 = lam["recn"] * terms["recn"] + lam["tm1"] * terms["tm"] + lam["tmm"] * terms["tmm"] + lam["td"] * terms["td"]
+    s2 = lam["recn"] * terms["recn_ss2"] + lam["td"] * terms["td_ss2"] + lam["tm2"] * terms["tm_ss2"]
+    assert abs(s1 + lam["ss2"] * s2 - loss) < 1e-9 * abs(loss)
