@@ -125,6 +125,16 @@ def main(argv=None):
         from . import train_harness
         if args.device is None:
             args.device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(torch.device(args.device))
+            backend = os.environ.get("FISR_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(args.device))
+            else:
+                dist.init_process_group(backend)
         train_harness.run_train(args)
         print(" [*] Training finished!")
         return 0

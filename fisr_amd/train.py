@@ -51,12 +51,20 @@ class TrainNet:
         _weights.check_complete(W)
         self.convs = OrderedDict()
         f32 = torch.float32
-        for name, ci, co in _weights.conv_specs():
+        # all gradients live in ONE flat buffer (views per tensor): data-parallel training all-reduces it in one call
+        specs = _weights.conv_specs()
+        total = sum(9 * ci * co + co for _, ci, co in specs)
+        self.gflat = torch.zeros(total, dtype=f32, device=self.device)
+        off = 0
+        for name, ci, co in specs:
             c = _Conv()
             c.name, c.ci, c.co = name, ci, co
             c.w = torch.from_numpy(np.ascontiguousarray(W[name + "/w"], dtype=np.float32)).to(self.device)
             c.b = torch.from_numpy(np.ascontiguousarray(W[name + "/b"], dtype=np.float32)).to(self.device)
-            c.gw, c.gb = torch.zeros_like(c.w), torch.zeros_like(c.b)
+            c.gw = self.gflat[off:off + 9 * ci * co].view(3, 3, ci, co)
+            off += 9 * ci * co
+            c.gb = self.gflat[off:off + co]
+            off += co
             c.mw, c.vw, c.mb, c.vb = (torch.zeros_like(c.w), torch.zeros_like(c.w), torch.zeros_like(c.b), torch.zeros_like(c.b))
             c.pk = torch.empty(self.L.fisr_train_packed_bytes(ci, co, 0) // 4, dtype=f32, device=self.device)
             c.pk_t = torch.empty(self.L.fisr_train_packed_bytes(ci, co, 1) // 4, dtype=f32, device=self.device)
@@ -66,6 +74,7 @@ class TrainNet:
         self.step_count = 0
         self.tape = []
         self.keep_preds = False        # loss_and_grads() then leaves the four passes' predictions in last_preds
+        self.grad_scale = 1.0          # data parallel: 1 / world (see allreduce_grads)
         self.last_preds = None
         self.repack()
 
@@ -109,9 +118,22 @@ class TrainNet:
         return out
 
     def zero_grad(self):
-        for c in self.convs.values():
-            c.gw.zero_()
-            c.gb.zero_()
+        self.gflat.zero_()
+
+    def allreduce_grads(self, group=None):
+        """Data-parallel training: every rank ran loss_and_grads on its shard of the batch with `grad_scale = 1 / world`
+        (all seven loss terms are means over the batch), so the SUM over ranks is the gradient of the whole batch.  One
+        all-reduce of the flat gradient buffer: RCCL over xGMI under the `nccl` backend; other backends (gloo in the
+        one-GPU tests) stage through the host."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=group)
+        else:
+            h = self.gflat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            self.gflat.copy_(h)
 
     # ------------------------------------------------------------------ forward ops (recorded)
     def conv(self, name, x0, x1=None, res=None, flags=0, scatter=None, out=None):
@@ -330,7 +352,7 @@ class TrainNet:
             n1, n3, s = npix * 3.0, npix * 9.0, LEVEL_SCALE[lv]
             k7 = np.array([lam["recn"] * s * 2 / n3, lam["tm1"] * s * 2 / n1, lam["tmm"] * s * 2 / n1, lam["td"] * s * 2 / n1,
                            lam["ss2"] * lam["recn"] * s * 2 / n3, lam["ss2"] * lam["td"] * s * 2 / n1,
-                           lam["ss2"] * lam["tm2"] * s * 2 / n3], dtype=np.float32)
+                           lam["ss2"] * lam["tm2"] * s * 2 / n3], dtype=np.float32) * np.float32(self.grad_scale)
             gs = [self.new(b, h, w, 9) for _ in range(4)]
             sums = self.zeros(8)
             pa = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in ps])
@@ -357,9 +379,10 @@ class TrainNet:
             self._ck(self.L.fisr_train_adam(self._p(c.b), self._p(c.gb), self._p(c.mb), self._p(c.vb), c.b.numel(), lr_t, b1, b2, eps, self._st()))
         self.repack()
 
-    def train_step(self, batch, lr):
+    def train_step(self, batch, lr, group=None):
         self.zero_grad()
         total, terms = self.loss_and_grads(batch)
+        self.allreduce_grads(group)
         self.adam_step(lr)
         return total, terms
 

@@ -96,8 +96,21 @@ def _psnr(pred7, label21):
 def run_train(args):
     """FISRnet.train (FISRnet.py:583-745).  Returns the last epoch's mean total loss."""
     import torch
+    import torch.distributed as dist
     from . import train as ft
     dev = args.device or "cuda:0"
+    # data parallel under `python -m torch.distributed.run --nproc-per-node N -m fisr_amd.main --phase train ...`: every
+    # rank takes batch_size / N samples of each batch, the gradients are all-reduced (RCCL), every rank applies Adam
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if args.batch_size % world:
+        raise ValueError(f"--batch_size {args.batch_size} must be a multiple of the {world} ranks")
+    if rank:
+        import builtins
+        print = lambda *a, **k: None  # noqa: A001,E731  (rank 0 reports)
+    else:
+        import builtins
+        print = builtins.print  # noqa: A001
     d = load_train_set(args)
     n = d["data"].shape[0]
     nv = min(args.val_data_size, max(0, n - args.batch_size))
@@ -119,6 +132,9 @@ def run_train(args):
     lam = dict(recn=args.recn_lambda, tm1=args.tm1_lambda, tm2=args.tm2_lambda, tmm=args.tmm_lambda, td=args.td_lambda, ss2=args.ss2_lambda)
     net = ft.TrainNet(W, device=dev, lambdas=lam)
     net.step_count = counter
+    net.grad_scale = 1.0 / world
+    if world > 1:
+        np.random.seed(1234 + args.exp_num)          # every rank must draw the same permutations
     start_epoch = counter // max(train_iter, 1)
     start_time = time.time()
     keymap = (("data15", "data"), ("label21", "label"), ("flow16", "flow"), ("warp24", "warp"), ("flow_ss2", "flow_ss2"), ("warp_ss2", "warp_ss2"))
@@ -128,13 +144,19 @@ def run_train(args):
         rand_idx = np.random.permutation(n - nv)
         lr = args.init_lr
         for idx in range(train_iter):
-            sel = rand_idx[args.batch_size * idx:args.batch_size * (idx + 1)]
+            sel = rand_idx[args.batch_size * idx:args.batch_size * (idx + 1)][rank::world]
             batch = ft.to_device_batch({a: tr[b][sel] for a, b in keymap}, dev)
             lr = learning_rate(args, epoch, counter, train_iter)
             net.zero_grad()
             net.keep_preds = True
             total, t = net.loss_and_grads(batch)
+            net.allreduce_grads()
             net.adam_step(lr)
+            if world > 1:                             # the logged numbers are the mean over the ranks' shards
+                v = torch.tensor([total] + [t[k] for k in sorted(t)], dtype=torch.float64)
+                dist.all_reduce(v)
+                v /= world
+                total, t = float(v[0]), dict(zip(sorted(t), v[1:].tolist()))
             psnr = _psnr(_ovlp([p[2] for p in net.last_preds[:3]]), batch["label21"])
             s1 = lam["recn"] * t["recn"] + lam["tm1"] * t["tm"] + lam["tmm"] * t["tmm"] + lam["td"] * t["td"]
             s2 = lam["recn"] * t["recn_ss2"] + lam["td"] * t["td_ss2"] + lam["tm2"] * t["tm_ss2"]
@@ -173,7 +195,8 @@ def run_train(args):
                   "recnLoss: %.6f #########" % (epoch, args.epoch, (time.time() - start_time) / 60, np.mean(vp), np.mean(vl)))
         # save_checkpoint (FISRnet.py:1091-1099): <checkpoint_dir>/<model_dir>/FISRnet-<global_step>
         name = f"FISRnet-{counter}"
-        _weights.save_npz(os.path.join(ckpt_dir, name + ".npz"), net.weights_numpy())
-        with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
-            f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
+        if rank == 0:
+            _weights.save_npz(os.path.join(ckpt_dir, name + ".npz"), net.weights_numpy())
+            with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
+                f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
     return last

@@ -203,3 +203,69 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     p1, p2, p3 = net.model(x)
     assert torch.isfinite(p3).all()
     net.close()
+
+
+def _dp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import fisr_train_oracle as fo
+        from fisr_amd import train, weights
+        torch.cuda.set_device(0)
+        W = weights.synthetic_weights(2020)
+        full = fo.synthetic_batch(21, world, 32, 32)
+        net = train.TrainNet(W)
+        net.grad_scale = 1.0 / world
+        shard = train.to_device_batch({k: v[rank::world] for k, v in full.items()})
+        net.train_step(shard, lr=1e-4)                       # loss_and_grads on the shard, all-reduce, Adam
+        got = net.weights_numpy()
+        ok, worst = True, 0.0
+        if rank == 0:
+            ref = train.TrainNet(W)                          # the whole batch in this process alone: no collective
+            ref.zero_grad()
+            ref.loss_and_grads(train.to_device_batch(full))
+            ref.adam_step(1e-4)
+            exp = ref.weights_numpy()
+            for k in exp:
+                du, dr = got[k].astype(np.float64) - W[k], exp[k].astype(np.float64) - W[k]
+                frac = float(np.isclose(du, dr, rtol=2e-3, atol=2e-8).mean())
+                worst = max(worst, 1.0 - frac)
+                ok = ok and frac > 0.995
+        q.put((rank, ok, worst))
+    except Exception:  # noqa: BLE001  (a silent worker death would leave the parent waiting for the queue)
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-3000:]))
+    finally:
+        try:
+            dist.barrier()                                   # nobody leaves while a peer may still be receiving
+        except Exception:  # noqa: BLE001
+            pass
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_the_full_batch_step(env):
+    """Two ranks (gloo processes sharing cuda:0; RCCL on a real node) each take half of a batch, all-reduce the flat
+    gradient buffer and apply Adam: the weights must move as in the single-process step on the whole batch."""
+    torch, L, lib = env
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    print("data-parallel vs full batch:", sorted(res))
+    for r_ in res:
+        if not r_[1]:
+            print(r_[2])
+    assert all(ok for _, ok, _ in res), res
