@@ -202,7 +202,15 @@ def test_cli_flags_match_reference_defaults(tmp_path):
         assert os.path.isdir(d)                               # check_args creates them (main.py:108-121)
     with pytest.raises(SystemExit):
         fmain.parse_args(["--test_patch", "2"])
-    assert fmain.main(["--phase", "train"]) == 2
+    # --phase train: the reference's hyper-parameters (main.py:64-85) ...
+    t = fmain.parse_args(["--phase", "train"])
+    assert (t.epoch, t.freq_display, t.init_lr, t.lr_type, t.lr_stair_decay_points, t.lr_decreasing_factor) == (100, 100, 1e-4, "stair_decay", [80, 90], 0.1)
+    assert (t.batch_size, t.val_batch_size, t.val_data_size) == (8, 2, 320)
+    assert (t.recn_lambda, t.tm1_lambda, t.tm2_lambda, t.tmm_lambda, t.td_lambda, t.ss2_lambda) == (1.0, 1.0, 0.1, 1.0, 0.1, 1.0)
+    assert t.train_data_path == "./data/train/LR_LFR/LR_Surfing_SlamDunk_5seq.mat"
+    # ... and, like the reference, it starts by reading the pre-made training files (FISRnet.py:177-209)
+    with pytest.raises(FileNotFoundError):
+        fmain.main(["--phase", "train"])
 
 
 def test_split_format_roundtrip():
