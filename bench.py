@@ -352,6 +352,34 @@ def time_flow_pipeline(net, wl, torch, local_rank, reps=2):
             "weights": "synthetic seeded (PWC-Net checkpoint absent from the reference tree)"}
 
 
+def time_training_step(W, torch, local_rank, steps=3):
+    """Row f4 (FISRnet.py:175-497): one training step of the reference's configuration -- batch 8 of 96x96 LR patches of 5
+    frames (main.py:74), four weight-sharing passes forward and backward, seven loss terms, Adam -- on fisr_amd/train.py.
+    Not part of `value`."""
+    from fisr_amd import train
+    r = np.random.default_rng(0)
+    b, p, f32 = 8, 96, np.float32
+    batch = train.to_device_batch(dict(
+        data15=r.random((b, p, p, 15), dtype=f32), label21=r.random((b, 2 * p, 2 * p, 21), dtype=f32),
+        flow16=(r.standard_normal((b, p, p, 16)) * 0.02).astype(f32), warp24=r.random((b, p, p, 24), dtype=f32),
+        flow_ss2=(r.standard_normal((b, p, p, 8)) * 0.04).astype(f32), warp_ss2=r.random((b, p, p, 12), dtype=f32)),
+        f"cuda:{local_rank}")
+    net = train.TrainNet(W, device=f"cuda:{local_rank}")
+    net.train_step(batch, 1e-4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = net.train_step(batch, 1e-4)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flop = 4 * b * FLOP_PER_LR_PX * p * p * 3      # forward + data gradient + weight gradient, four passes
+    del net
+    torch.cuda.empty_cache()
+    return {"what": "one training step: batch 8 x 96x96 LR patches of 5 frames, 4 weight-sharing passes forward + backward, "
+                    "7 loss terms, Adam (fp32)", "ms_per_step": round(dt * 1e3, 1), "samples_per_s": round(b / dt, 2),
+            "tflops_3x_forward": round(flop / dt / 1e12, 1), "loss_after": round(float(loss), 4)}
+
+
 def oracle_tile_check(net, torch):
     """One 544x992 reference tile through this engine against the fp64-oracle values committed on a sparse
     grid (tests/golden/model_544x992_sparse.npz, made by oracle/make_golden_fullsize.py), with the PSNR
@@ -469,6 +497,7 @@ def main():
                     "per-kernel averages of rocprofv3 free of the small one-tile launches)")
     ap.add_argument("--no-gather", action="store_true", help="frame-parallel: skip the RCCL gather of the output frames")
     ap.add_argument("--no-flow", action="store_true", help="skip the cfg5 measurement (on-GPU PWC-Net flow + warp + FISRnet)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement (row f4)")
     args = ap.parse_args()
     patch = tuple(int(v) for v in args.patch.strip("()").split(","))
 
@@ -601,6 +630,13 @@ def main():
             del eng, out_alt
             torch.cuda.empty_cache()
 
+    training = None
+    if solo and not args.no_train:
+        try:
+            training = time_training_step(W, torch, local_rank)
+        except Exception as e:  # noqa: BLE001  (the headline must survive a failure of this extra)
+            training = {"error": repr(e)}
+
     cpu_port = cpu_onednn = None
     if solo and not args.no_cpu_baseline:
         cpu_port, cpu_onednn = cpu_baselines(W, wl)
@@ -633,7 +669,8 @@ def main():
                        "forwards_per_s": round(stacks * 3 * args.steps / elapsed, 3),
                        "achieved_tflops_whole_step": round(stacks * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
             "roofline": roofline, "cpu_baseline": cpu_port, "cpu_baseline_onednn": cpu_onednn,
-            "parity_vs_oracle": parity_oracle, "cfg5_flow_pipeline": cfg5, "other_precisions": other or None,
+            "parity_vs_oracle": parity_oracle, "cfg5_flow_pipeline": cfg5, "training_step": training,
+            "other_precisions": other or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -6,7 +6,7 @@ PREC="${PREC:-bf16x3}"
 OUT="$REPO/gpurun_out/prof_${PREC}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps ${STEPS:-2} --warmup 1 --precision $PREC --others none --no-cpu-baseline --no-roofline --no-parity --no-flow"
+CMD="python $REPO/bench.py --steps ${STEPS:-2} --warmup 1 --precision $PREC --others none --no-cpu-baseline --no-roofline --no-parity --no-flow --no-train"
 echo "== kernel trace + stats"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 1 (SQ / MFMA busy)"
