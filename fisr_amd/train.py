@@ -338,30 +338,36 @@ class TrainNet:
         gradients are left accumulated in the conv states (call zero_grad() first)."""
         torch, L = self.torch, self.L
         self.tape = []
-        preds = [self.model(self.window_input(batch, k)) for k in range(3)]          # stride 1 (FISRnet.py:283-310)
-        preds.append(self.model(self.stride2_input(batch)))                          # stride 2 (:403-409)
+        # The four passes share the weights, so they run as ONE pass over a batch of 4B: windows 0, 1, 2 (stride 1,
+        # FISRnet.py:283-310) and the stride-2 window (:403-409) stacked along the batch axis -- a quarter of the kernel
+        # launches, four times the work per launch, the same numbers (every sample is convolved independently).
+        b0 = batch["data15"].shape[0]
+        x_all = torch.cat([self.window_input(batch, k) for k in range(3)] + [self.stride2_input(batch)], dim=0)
+        pred_all = self.model(x_all)
         label = batch["label21"]
         gts = (label[:, ::4, ::4].contiguous(), label[:, ::2, ::2].contiguous(), label)   # FISRnet.py:262-263 (see the oracle)
         lam = self.lam
         terms = np.zeros(7)
         pred_grads = []
         for li, lv in enumerate(_weights.LEVELS):
-            ps = [preds[k][li] for k in range(4)]
-            b, h, w, _ = ps[0].shape
-            npix = b * h * w
+            pa_t = pred_all[li]                                      # [4B, h, w, 9]: chunk k = window k
+            _, h, w, _ = pa_t.shape
+            npix = b0 * h * w
+            chunk = npix * 9 * 4                                     # bytes per window
             n1, n3, s = npix * 3.0, npix * 9.0, LEVEL_SCALE[lv]
             k7 = np.array([lam["recn"] * s * 2 / n3, lam["tm1"] * s * 2 / n1, lam["tmm"] * s * 2 / n1, lam["td"] * s * 2 / n1,
                            lam["ss2"] * lam["recn"] * s * 2 / n3, lam["ss2"] * lam["td"] * s * 2 / n1,
                            lam["ss2"] * lam["tm2"] * s * 2 / n3], dtype=np.float32) * np.float32(self.grad_scale)
-            gs = [self.new(b, h, w, 9) for _ in range(4)]
+            g_all = self.new(4 * b0, h, w, 9)
             sums = self.zeros(8)
-            pa = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in ps])
-            ga = (ctypes.c_void_p * 4)(*[g.data_ptr() for g in gs])
+            pa = (ctypes.c_void_p * 4)(*[pa_t.data_ptr() + k * chunk for k in range(4)])
+            ga = (ctypes.c_void_p * 4)(*[g_all.data_ptr() + k * chunk for k in range(4)])
             self._ck(L.fisr_train_loss(pa, self._p(gts[li]), ga, self._p(sums), npix,
                                        k7.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), self._st()))
             sv = sums.cpu().numpy().astype(np.float64)
             terms += s * np.array([sv[0] / n3, sv[1] / n1, sv[2] / n1, sv[3] / n1, sv[4] / n3, sv[5] / n1, sv[6] / n3])
-            pred_grads += list(zip(ps, gs))
+            pred_grads.append((pa_t, g_all))
+        preds = [tuple(p[k * b0:(k + 1) * b0] for p in pred_all) for k in range(4)]     # per window, as the reference names them
         total = (lam["recn"] * terms[0] + lam["tm1"] * terms[1] + lam["tmm"] * terms[2] + lam["td"] * terms[3]
                  + lam["ss2"] * (lam["recn"] * terms[4] + lam["td"] * terms[5] + lam["tm2"] * terms[6]))
         self.last_preds = preds if self.keep_preds else None
