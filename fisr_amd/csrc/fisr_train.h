@@ -79,7 +79,8 @@ int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_
   a.N = n; a.H = h; a.W = w; a.relu_in = relu_in;
   const int blocks = ((ci + 31) / 32) * ((co + 31) / 32);
   const int ntiles = ((w + WG_TW - 1) / WG_TW) * ((h + WG_TH - 1) / WG_TH) * n;
-  a.ksplit = std::max(1, std::min(ntiles, (1024 + blocks - 1) / blocks));      // about four workgroups per CU in total
+  a.ksplit = std::max(1, std::min(ntiles, (512 + blocks - 1) / blocks));       // about two workgroups per CU in total (each ends
+                                                                                // with 9216 atomics: few, long-running workgroups)
   hipLaunchKernelGGL(train_wgrad_kernel, dim3(blocks * a.ksplit), dim3(256), wgrad_lds_bytes(), (hipStream_t)stream, a);
   HIP_OK(nullptr, hipGetLastError());
   return 0;

@@ -68,15 +68,20 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;                                   // bias gradient: every g value passes through a lane as operand B
-  for (int tile = ks; tile < ntiles; tile += p.ksplit) {
+  // Software pipeline: the global loads of the NEXT tile are issued into registers before the MFMAs of this one and
+  // written to LDS after them, so their latency (eleven + eight dependent round trips otherwise) hides under the MFMAs.
+  constexpr int NX = ((WG_TH + 2) * (WG_TW + 2) * 8 + 255) / 256, NG = WG_TH * WG_TW * 8 / 256;
+  f32x4 rx[NX], rg[NG];
+  auto load_tile = [&](int tile) {
     int t = tile;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int nb = t / tiles_y;
     const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-    __syncthreads();
-    for (int i = tid; i < (WG_TH + 2) * (WG_TW + 2) * 8; i += 256) {      // x halo tile, 4 channels per thread
-      const int px = i >> 3, q = i & 7;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {                   // x halo tile, 4 channels per thread
+      const int i = tid + 256 * k;
+      const int px = min(i >> 3, (WG_TH + 2) * (WG_TW + 2) - 1), q = i & 7;
       const int py = px / (WG_TW + 2), pxx = px - py * (WG_TW + 2);
       const int gy = y0 - 1 + py, gx = x0 - 1 + pxx, c = cib + 4 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -84,11 +89,12 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
         const size_t pix = ((size_t)nb * p.H + gy) * p.W + gx;
         if (c < p.C0) v = *reinterpret_cast<const f32x4*>(p.x0 + pix * p.C0 + c);            // (C0 % 4 == 0)
         else if (c < p.C0 + p.C1) v = *reinterpret_cast<const f32x4*>(p.x1 + pix * p.C1 + (c - p.C0));
-        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
-      *reinterpret_cast<f32x4*>(sX + px * 32 + 4 * q) = v;
+      rx[k] = v;
     }
-    for (int i = tid; i < WG_TH * WG_TW * 8; i += 256) {                   // g tile
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {                   // g tile
+      const int i = tid + 256 * k;
       const int px = i >> 3, q = i & 7;
       const int py = px / WG_TW, pxx = px - py * WG_TW;
       const int gy = y0 + py, gx = x0 + pxx, c = cob + 4 * q;
@@ -98,9 +104,31 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
         if (c + 3 < p.Cg) v = *reinterpret_cast<const f32x4*>(src);                          // (Cg % 4 == 0 or a ragged tail)
         else { if (c < p.Cg) v.x = src[0]; if (c + 1 < p.Cg) v.y = src[1]; if (c + 2 < p.Cg) v.z = src[2]; }
       }
-      *reinterpret_cast<f32x4*>(sG + px * 32 + 4 * q) = v;
+      rg[k] = v;
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int i = tid + 256 * k;
+      if (i < (WG_TH + 2) * (WG_TW + 2) * 8) {
+        f32x4 v = rx[k];
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(sX + (i >> 3) * 32 + 4 * (i & 7)) = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int i = tid + 256 * k;
+      *reinterpret_cast<f32x4*>(sG + (i >> 3) * 32 + 4 * (i & 7)) = rg[k];
+    }
+  };
+  if (ks < ntiles) load_tile(ks);
+  for (int tile = ks; tile < ntiles; tile += p.ksplit) {
+    __syncthreads();                                 // every wave is done with the previous tile
+    store_tile();
     __syncthreads();
+    if (tile + p.ksplit < ntiles) load_tile(tile + p.ksplit);
     // wave w: tile rows 2w, 2w+1; K steps of two neighbouring pixels
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
@@ -120,6 +148,32 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
   // D layout: column (co) = lane & 31, row (ci) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int n = cob + li;
   if (p.db != nullptr && cib == 0 && n < p.co) unsafeAtomicAdd(p.db + n, bsum);
+  // The four waves hold partial sums over different pixel rows: add them up through LDS (the tiles are dead by now;
+  // 36 KB per wave, two rounds) so that one wave, not four, sends the 9216 atomics of this workgroup.
+  float* const red = reinterpret_cast<float*>(wg_smem);
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((slot * 9 + tap) * 16 + r) * 64 + lane] = acc[tap][r];
+  };
+  auto take = [&](int slot) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tap][r] += red[((slot * 9 + tap) * 16 + r) * 64 + lane];
+  };
+  __syncthreads();
+  if (wave == 1) put(0);
+  if (wave == 3) put(1);
+  __syncthreads();
+  if (wave == 0) take(0);
+  if (wave == 2) take(1);
+  __syncthreads();
+  if (wave == 2) put(0);
+  __syncthreads();
+  if (wave != 0) return;
+  take(0);
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
