@@ -30,13 +30,35 @@ int fisr_train_pack(const float* d_w_hwio, int ci, int co, int transpose, void* 
   return 0;
 }
 
-/* out = [relu]( conv3x3([relu](cat(in0, in1))) + bias [+ res] ), weights packed by fisr_train_pack (device).  c0 + c1 is
+/* Winograd slabs of the same conv for the persistent fp32 Winograd kernel (conv3x3_wino8p.h): bytes (0 = this conv is
+ * not eligible: it needs 64 | padded output channels and >= 32 input channels) and the device-side packing. */
+size_t fisr_train_wino_bytes(int ci, int co, int transpose) {
+  const int ci_ = transpose ? co : ci, co_ = transpose ? ci : co;
+  const int cin_pad = round_up(ci_, 16), cout_pad = round_up(co_, 16);
+  if (cout_pad % W_BN || cin_pad < 32) return 0;
+  return (size_t)(cin_pad / W_CH) * (cout_pad / W_BN) * W_SLAB;
+}
+
+int fisr_train_pack_wino(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream) {
+  if (!d_w_hwio || !d_packed || !fisr_train_wino_bytes(ci, co, transpose)) return fail(nullptr, FISR_EINVAL, "fisr_train_pack_wino: bad argument");
+  const int ci_ = transpose ? co : ci, co_ = transpose ? ci : co;
+  const int cin_pad = round_up(ci_, 16), nb = round_up(co_, 16) / W_BN;
+  DeviceGuard guard(device_of(d_packed));
+  HIP_OK(nullptr, guard.err);
+  hipLaunchKernelGGL(train_pack_wino_kernel, dim3(grid_for((size_t)cin_pad * nb * 64)), dim3(256), 0, (hipStream_t)stream, d_w_hwio, ci, co,
+                     transpose ? 1 : 0, ci_, co_, cin_pad, nb, (char*)d_packed);
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
+/* out = [relu]( conv3x3([relu](cat(in0, in1))) + bias [+ res] ), weights packed by fisr_train_pack (device).
+ * d_packed_wino (nullable): the slabs of fisr_train_pack_wino; large dense layers then run on the Winograd kernel.  c0 + c1 is
  * the padded channel count (multiple of 16).  out_cstride == 0: dense [n,h,w,cout] records (or the depth_to_space layout
  * with FISR_CONV_D2S); != 0: channel n is stored at n + out_coff + (n >= out_split ? out_gap : 0) of a pixel stride
  * out_cstride (the [fr1, SR, fr2] scatter of the heads, FISRnet.py:107-108). */
 int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed, const float* d_bias, int cout,
                        const float* res, float* out, int n, int h, int w, int flags, int out_cstride, int out_coff, int out_split,
-                       int out_gap, void* stream) {
+                       int out_gap, const void* d_packed_wino, void* stream) {
   if (!in0 || !d_packed || !d_bias || !out || n <= 0 || h <= 0 || w <= 0 || c0 <= 0 || c1 < 0 || (c0 % 16) || (c1 % 16) || (c1 && !in1))
     return fail(nullptr, FISR_EINVAL, "fisr_train_conv3x3: bad argument");
   const int nt = nt_for<float>(cout);
@@ -55,6 +77,14 @@ int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const
   a.out_split = scatter ? out_split : 1 << 30; a.out_gap = scatter ? out_gap : 0;
   a.wexp = 0; a.trace = nullptr;
   a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
+  // the persistent Winograd kernel pays off from two rounds of work items per CU on; below that the direct kernel wins
+  const long items = (long)((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n * (cout / W_BN);
+  if (d_packed_wino && !scatter && cout % W_BN == 0 && (c0 + c1) / W_CH >= 4 && items >= 512 && wino_fits(n, h, w, c0, c1, cout)) {
+    a.wpk = d_packed_wino;
+    a.CoutPad = cout;
+    HIP_OK(nullptr, launch_conv_wino(a, (hipStream_t)stream));
+    return 0;
+  }
   HIP_OK(nullptr, launch_conv<float>(a, nt, scatter, (hipStream_t)stream));
   return 0;
 }

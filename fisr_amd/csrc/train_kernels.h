@@ -12,6 +12,7 @@
 //   with respect to the twelve predicted frames of a level), Adam (tf.train.AdamOptimizer, TF 1.13)
 #pragma once
 #include "conv3x3.h"
+#include "conv3x3_wino8p.h"
 
 namespace fisr {
 
@@ -38,6 +39,41 @@ __global__ void train_pack_kernel(const float* __restrict__ w, int ci_src, int c
     if (c < ci && n < co)
       v = transpose ? w[((size_t)(8 - tap) * ci_src + n) * co_src + c] : w[((size_t)tap * ci_src + c) * co_src + n];
     out[i] = v;
+  }
+}
+
+// ---- weights: HWIO -> Winograd slabs U = G g G^T of conv3x3_wino8p.h (pack_weights_wino in fisr_api.hip, on the device, fp32) ----
+// One thread per (input channel c < cin_pad, output channel n < nb * 64); transpose as in train_pack_kernel.
+__global__ void train_pack_wino_kernel(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
+                                       int cin_pad, int nb, char* __restrict__ out) {
+  const size_t total = (size_t)cin_pad * nb * 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % (nb * 64)), c = (int)(i / (nb * 64));
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int tap = a * 3 + b;
+        g[a][b] = (c < ci && n < co) ? (transpose ? w[((size_t)(8 - tap) * ci_src + n) * co_src + c] : w[((size_t)tap * ci_src + c) * co_src + n]) : 0.f;
+      }
+    float t[4][3], u[4][4];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = g[0][b]; t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]); t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]); t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      u[a][0] = t[a][0]; u[a][1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]); u[a][2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]); u[a][3] = t[a][2];
+    }
+    const int kc = c / W_CH, cc = c % W_CH, h = cc >> 2, e = cc & 3;
+    const int blk = n / W_BN, nl = n % W_BN;
+    const int wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+    const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+    char* slab = out + ((size_t)kc * nb + blk) * W_SLAB;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos)
+      reinterpret_cast<float*>(slab + ((size_t)pos * 64 + row) * W_REC + ((h ^ ((row >> 3) & 1)) * 16))[e] = u[pos >> 2][pos & 3];
   }
 }
 

@@ -35,7 +35,7 @@ def _pad16(c):
 
 class _Conv:
     """One conv layer's device state: master weights (TF layout), gradients, Adam slots, the two packed copies."""
-    __slots__ = ("name", "ci", "co", "w", "b", "gw", "gb", "mw", "vw", "mb", "vb", "pk", "pk_t", "b_pad")
+    __slots__ = ("name", "ci", "co", "w", "b", "gw", "gb", "mw", "vw", "mb", "vb", "pk", "pk_t", "pkw", "pkw_t", "b_pad")
 
 
 class TrainNet:
@@ -68,6 +68,9 @@ class TrainNet:
             c.mw, c.vw, c.mb, c.vb = (torch.zeros_like(c.w), torch.zeros_like(c.w), torch.zeros_like(c.b), torch.zeros_like(c.b))
             c.pk = torch.empty(self.L.fisr_train_packed_bytes(ci, co, 0) // 4, dtype=f32, device=self.device)
             c.pk_t = torch.empty(self.L.fisr_train_packed_bytes(ci, co, 1) // 4, dtype=f32, device=self.device)
+            nw, nwt = self.L.fisr_train_wino_bytes(ci, co, 0), self.L.fisr_train_wino_bytes(ci, co, 1)     # Winograd slabs (0 = not eligible)
+            c.pkw = torch.empty(nw // 4, dtype=f32, device=self.device) if nw else None
+            c.pkw_t = torch.empty(nwt // 4, dtype=f32, device=self.device) if nwt else None
             c.b_pad = torch.zeros(max(64, _pad16(co) + 48), dtype=f32, device=self.device)     # bias, padded to the N block
             self.convs[name] = c
         self.zero_bias = torch.zeros(1024, dtype=f32, device=self.device)
@@ -101,6 +104,10 @@ class TrainNet:
         for c in self.convs.values():
             self._ck(self.L.fisr_train_pack(self._p(c.w), c.ci, c.co, 0, self._p(c.pk), self._st()))
             self._ck(self.L.fisr_train_pack(self._p(c.w), c.ci, c.co, 1, self._p(c.pk_t), self._st()))
+            if c.pkw is not None:
+                self._ck(self.L.fisr_train_pack_wino(self._p(c.w), c.ci, c.co, 0, self._p(c.pkw), self._st()))
+            if c.pkw_t is not None:
+                self._ck(self.L.fisr_train_pack_wino(self._p(c.w), c.ci, c.co, 1, self._p(c.pkw_t), self._st()))
             c.b_pad[:c.co].copy_(c.b)
 
     def weights_numpy(self):
@@ -144,12 +151,12 @@ class TrainNet:
         if scatter is not None:
             dst, coff, split, gap = scatter
             self._ck(self.L.fisr_train_conv3x3(self._p(x0), c0, self._p(x1), c1, self._p(c.pk), self._p(c.b_pad), c.co, None,
-                                               self._p(dst), n, h, w, flags, dst.shape[3], coff, split, gap, self._st()))
+                                               self._p(dst), n, h, w, flags, dst.shape[3], coff, split, gap, None, self._st()))
             self.tape.append(("conv", c, x0, x1, None, dst, flags, scatter))
             return dst
         y = out if out is not None else (self.new(n, 2 * h, 2 * w, c.co // 4) if flags & D2S else self.new(n, h, w, c.co))
         self._ck(self.L.fisr_train_conv3x3(self._p(x0), c0, self._p(x1), c1, self._p(c.pk), self._p(c.b_pad), c.co, self._p(res),
-                                           self._p(y), n, h, w, flags, 0, 0, 0, 0, self._st()))
+                                           self._p(y), n, h, w, flags, 0, 0, 0, 0, self._p(c.pkw), self._st()))
         self.tape.append(("conv", c, x0, x1, res, y, flags, None))
         return y
 
@@ -273,7 +280,7 @@ class TrainNet:
                 # data gradient: the same conv with rotated taps, input g (cg channels, cg % 16 == 0), output c0 + c1 channels
                 dx = self.new(n, h, w, c0 + c1)
                 self._ck(L.fisr_train_conv3x3(self._p(g), cg, None, 0, self._p(c.pk_t), self._p(self.zero_bias), c0 + c1,
-                                              None, self._p(dx), n, h, w, 0, 0, 0, 0, 0, self._st()))
+                                              None, self._p(dx), n, h, w, 0, 0, 0, 0, 0, self._p(c.pkw_t), self._st()))
                 if c1:
                     d0, d1 = self.new(n, h, w, c0), self.new(n, h, w, c1)
                     npix = n * h * w

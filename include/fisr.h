@@ -235,9 +235,11 @@ int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int
  * (FISRnet.py:490-491). */
 size_t fisr_train_packed_bytes(int ci, int co, int transpose);
 int fisr_train_pack(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
+size_t fisr_train_wino_bytes(int ci, int co, int transpose);      /* 0: not eligible for the Winograd kernel */
+int fisr_train_pack_wino(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
 int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed, const float* d_bias,
                        int cout, const float* res, float* out, int n, int h, int w, int flags, int out_cstride,
-                       int out_coff, int out_split, int out_gap, void* stream);
+                       int out_coff, int out_split, int out_gap, const void* d_packed_wino /* nullable */, void* stream);
 int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw,
                      float* db /* nullable */, int ci, int co, int n, int h, int w, void* stream);
 int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream);

@@ -73,7 +73,7 @@ def test_wgrad_bgrad_dgrad_vs_autograd(env, n, h, w, c0, c1, ci, co, cg, relu_in
         assert L.fisr_train_pack(_ptr(wd), ci, co, 1, _ptr(pk), None) == 0
         zb = torch.zeros(1024, device="cuda:0")
         dx = torch.empty(n, h, w, c0 + c1, device="cuda:0")
-        assert L.fisr_train_conv3x3(_ptr(gd), cg, None, 0, _ptr(pk), _ptr(zb), c0 + c1, None, _ptr(dx), n, h, w, 0, 0, 0, 0, 0, None) == 0
+        assert L.fisr_train_conv3x3(_ptr(gd), cg, None, 0, _ptr(pk), _ptr(zb), c0 + c1, None, _ptr(dx), n, h, w, 0, 0, 0, 0, 0, None, None) == 0
         if relu_in:
             xd = _dev(torch, x)
             assert L.fisr_train_relu_bwd(_ptr(dx), _ptr(xd), _ptr(dx), dx.numel(), None) == 0
@@ -288,3 +288,33 @@ def test_data_parallel_step_equals_the_full_batch_step(env):
         if not r_[1]:
             print(r_[2])
     assert all(ok for _, ok, _ in res), res
+
+
+@pytest.mark.parametrize("transpose,flags,with_res", [(0, 3, True), (1, 0, False), (0, 7, False)])
+def test_train_conv_winograd_path_equals_direct_path(env, transpose, flags, with_res):
+    """Large dense layers of the training forward / data-gradient pass run on the persistent Winograd kernel with
+    device-packed slabs (fisr_train_pack_wino); the same call without the slabs runs the direct kernel."""
+    torch, L, lib = env
+    r = np.random.default_rng(17 + transpose)
+    n, h, w, ci, co = (8 if transpose else 4), 64, 256, 64, 128        # >= 512 work items either way
+    wt = _dev(torch, (r.standard_normal((3, 3, ci, co)) * 0.05).astype(np.float32))
+    cin, cout = (co, ci) if transpose else (ci, co)
+    x = _dev(torch, r.standard_normal((n, h, w, cin)).astype(np.float32))
+    bias = _dev(torch, r.standard_normal(1024).astype(np.float32) * 0.1)
+    d2s = bool(flags & 4)
+    res = _dev(torch, r.standard_normal((n, h, w, cout)).astype(np.float32)) if with_res else None
+    pk = torch.empty(L.fisr_train_packed_bytes(ci, co, transpose) // 4, device="cuda:0")
+    nb = L.fisr_train_wino_bytes(ci, co, transpose)
+    assert nb > 0
+    pkw = torch.empty(nb // 4, device="cuda:0")
+    assert L.fisr_train_pack(_ptr(wt), ci, co, transpose, _ptr(pk), None) == 0
+    assert L.fisr_train_pack_wino(_ptr(wt), ci, co, transpose, _ptr(pkw), None) == 0
+    shape = (n, 2 * h, 2 * w, cout // 4) if d2s else (n, h, w, cout)
+    y0, y1 = torch.empty(shape, device="cuda:0"), torch.empty(shape, device="cuda:0")
+    for y, slabs in ((y0, None), (y1, pkw)):
+        assert L.fisr_train_conv3x3(_ptr(x), cin, None, 0, _ptr(pk), _ptr(bias), cout, _ptr(res), _ptr(y), n, h, w, flags,
+                                    0, 0, 0, 0, _ptr(slabs), None) == 0
+    a, b = y0.cpu().numpy(), y1.cpu().numpy()
+    assert np.abs(a).max() > 0.5
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
+    assert not np.array_equal(a, b)          # (two different algorithms: identical bits would mean the slabs were ignored)
