@@ -815,3 +815,13 @@ def test_ssim_kernel_vs_oracle(net32):
     assert abs(net32.ssim_u8(torch.from_numpy(a), torch.from_numpy(a)) - 1.0) < 1e-12
     flat = np.full((14, 14, 3), 7, np.uint8)                  # zero variance tiles
     assert abs(net32.ssim_u8(torch.from_numpy(flat), torch.from_numpy(flat)) - 1.0) < 1e-12
+
+
+def test_winograd_vs_direct_random_large_shapes():
+    """The persistent Winograd kernel (many work items per workgroup, ragged sizes, concat, in-place residual, d2s) against
+    the direct exact-fp32 kernel on seeded random shapes; FISR_WINO_CAMPAIGN raises the case count for one-off campaigns
+    (250 cases passed when the kernel was written)."""
+    import subprocess
+    cases = os.environ.get("FISR_WINO_CAMPAIGN", "16")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "wino_campaign.py"), cases, "7"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
