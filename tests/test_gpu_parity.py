@@ -822,6 +822,8 @@ def test_winograd_vs_direct_random_large_shapes():
     the direct exact-fp32 kernel on seeded random shapes; FISR_WINO_CAMPAIGN raises the case count for one-off campaigns
     (250 cases passed when the kernel was written)."""
     import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cases = os.environ.get("FISR_WINO_CAMPAIGN", "16")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "wino_campaign.py"), cases, "7"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "wino_campaign.py"), cases, "7"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
