@@ -85,10 +85,14 @@ struct WgradArgs {
   float* db;                                        // nullable: db[co] += sum over pixels of g (done by the first ci block)
   int N, H, W, relu_in, ksplit;
 };
-constexpr int WG_TH = 8, WG_TW = 32;
-constexpr size_t wgrad_lds_bytes() { return (size_t)((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4; }
+constexpr int WG_TH = 4, WG_TW = 32;     // 4 rows = one per wave: the register tile prefetch stays small enough for two workgroups per CU
+// (the tiles, or the two 36 KB slots of the final reduction, whichever is larger)
+constexpr size_t wgrad_lds_bytes() {
+  return (size_t)((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4 > (size_t)2 * 9 * 16 * 64 * 4
+             ? (size_t)((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4 : (size_t)2 * 9 * 16 * 64 * 4;
+}
 
-__global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) char wg_smem[];
   float* const sX = reinterpret_cast<float*>(wg_smem);                       // [(8+2) x (32+2) px][32 ci]
   float* const sG = sX + (WG_TH + 2) * (WG_TW + 2) * 32;                     // [8 x 32 px][32 co]
@@ -165,10 +169,9 @@ __global__ __launch_bounds__(256) void train_wgrad_kernel(const WgradArgs p) {
     store_tile();
     __syncthreads();
     if (tile + p.ksplit < ntiles) load_tile(tile + p.ksplit);
-    // wave w: tile rows 2w, 2w+1; K steps of two neighbouring pixels
-#pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-      const int row = 2 * wave + rr;
+    // wave w: tile row w; K steps of two neighbouring pixels
+    {
+      const int row = wave;
 #pragma unroll 2
       for (int col = 0; col < WG_TW; col += 2) {
         const float b = sG[(row * WG_TW + col + kh) * 32 + li];
