@@ -19,6 +19,7 @@
 #include "../../include/fisr.h"
 #include "conv3x3.h"
 #include "conv3x3_wino8p.h"
+#include "head_conv.h"
 #include "glue_kernels.h"
 
 using namespace fisr;
@@ -37,6 +38,7 @@ struct ConvW {
   int cin_pad = 0, cout_pad = 0, nt = 2;
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino.h), else NULL
+  float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][8] for the vector-ALU head kernel (head_conv.h), else NULL
 };
 
 struct ProfEntry {
@@ -320,6 +322,15 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false) {
     HIP_OK(ctx, hipMalloc(&cw.d_wu, wp.size()));
     HIP_OK(ctx, hipMemcpy(cw.d_wu, wp.data(), wp.size(), hipMemcpyHostToDevice));
   }
+  if (cw.d_wh) { (void)hipFree(cw.d_wh); cw.d_wh = nullptr; }
+  if (wino && std::is_same<T, float>::value && cw.co <= 6) {
+    std::vector<float> wh((size_t)9 * cw.cin_pad * 8, 0.f);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int c = 0; c < cw.ci; ++c)
+        for (int n = 0; n < cw.co; ++n) wh[((size_t)tap * cw.cin_pad + c) * 8 + n] = cw.w[((size_t)tap * cw.ci + c) * cw.co + n];
+    HIP_OK(ctx, hipMalloc((void**)&cw.d_wh, wh.size() * sizeof(float)));
+    HIP_OK(ctx, hipMemcpy(cw.d_wh, wh.data(), wh.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -349,6 +360,33 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles * (a.CoutPad / (NT == 0 ? 16 : 32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
   hipLaunchKernelGGL(kern, grid, dim3(64 * (TILE_H / MR)), lds, st, a);
+  return hipGetLastError();
+}
+
+// The 3 / 6-channel heads of the fp32 engine on the vector ALU (head_conv.h); FISR_HEAD_VALU=0 keeps them on the 16-row MFMA
+// variant for A/B runs.
+inline bool head_valu_enabled() {
+  static const bool on = [] { const char* e = getenv("FISR_HEAD_VALU"); return !(e && e[0] == '0'); }();
+  return on;
+}
+hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    for (const void* k : {reinterpret_cast<const void*>(head_conv_f32_kernel<2>), reinterpret_cast<const void*>(head_conv_f32_kernel<3>)}) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds_bytes());
+      if (e != hipSuccess) return e;
+    }
+    attr_done[dev] = true;
+  }
+  HeadArgs h;
+  h.in = (const float*)a.in0; h.w = d_wh; h.bias = a.bias; h.out = (float*)a.out;
+  h.N = a.N; h.H = a.H; h.W = a.W; h.Cin = a.C0; h.Cout = a.Cout; h.relu_in = a.relu_in; h.relu_out = a.relu_out;
+  h.out_cstride = a.out_cstride; h.out_coff = a.out_coff; h.out_split = a.out_split; h.out_gap = a.out_gap;
+  const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
+  if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(256), head_lds_bytes(), st, h);
+  else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(256), head_lds_bytes(), st, h);
   return hipGetLastError();
 }
 
@@ -550,8 +588,10 @@ struct Runner {
     const double px = (double)n * h * w;
     const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
+    const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && !res && head_valu_enabled();
     char cls[96];
     if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s>", a.relu_in ? "relu_in" : "plain");
+    else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
     std::string cname(cls);
     if (ctx->prof_mode == 2) {
@@ -561,7 +601,7 @@ struct Runner {
     }
     ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
                  px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
-    check(use_wino ? launch_conv_wino(a, st) : launch_conv<T>(a, cw.nt, out_f32, st), name.c_str());
+    check(use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
   }
 
   // ops.py:39-44 res_block, in place on X with scratch A.
@@ -727,6 +767,7 @@ void fisr_destroy(fisr_ctx* ctx) {
     if (kv.second.d_w) (void)hipFree(kv.second.d_w);
     if (kv.second.d_b) (void)hipFree(kv.second.d_b);
     if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
+    if (kv.second.d_wh) (void)hipFree(kv.second.d_wh);
   }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
@@ -985,6 +1026,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   (void)hipFree(cw.d_w);
   (void)hipFree(cw.d_b);
   if (cw.d_wu) (void)hipFree(cw.d_wu);
+  if (cw.d_wh) (void)hipFree(cw.d_wh);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv sync: ") + hipGetErrorString(e2));
   return 0;
@@ -1102,7 +1144,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
-  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu);
+  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wh) (void)hipFree(cw.d_wh);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
   return 0;
 }

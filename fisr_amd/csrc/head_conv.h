@@ -1,0 +1,113 @@
+// The 3- and 6-channel heads of the fp32 engine (FISRnet.py:100,105: Conv2d(relu(n2), [3,3,64,6]) and Conv2d(n3, [3,3,64,3]) on
+// the pixel-shuffled 2H x 2W x 64 maps) on the VECTOR ALU.
+//
+// On the matrix pipe a head wastes most of every MFMA: 3 or 6 useful rows of the 16 the smallest fp32 MFMA has (the 16-row
+// variant of conv3x3.h: 92 TF/s of padded work, 6 % of the fp32 step).  The work itself is small -- 9 x 64 x (3 | 6) FMAs
+// per pixel -- and the packed fp32 FMA (v_pk_fma_f32: two lanes' worth per instruction) runs at the same 256 FLOP/clk/CU
+// as the fp32 MFMA, so here every lane owns one output pixel and keeps its 3 | 6 sums in registers:
+//     acc[o .. o+1] += x[tap][c] * w[tap][c][o .. o+1]            one v_pk_fma_f32 per channel and output pair,
+// x from the LDS halo tile (a ds_read_b128 = 4 channels feeds 12 | 8 packed FMAs), the weights -- uniform over the
+// workgroup -- straight from scalar registers (s_load), the op_sel bits broadcasting one x to both halves.
+// Tile 8 x 32 pixels, 256 threads, 16 channels (64 B per pixel, 80-byte LDS records as in conv3x3.h) per K chunk.
+#pragma once
+#include "conv3x3.h"
+
+namespace fisr {
+
+struct HeadArgs {
+  const float* in;    // [N, H, W, Cin] fp32, Cin % 16 == 0
+  const float* w;     // [9][Cin][8]: outputs padded to 8 (zeros)
+  const float* bias;  // [8]
+  float* out;         // channel n of pixel p at out[p * out_cstride + n + out_coff + (n >= out_split ? out_gap : 0)]
+  int N, H, W, Cin, Cout, relu_in, relu_out;
+  int out_cstride, out_coff, out_split, out_gap;
+};
+
+constexpr size_t head_lds_bytes() { return (size_t)HALO_PIX * REC_BYTES; }
+
+template <int NPAIR>   // output pairs: 3 (6 channels) or 2 (3 channels)
+__global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char hs[];
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x;
+  const int tiles_x = (p.W + TILE_W - 1) / TILE_W, tiles_y = (p.H + TILE_H - 1) / TILE_H;
+  int t = blockIdx.x;
+  const int tx_ = t % tiles_x; t /= tiles_x;
+  const int ty_ = t % tiles_y;
+  const int nb = t / tiles_y;
+  const int x0 = tx_ * TILE_W, y0 = ty_ * TILE_H;
+  const int px = tid & 31, py = tid >> 5;                   // this lane's pixel of the tile
+  f2 acc[NPAIR];
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) acc[k] = f2{p.bias[2 * k], p.bias[2 * k + 1]};
+  // loader: unit u = tid + 256 * i -> halo pixel u >> 2, 16-byte slot u & 3 (records spread as in conv3x3.h: no bank conflicts)
+  constexpr int NU = (HALO_PIX * 4 + 255) / 256;
+  auto spread4 = [](int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); };
+  int src[NU];                                              // pixel index in the image, -1: padding / nothing
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int hp = spread4((tid >> 2) + 64 * i);
+    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    src[i] = (hp < HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (nb * p.H + gy) * p.W + gx : -1;
+  }
+  const int slot = tid & 3;
+  f32x4 r[NU];
+  auto load = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (src[i] >= 0) r[i] = *reinterpret_cast<const f32x4*>(p.in + (size_t)src[i] * p.Cin + c0 + 4 * slot);
+    }
+  };
+  load(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += 16) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int hp = spread4((tid >> 2) + 64 * i);
+      if (hp < HALO_PIX) {
+        f32x4 v = r[i];
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(hs + hp * REC_BYTES + slot * 16) = v;
+      }
+    }
+    __syncthreads();
+    if (c0 + 16 < p.Cin) load(c0 + 16);                     // the next chunk's loads fly under this chunk's FMAs
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const char* rec = hs + ((py + tap / 3) * HALO_W + px + tap % 3) * REC_BYTES;
+      const float* wt = p.w + ((size_t)tap * p.Cin + c0) * 8;            // uniform: scalar loads
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(rec + q * 16);
+        const f2 xlo = {x.x, x.y}, xhi = {x.z, x.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* we = wt + (4 * q + e) * 8;
+#pragma unroll
+          for (int k = 0; k < NPAIR; ++k) {
+            const f2 wp = {we[2 * k], we[2 * k + 1]};
+            // low half: x_e * w[2k], high half: x_e * w[2k + 1] -- op_sel picks x_e out of its register pair for both
+            if ((e & 1) == 0)
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[k]) : "v"(e < 2 ? xlo : xhi), "s"(wp));
+            else
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[k]) : "v"(e < 2 ? xlo : xhi), "s"(wp));
+          }
+        }
+      }
+    }
+  }
+  const int x = x0 + px, y = y0 + py;
+  if (x >= p.W || y >= p.H) return;
+  float* ob = p.out + ((size_t)(nb * p.H + y) * p.W + x) * (size_t)p.out_cstride;
+#pragma unroll
+  for (int n = 0; n < 2 * NPAIR; ++n)
+    if (n < p.Cout) {
+      float v = (n & 1) ? acc[n >> 1].y : acc[n >> 1].x;
+      if (p.relu_out) v = fmaxf(v, 0.f);
+      ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = v;
+    }
+}
+
+}  // namespace fisr
