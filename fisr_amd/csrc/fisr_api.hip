@@ -1020,8 +1020,11 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
+  // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)
+  const bool use_head = precision == FISR_PREC_F32W && out_f32 && cw.d_wh && c1 == 0 && !res && head_valu_enabled();
   hipError_t e = use_wino ? launch_conv_wino(a, st)
-                          : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
+                 : use_head ? launch_head_valu(a, cw.d_wh, st)
+                            : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
   hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(cw.d_w);
   (void)hipFree(cw.d_b);

@@ -827,3 +827,17 @@ def test_winograd_vs_direct_random_large_shapes():
     cases = os.environ.get("FISR_WINO_CAMPAIGN", "16")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "wino_campaign.py"), cases, "7"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,flags", [(1, 8, 32, 64, 6, 0), (2, 13, 45, 64, 3, 1), (1, 37, 70, 32, 6, 3), (3, 5, 9, 64, 5, 0),
+                                                   (1, 64, 96, 64, 6, 1), (1, 16, 33, 128, 2, 2)])
+def test_fp32_heads_on_the_vector_alu_vs_oracle(n, h, w, cin, cout, flags):
+    """head_conv.h (the fp32 engine's 3 / 6-channel heads, FISRnet.py:100,105) through the conv op: ragged tiles, relu in /
+    out, channel counts the forward does not use."""
+    rng = np.random.default_rng(n * 100 + h + w + cout)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    got = hip_conv(x, wt, b, None, None, flags, prec="fp32w", out_f32=True)
+    exp = ref_conv(x, wt, b, None, None, flags)
+    assert got.shape == exp.shape and np.abs(got.astype(np.float64) - exp).max() < 2e-5
