@@ -84,6 +84,8 @@ def parse_args(argv=None):
     p.add_argument("--tmm_lambda", type=float, default=1.0)
     p.add_argument("--td_lambda", type=float, default=0.1)
     p.add_argument("--ss2_lambda", type=float, default=1.0)
+    p.add_argument("--save_tf_bundle", action="store_true",
+                   help="--phase train: also write every checkpoint as a TensorFlow checkpoint-V2 bundle (FISRnet-<step>.index/.data-*)")
     p.add_argument("--synthetic_train", type=int, default=0, metavar="N",
                    help="train on N seeded synthetic samples (the reference's pre-made training .mat/.flo files are not in its tree)")
     p.add_argument("--test_patch", type=_tuple2, default=(2, 2))

@@ -196,7 +196,13 @@ def run_train(args):
         # save_checkpoint (FISRnet.py:1091-1099): <checkpoint_dir>/<model_dir>/FISRnet-<global_step>
         name = f"FISRnet-{counter}"
         if rank == 0:
-            _weights.save_npz(os.path.join(ckpt_dir, name + ".npz"), net.weights_numpy())
+            Wn = net.weights_numpy()
+            _weights.save_npz(os.path.join(ckpt_dir, name + ".npz"), Wn)
+            if getattr(args, "save_tf_bundle", False):
+                # tf.train.Saver's checkpoint-V2 files (<name>.index / .data-00000-of-00001) under the reference's variable
+                # names, so that the reference's FISRnet.load (FISRnet.py:1101-1115) restores what was trained here
+                from . import tf_bundle
+                tf_bundle.write_bundle(os.path.join(ckpt_dir, name), Wn)
             with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
                 f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
     return last

@@ -208,12 +208,15 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     from fisr_amd.fisrnet import FISRnet
     d = str(tmp_path)
     argv = ["--phase", "train", "--synthetic_train", "6", "--epoch", "2", "--batch_size", "2", "--val_data_size", "2",
-            "--val_batch_size", "2", "--freq_display", "1", "--lr_type", "no_decay",
+            "--val_batch_size", "2", "--freq_display", "1", "--lr_type", "no_decay", "--save_tf_bundle",
             "--checkpoint_dir", d + "/ck", "--text_dir", d + "/tx", "--log_dir", d + "/lg", "--test_img_dir", d + "/ti"]
     assert main.main(argv) == 0
     path, kind, step = weights.find_checkpoint(d + "/ck", "FISRnet_exp1")
-    assert kind == "npz" and step == 4
+    assert kind in ("npz", "tf_bundle") and step == 4
     W = weights.load_weights(path, kind)
+    from fisr_amd import tf_bundle                                  # the TF checkpoint-V2 twin holds the same tensors
+    Wb = tf_bundle.read_bundle(os.path.join(d, "ck", "FISRnet_exp1", "FISRnet-4"), name_filter="FISRnet")
+    assert all(np.array_equal(Wb[k], W[k]) for k in W)
     W0 = weights.synthetic_weights(2020)
     assert any(not np.array_equal(W[k], W0[k]) for k in W)
     net = FISRnet(device="cuda:0", precision="fp32")
