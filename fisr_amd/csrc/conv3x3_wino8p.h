@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     // Output and residual are addressed as a per-item 64-bit base (the item's first pixel row) + 32-bit lane offsets.
     // Recomputed from an opaque lane id wherever it is used: hoisted out of the item loop, these per-lane values
     // would stay live across the K loops, which have no register to spare.
-    struct Geo { int ty, txq, c0; bool c_ok; };
+    struct Geo { int ty, txq, c0, lq; bool c_ok; };
     auto geometry = [&]() {
       int l = lane;
       asm volatile("" : "+v"(l));
@@ -462,23 +462,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       g.txq = (w_ & 15) & ~3;
       g.c0 = cur.nblk * W_BN + 32 * nh + 16 * (l >> 5);
       g.c_ok = g.c0 < p.Cout;
+      g.lq = l & 3;
       return g;
     };
     // residual records of output row `row` (quad-transposed fetch: lane q of a quad reads bytes 16q.. of each of the
-    // quad's four pixels, 64 contiguous bytes per quad and instruction)
+    // quad's four pixels, 64 contiguous bytes per quad and instruction).  Buffer loads: a lane outside the image (or the
+    // whole wave, without a residual) gets an offset behind the buffer's end and reads zeros -- no branch per record.
     auto load_res = [&](int row, uint4 (&rres)[2][4]) {      // rres[output column j][pixel k of the quad]
       const Geo g = geometry();
-      const char* const res_base = (const char*)p.res + ((size_t)cur.nb * p.H * p.W * rec_cs + rec_co) * 4;
+      const unsigned img_bytes = (unsigned)(p.H * p.W) * (unsigned)rec_cs * 4u - (unsigned)rec_co * 4u;
+      const unsigned nrec = (p.res != nullptr && !(FISR_WABL & 256)) ? img_bytes : 0u;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)p.res + ((size_t)cur.nb * p.H * p.W * rec_cs + rec_co) * 4), 0, nrec, 0x00020000);
       const int oy = (cur.y0 + 2 * g.ty + row) * dil + cur.ry;
+      const bool row_ok = g.c_ok & (oy < p.H);
+      const unsigned rowoff = ((unsigned)(oy * p.W) * (unsigned)rec_cs + (unsigned)(g.c0 + 4 * g.lq)) * 4u;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int x = (cur.x0 + 2 * (g.txq + k) + j) * dil + cur.rx;
-          rres[j][k] = make_uint4(0u, 0u, 0u, 0u);
-          if (!(FISR_WABL & 256) && p.res != nullptr && g.c_ok && oy < p.H && x < p.W)
-            rres[j][k] = *reinterpret_cast<const uint4*>(
-                res_base + ((unsigned)(oy * p.W + x) * (unsigned)rec_cs + (unsigned)(g.c0 + 4 * (lane & 3))) * 4u);
+          const unsigned xo = rowoff + (unsigned)x * (unsigned)rec_cs * 4u;
+          const unsigned off = (row_ok & (x < p.W)) ? xo : nrec;     // (&: a select, no control flow)
+          rres[j][k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         }
     };
 
@@ -550,17 +556,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     lds_barrier();
     if (p.trace && n_done == tr_item) t_bar = __builtin_readcyclecounter();
     if (ph == 0) {
+      // Store addressing without a branch per record: inside image nb the byte offset of the lane's 16 bytes is
+      //     4 * (oy * A + x * B + C),   A, B uniform, C per lane
+      // (depth_to_space: record (y, x), channel c0 -> pixel (2y + sub / 2, 2x + sub % 2) of the 2H x 2W image, channel
+      // c0 % cq with sub = c0 / cq, cq = Cout / 4), and buffer stores, which drop the lanes whose offset lies behind the
+      // buffer's end: that is where the lanes outside the image point.  The relu is a maximum with 0 or -inf (leaky:
+      // with slope * v or 1 * v), a uniform operand instead of a branch.  (With a branch per record and flag the 16
+      // stores of a wave were 100 taken or skipped branches: 2k of the 6k cycles of this stage, which one wave per SIMD
+      // runs alone.)
       const int cq_shift = p.d2s_shift;
-      // element offset of the record of pixel (y, xc) inside image nb (one image of the tensor: fits 32 bits)
-      char* const out_base = (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4
-                                                   : ((size_t)cur.nb * p.H * p.W * rec_cs + rec_co) * 4);
-      auto record = [&](int y, int xc) -> unsigned {
-        if (p.d2s) {
-          const int sub = c0 >> cq_shift, c = c0 & ((1 << cq_shift) - 1);
-          return ((unsigned)((2 * y + (sub >> 1)) * (2 * p.W) + 2 * xc + (sub & 1)) << cq_shift) + (unsigned)c;
-        }
-        return (unsigned)(y * p.W + xc) * (unsigned)rec_cs + (unsigned)c0;
-      };
+      const unsigned sub = (unsigned)c0 >> cq_shift;
+      const unsigned sA = p.d2s ? (unsigned)(4 * p.W) << cq_shift : (unsigned)p.W * (unsigned)rec_cs;
+      const unsigned sB = p.d2s ? 2u << cq_shift : (unsigned)rec_cs;
+      const unsigned vC = (p.d2s ? ((((sub >> 1) * 2u * (unsigned)p.W + (sub & 1u)) << cq_shift) + ((unsigned)c0 & ((1u << cq_shift) - 1u)))
+                                 : (unsigned)c0) + 4u * (unsigned)geo.lq;
+      const unsigned out_bytes = p.d2s ? ((unsigned)(4 * p.H * p.W) << cq_shift) * 4u
+                                       : (unsigned)(p.H * p.W) * (unsigned)rec_cs * 4u - (unsigned)rec_co * 4u;
+      const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+          (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4
+                                : ((size_t)cur.nb * p.H * p.W * rec_cs + rec_co) * 4), 0, out_bytes, 0x00020000);
+      const float relu_lo = __builtin_bit_cast(float, p.relu_out ? 0u : 0xff800000u);
+      const float relu_sl = p.relu_out ? slope : 1.f;
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {              // output column j of every winograd tile
@@ -580,16 +596,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
             const f2 y1 = t1 + f2{X1[e], X1[e + 1]};
             o0[e] = y0.x; o0[e + 1] = y0.y; o1[e] = y1.x; o1[e + 1] = y1.y;
           }
-          if (p.relu_out) {
-            if (slope != 0.f) {                // leaky relu (0 < slope < 1)
+          if (GENERAL) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], slope * o0[e]); o1[e] = fmaxf(o1[e], slope * o1[e]); }
-            } else {
+            for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], relu_sl * o0[e]); o1[e] = fmaxf(o1[e], relu_sl * o1[e]); }
+          } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                asm("v_max_f32 %0, 0, %0" : "+v"(o0[e]));
-                asm("v_max_f32 %0, 0, %0" : "+v"(o1[e]));
-              }
+            for (int e = 0; e < 4; ++e) {
+              asm("v_max_f32 %0, %1, %0" : "+v"(o0[e]) : "s"(relu_lo));
+              asm("v_max_f32 %0, %1, %0" : "+v"(o1[e]) : "s"(relu_lo));
             }
           }
           rec[0][k] = __builtin_bit_cast(uint4, o0);
@@ -598,13 +612,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
 #pragma unroll
         for (int row = 0; row < 2; ++row) {
           quad_transpose(rec[row], lane);
+          const int oy = (cur.y0 + 2 * ty + row) * dil + cur.ry;
+          const bool row_ok = c_ok & (oy < p.H);
+          const unsigned rowoff = ((unsigned)oy * sA + vC) * 4u;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int x = (cur.x0 + 2 * (txq + k) + j) * dil + cur.rx, oy = (cur.y0 + 2 * ty + row) * dil + cur.ry;
-            if (!(FISR_WABL & 128) && c_ok && oy < p.H && x < p.W) {
-              u32x4_t* dst = reinterpret_cast<u32x4_t*>(out_base + (record(oy, x) + 4u * (lane & 3)) * 4u);
-              __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, rec[row][k]), dst);
-            }
+            const int x = (cur.x0 + 2 * (txq + k) + j) * dil + cur.rx;
+            const unsigned xo = rowoff + (unsigned)x * sB * 4u;
+            const unsigned off = (row_ok & (x < p.W) & !(FISR_WABL & 128)) ? xo : out_bytes;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, rec[row][k]), os, off, 0, 2);   // aux 2: nontemporal
           }
         }
       }

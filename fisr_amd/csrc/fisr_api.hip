@@ -258,7 +258,7 @@ inline bool wino_eligible(int ci, int co) { (void)ci; return co >= W_BN && co % 
 // the kernel addresses its input tensors, and one image of its output, with 32-bit byte offsets
 inline bool wino_fits(int n, int h, int w, int c0, int c1, int co) {
   const double px = (double)n * h * w;
-  return px * std::max(c0, c1) * 4.0 < 4294967296.0 && (double)h * w * co * 4.0 < 4294967296.0;
+  return px * std::max(c0, c1) * 4.0 < 4294967296.0 && (double)h * w * co * 4.0 < 4294967296.0 - 64.0;
 }
 // (co need not be a multiple of the 64-channel block: the last block is zero padded, the kernel skips the stores)
 void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {

@@ -13,11 +13,17 @@ print("rc", rc, "us", us.value, L.fisr_last_error(None) if rc else "")
 
 import numpy as np
 a = np.fromfile(out, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+nwg = int((a[:, 7] > 0).sum())
+if prec == 4 and len(a) >= 2 * nwg and nwg > 0 and (a[nwg:2 * nwg, 3] > a[nwg:2 * nwg, 0]).all():
+    x = a[nwg:2 * nwg]
+    print("output stage: combine in LDS %.0f  read back %.0f  relu + stores %.0f" % (
+        np.median(x[:, 1] - x[:, 0]), np.median(x[:, 2] - x[:, 1]), np.median(x[:, 3] - x[:, 2])))
+    a = a[:nwg]
 a = a[a[:, 2] > a[:, 0]]
 t0, tm, te, tf, e1, e2, e3 = a[:, 0], a[:, 1], a[:, 2], a[:, 4], a[:, 5], a[:, 6], a[:, 7]
 med = lambda x: float(np.median(x))
 clk = (te - t0) / np.maximum(e2 - e1, 1) * 100.0   # s_memtime ticks per 100 MHz s_memrealtime tick -> MHz
 print(f"shader clock while the kernel runs: median {med(clk):.0f} MHz (10%..90%: {np.percentile(clk,10):.0f}..{np.percentile(clk,90):.0f})")
 if (a[:, 3] > tm).all():   # persistent kernel: the exchange barrier of the traced item
-    print(f"epilogue up to the exchange barrier {med(a[:, 3] - tm):.0f}")
+    print(f"epilogue up to the exchange barrier {med(a[:, 3] - tm):.0f}  output stage {med(te - a[:, 3]):.0f}  first iteration {med(tf - t0):.0f}  items/wg {med(e3):.0f}")
 print(f"blocks {len(a)}  life {med(te - t0):.0f}  prologue {med(tf - t0):.0f}  main(after prologue) {med(tm - tf):.0f}  epilogue {med(te - tm):.0f}")
