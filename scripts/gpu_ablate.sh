@@ -4,9 +4,10 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ -n "$PARITY" ]; then
-  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q --no-header -rf -p no:cacheprovider -x -k "winograd" > gpurun_out/pytest_wino.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_wino.log | cut -c1-600
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --no-header -rf -p no:cacheprovider -x -k "${PARITY_K:-winograd}" > gpurun_out/pytest_wino.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_wino.log | cut -c1-600
 fi
 for so in fisr_amd/libfisr_hip.so build_ab/*.so; do
+  [ -f "$so" ] || continue
   for res in 1 0; do
     echo "== $so res=$res 64->64"
     FISR_HIP_SO=$PWD/$so timeout 120 python scripts/trace_conv.py /tmp/t.bin 12 544 992 64 64 3 $res fp32w 2>&1 | grep -v "^shader"
