@@ -26,7 +26,10 @@ struct rest_t { static constexpr bool value = false; };
 // GENERAL = false: FISRnet (dense NHWC tensors, relu).  GENERAL = true: PWC-Net's layers as well -- channel ranges of a
 // wider buffer as input and output (in0_cs, rec_cs, rec_co), leaky relu (slope), dilation (dil).  A template flag because
 // the K loops have no register to spare: the extra kernel arguments alone make the compiler spill.
-template <bool RELU_IN, bool GENERAL>
+// HAS_RES = false: the layer has no residual input (p.res == NULL) -- nothing is loaded, transposed or added for it: a
+// third of the output stage's instructions.  (A kernel template parameter: the same epilogue twice inside one kernel
+// makes the compiler spill.)
+template <bool RELU_IN, bool GENERAL, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p, const int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sV = smem;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     // part of their latency.  (Hoisted further, into the last K iteration, these 32 registers make the compiler spill
     // inside the K loop.)
     uint4 rres[2][4];
-    load_res(ph, rres);
+    if constexpr (HAS_RES) load_res(ph, rres);
     __builtin_amdgcn_sched_barrier(0);
     flush_stage3();                                // the last chunk's pending stage
     if (p.trace) { t_main = __builtin_readcyclecounter(); if (n_done == tr_item) t_it1 = t_main; }
@@ -534,10 +537,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        quad_transpose(rres[j], lane);           // -> [k] = this lane's pixel, channels 4k .. 4k+3
+        if constexpr (HAS_RES) quad_transpose(rres[j], lane);           // -> [k] = this lane's pixel, channels 4k .. 4k+3
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const f32x4 r1 = __builtin_bit_cast(f32x4, rres[j][k]);
+          f32x4 r1 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (HAS_RES) r1 = __builtin_bit_cast(f32x4, rres[j][k]);
           f32x4 X0, X1;
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
             const f2 t2 = FISR_W8_COL(pk_sub1, 0, j, r), t3 = FISR_W8_COL(pk_sub1, 4, j, r);
             const f2 b = {bv[r], bv[r + 1]};
             const f2 x0 = t2 + b;
-            const f2 x1 = pk_sub1(b + f2{r1[e], r1[e + 1]}, t2 + t3);
+            const f2 x1 = pk_sub1(HAS_RES ? b + f2{r1[e], r1[e + 1]} : b, t2 + t3);
             X0[e] = x0.x; X0[e + 1] = x0.y; X1[e] = x1.x; X1[e + 1] = x1.y;
           }
           *reinterpret_cast<f32x4*>(sV + xoff + (j * 4 + k) * 1024) = X0;
@@ -581,18 +585,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
 #pragma unroll
       for (int j = 0; j < 2; ++j) {              // output column j of every winograd tile
         uint4 rec[2][4];
-        quad_transpose(rres[j], lane);
+        if constexpr (HAS_RES) quad_transpose(rres[j], lane);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {            // channels 4k .. 4k+3 of the record
           const f32x4 X0 = *reinterpret_cast<const f32x4*>(sV + xoff + (j * 4 + k) * 1024);
           const f32x4 X1 = *reinterpret_cast<const f32x4*>(sU + xoff + (j * 4 + k) * 1024);
-          const f32x4 r0 = __builtin_bit_cast(f32x4, rres[j][k]);
+          f32x4 r0 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (HAS_RES) r0 = __builtin_bit_cast(f32x4, rres[j][k]);
           f32x4 o0, o1;
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
             const int r = 4 * k + e;
             const f2 t0 = FISR_W8_COL(pk_sub0, 0, j, r), t1 = FISR_W8_COL(pk_sub0, 4, j, r);
-            const f2 y0 = ((t0 + t1) + f2{X0[e], X0[e + 1]}) + f2{r0[e], r0[e + 1]};
+            f2 y0 = (t0 + t1) + f2{X0[e], X0[e + 1]};
+            if constexpr (HAS_RES) y0 += f2{r0[e], r0[e + 1]};
             const f2 y1 = t1 + f2{X1[e], X1[e + 1]};
             o0[e] = y0.x; o0[e + 1] = y0.y; o1[e] = y1.x; o1[e + 1] = y1.y;
           }

@@ -402,12 +402,15 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    const void* kerns[6] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
+    const void* kerns[9] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
                             reinterpret_cast<const void*>(conv3x3_wino8_kernel<false>),
                             reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true>)};
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false, false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false, true>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false, false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false, true>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true, false>),
+                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true, true>)};
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
@@ -434,11 +437,18 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
     // one workgroup per CU (the kernel needs all of a CU's LDS and half its registers), a multiple of 8 so that the
     // items of a workgroup stay on one XCD
     const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
+    const bool res = a.res != nullptr;                 // (its own instantiation: see conv3x3_wino8p.h)
+#define FISR_W8P_LAUNCH(RI, GEN)                                                                              \
+  do {                                                                                                        \
+    if (res) hipLaunchKernelGGL((conv3x3_wino8p_kernel<RI, GEN, true>), dim3(grid), dim3(512), lds, st, a, items);  \
+    else hipLaunchKernelGGL((conv3x3_wino8p_kernel<RI, GEN, false>), dim3(grid), dim3(512), lds, st, a, items);     \
+  } while (0)
     if (!plain) {
       if (a.relu_in) return hipErrorInvalidValue;      // (not instantiated: PWC-Net's activations come out of the producer)
-      hipLaunchKernelGGL((conv3x3_wino8p_kernel<false, true>), dim3(grid), dim3(512), lds, st, a, items);
-    } else if (a.relu_in) hipLaunchKernelGGL((conv3x3_wino8p_kernel<true, false>), dim3(grid), dim3(512), lds, st, a, items);
-    else hipLaunchKernelGGL((conv3x3_wino8p_kernel<false, false>), dim3(grid), dim3(512), lds, st, a, items);
+      FISR_W8P_LAUNCH(false, true);
+    } else if (a.relu_in) FISR_W8P_LAUNCH(true, false);
+    else FISR_W8P_LAUNCH(false, false);
+#undef FISR_W8P_LAUNCH
   }
   return hipGetLastError();
 }

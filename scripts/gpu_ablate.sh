@@ -4,7 +4,10 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ -n "$PARITY" ]; then
-  timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --no-header -rf -p no:cacheprovider -x -k "${PARITY_K:-winograd}" > gpurun_out/pytest_wino.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_wino.log | cut -c1-600
+  for so in fisr_amd/libfisr_hip.so ${PARITY_ALL:+build_ab/*.so}; do
+    [ -f "$so" ] || continue
+    FISR_HIP_SO=$PWD/$so timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --no-header -rf -p no:cacheprovider -x -k "${PARITY_K:-winograd}" > gpurun_out/pytest_wino.log 2>&1; echo "pytest $so rc=$?"; tail -3 gpurun_out/pytest_wino.log | cut -c1-600
+  done
 fi
 for so in fisr_amd/libfisr_hip.so build_ab/*.so; do
   [ -f "$so" ] || continue
