@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the FISRnet hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--precision fp32|bf16x3|f16f8|fp16]
+    python bench.py --gpus N --steps K --warmup W [--precision fp32|bf16x3|f16f8|mixed|fp16]
                     [--parallelism frame|tile] [--others bf16x3,f16f8]
 
 A "step" is one pass of the hot path over one 5-frame 1080x1920 LR stack resident in HBM
@@ -47,13 +47,14 @@ import numpy as np
 FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 2 644 164 MAC)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md (spec; ~6300 achievable with a float4 copy)
 # dense MFMA peak of the instruction class each engine issues (MI355X_MICROARCH.md), TFLOP/s
-PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0}
+PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0, "mixed": 2500.0}
 # matrix-pipe work per algorithmic product (direct 3x3): Winograd F(2x2,3x3) issues 16/36 of the multiplies
-MFMA_PER_PRODUCT = {"fp32": None, "fp32d": 1, "fp32w": None, "fp16": 1, "bf16x3": 3, "f16f8": 2.11}
+MFMA_PER_PRODUCT = {"fp32": None, "fp32d": 1, "fp32w": None, "fp16": 1, "bf16x3": 3, "f16f8": 2.11, "mixed": None}
 DTYPE = {"fp32": "f32", "fp32d": "f32", "fp32w": "f32",
          "fp16": "f16 (f32 accumulate)",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
-         "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)"}
+         "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)",
+         "mixed": "mixed (bf16x3 at the full resolution of level 3 -- first encoder level, last decoder level, heads --, f16 elsewhere; f32 accumulate)"}
 UNIQUE_PER_STACK = 7                # 3 windows x 3 frames, overlaps counted once (FISRnet.py:913-920)
 
 
@@ -483,7 +484,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=sorted(PEAK))
-    ap.add_argument("--others", default="fp32d,bf16x3,f16f8",
+    ap.add_argument("--others", default="fp32d,bf16x3,f16f8,mixed",
                     help="further engines timed on rank 0 at N=1 under other_precisions ('' = none)")
     ap.add_argument("--parallelism", default="frame", choices=["frame", "tile"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")

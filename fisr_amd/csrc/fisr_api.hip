@@ -39,6 +39,7 @@ struct ConvW {
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino.h), else NULL
   float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][8] for the vector-ALU head kernel (head_conv.h), else NULL
+  int prec = -1;          // the precision the device copies are packed for (differs per layer in FISR_PREC_MIXED)
 };
 
 struct ProfEntry {
@@ -173,6 +174,20 @@ auto with_prec(int precision, F&& f) {
 inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
          precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W;
+}
+// FISR_PREC_MIXED: which layers keep the split-bf16 arithmetic -- everything that works at the full resolution of
+// level 3 (its first encoder level, its last decoder level, both heads); the rest of the network runs in fp16.
+// (Measured with the fp64 oracle and fp16 rounding injected layer by layer: all-fp16 shifts the SR channel's PSNR by
+// 0.026 dB on the default weight set, this plan by 0.008 dB, 0.005 / 0.0002 dB on the other two sets.)
+inline bool mixed_layer_is_hi(const std::string& name) {
+  static const char* const hi[] = {"FISRnet/level_3/enc/level_0/", "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/FI-SR/",
+                                   "FISRnet/level_3/SR/"};
+  for (const char* h : hi)
+    if (name.compare(0, strlen(h), h) == 0) return true;
+  return false;
+}
+inline int layer_prec(int precision, const std::string& name) {
+  return precision != FISR_PREC_MIXED ? precision : (mixed_layer_is_hi(name) ? FISR_PREC_BF16X3 : FISR_PREC_F16);
 }
 inline bool prec_grouped16(int precision) { return precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8; }
 
@@ -580,6 +595,10 @@ struct Runner {
     auto it = ctx->convs.find(name);
     if (it == ctx->convs.end()) { rc = fail(ctx, FISR_EMISSING, "unknown conv " + name); return; }
     const ConvW& cw = it->second;
+    if (with_prec(cw.prec, [](auto tag) { return !std::is_same<decltype(tag), T>::value; })) {
+      rc = fail(ctx, FISR_ESTATE, name + ": weights are packed for another precision than this engine stage runs in");
+      return;
+    }
     if (c0 + c1 != cw.cin_pad) {
       rc = fail(ctx, FISR_EINVAL, name + ": channel mismatch " + std::to_string(c0 + c1) + " vs " + std::to_string(cw.cin_pad));
       return;
@@ -642,51 +661,53 @@ struct Runner {
     check(hipGetLastError(), "prep_level_input");
   }
 
-  // One U-Net + the two heads at working resolution rh x rw (FISRnet.py:83-108).
-  // xin: [n,rh,rw,cin_pad]; pred: float32 [n,2rh,2rw,9].
-  void level(int lv, const T* xin, int cin_pad, int n, int rh, int rw, float* pred) {
-    const std::string P = "FISRnet/level_" + std::to_string(lv);
-    const int ch[3] = {64, 128, 256};
-    const T* cur = xin;
-    int cc = cin_pad, h = rh, w = rw;
-    T* skip[3];
-    for (int l = 0; l < 3; ++l) {  // Enc_level_res ops.py:48-55
-      const std::string e = P + "/enc/level_" + std::to_string(l);
-      const size_t px = (size_t)n * h * w;
-      T* X = talloc(px * ch[l]);
-      T* A = talloc(px * ch[l]);
-      conv(e + "/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
-      rb(e + "/res_block/0", X, A, ch[l], n, h, w, false);
-      rb(e + "/res_block/1", X, A, ch[l], n, h, w, true);  // n = relu(res_block(...)); skip = n
-      skip[l] = X;
-      T* Pl = talloc(px / 4 * ch[l]);
-      pool(X, Pl, n, h, w, ch[l]);
-      cur = Pl; cc = ch[l]; h /= 2; w /= 2;
-    }
-    {  // Bottleneck_res ops.py:59-63
-      const size_t px = (size_t)n * h * w;
-      T* X = talloc(px * 512);
-      T* A = talloc(px * 512);
-      conv(P + "/bottleneck/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
-      rb(P + "/bottleneck/res_block/0", X, A, 512, n, h, w, true);
-      cur = X; cc = 512;
-    }
-    for (int l = 2; l >= 0; --l) {  // Dec_level_res ops.py:67-76
-      const std::string d = P + "/dec/level_" + std::to_string(l);
-      T* U = talloc((size_t)n * h * w * 4 * cc);
-      up(cur, U, n, h, w, cc);
-      h *= 2; w *= 2;
-      const size_t px = (size_t)n * h * w;
-      T* D = talloc(px * ch[l]);
-      conv(d + "/resize", U, cc, nullptr, 0, nullptr, D, n, h, w, FISR_CONV_RELU_OUT);
-      T* X = talloc(px * ch[l]);
-      T* A = talloc(px * ch[l]);
-      conv(d + "/conv/0", D, ch[l], skip[l], ch[l], nullptr, X, n, h, w, 0);  // concat([n, skip])
-      rb(d + "/res_block/0", X, A, ch[l], n, h, w, false);
-      rb(d + "/res_block/1", X, A, ch[l], n, h, w, true);
-      cur = X; cc = ch[l];
-    }
-    // heads FISRnet.py:95-108
+  // The pieces of one level (FISRnet.py:83-108); `level` strings them together, the mixed-precision engine runs them
+  // on two Runners (see MixedRunner).
+  static const int* widths() { static const int ch[3] = {64, 128, 256}; return ch; }
+
+  // Enc_level_res ops.py:48-55 at h x w: returns the pooled map (h/2 x w/2), *skip = relu(res_block(...))
+  T* enc_level(const std::string& P, int l, const T* cur, int cc, int n, int h, int w, T** skip) {
+    const int c = widths()[l];
+    const std::string e = P + "/enc/level_" + std::to_string(l);
+    const size_t px = (size_t)n * h * w;
+    T* X = talloc(px * c);
+    T* A = talloc(px * c);
+    conv(e + "/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
+    rb(e + "/res_block/0", X, A, c, n, h, w, false);
+    rb(e + "/res_block/1", X, A, c, n, h, w, true);  // n = relu(res_block(...)); skip = n
+    *skip = X;
+    T* Pl = talloc(px / 4 * c);
+    pool(X, Pl, n, h, w, c);
+    return Pl;
+  }
+  // Bottleneck_res ops.py:59-63
+  T* bottleneck(const std::string& P, const T* cur, int cc, int n, int h, int w) {
+    const size_t px = (size_t)n * h * w;
+    T* X = talloc(px * 512);
+    T* A = talloc(px * 512);
+    conv(P + "/bottleneck/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
+    rb(P + "/bottleneck/res_block/0", X, A, 512, n, h, w, true);
+    return X;
+  }
+  // Dec_level_res ops.py:67-76: cur is h x w with cc channels, the result 2h x 2w with widths()[l]
+  T* dec_level(const std::string& P, int l, const T* cur, int cc, const T* skip, int n, int h, int w) {
+    const int c = widths()[l];
+    const std::string d = P + "/dec/level_" + std::to_string(l);
+    T* U = talloc((size_t)n * h * w * 4 * cc);
+    up(cur, U, n, h, w, cc);
+    h *= 2; w *= 2;
+    const size_t px = (size_t)n * h * w;
+    T* D = talloc(px * c);
+    conv(d + "/resize", U, cc, nullptr, 0, nullptr, D, n, h, w, FISR_CONV_RELU_OUT);
+    T* X = talloc(px * c);
+    T* A = talloc(px * c);
+    conv(d + "/conv/0", D, c, skip, c, nullptr, X, n, h, w, 0);  // concat([n, skip])
+    rb(d + "/res_block/0", X, A, c, n, h, w, false);
+    rb(d + "/res_block/1", X, A, c, n, h, w, true);
+    return X;
+  }
+  // heads FISRnet.py:95-108: cur [n,h,w,64] -> pred float32 [n,2h,2w,9]
+  void heads(const std::string& P, const T* cur, int n, int h, int w, float* pred) {
     const size_t px = (size_t)n * h * w;
     T* Hx = talloc(px * 64);
     T* A = talloc(px * 64);
@@ -701,6 +722,26 @@ struct Runner {
       if (hd == 0) conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 0, 3, 3);
       else         conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 3);
     }
+  }
+
+  // One U-Net + the two heads at working resolution rh x rw (FISRnet.py:83-108).
+  // xin: [n,rh,rw,cin_pad]; pred: float32 [n,2rh,2rw,9].
+  void level(int lv, const T* xin, int cin_pad, int n, int rh, int rw, float* pred) {
+    const std::string P = "FISRnet/level_" + std::to_string(lv);
+    const T* cur = xin;
+    int cc = cin_pad, h = rh, w = rw;
+    T* skip[3];
+    for (int l = 0; l < 3; ++l) {
+      cur = enc_level(P, l, cur, cc, n, h, w, &skip[l]);
+      cc = widths()[l]; h /= 2; w /= 2;
+    }
+    cur = bottleneck(P, cur, cc, n, h, w);
+    cc = 512;
+    for (int l = 2; l >= 0; --l) {
+      cur = dec_level(P, l, cur, cc, skip[l], n, h, w);
+      cc = widths()[l]; h *= 2; w *= 2;
+    }
+    heads(P, cur, n, h, w, pred);
   }
 
   // FISRnet.py:73-173
@@ -730,6 +771,82 @@ struct Runner {
     return rc;
   }
 };
+
+// FISR_PREC_MIXED: fp16 everywhere except at the full resolution of level 3 (mixed_layer_is_hi), which stays in
+// split bf16.  Two Runners over ONE arena; the activation format changes twice, both times on a quarter-size tensor:
+// behind the pooling of level 3's first encoder level (split bf16 -> fp16) and in front of the x2 up-sampling of its
+// last decoder level (fp16 -> split bf16).
+struct MixedRunner {
+  Runner<_Float16> lo;
+  Runner<bsplit> hi;
+
+  template <typename TI, typename TO>
+  void convert(Runner<TO>& dst, const TI* in, TO* out, size_t elems) {
+    if (dst.rc || dst.ar.dry) return;
+    const size_t nrec = elems / 16;
+    ProfScope ps(dst.ctx, dst.st, "convert_records", 0, (double)elems * (sizeof(TI) + sizeof(TO)));
+    hipLaunchKernelGGL((convert_records_kernel<TI, TO>), dim3(grid_for(nrec)), dim3(256), 0, dst.st, in, out, nrec);
+    dst.check(hipGetLastError(), "convert_records");
+  }
+
+  int forward(const float* in, int n, int h, int w, float* l3, float* l2, float* l1) {
+    if (!l1) l1 = (float*)lo.ar.alloc((size_t)n * (h / 2) * (w / 2) * 9 * sizeof(float));
+    if (!l2) l2 = (float*)lo.ar.alloc((size_t)n * h * w * 9 * sizeof(float));
+    const size_t mark = lo.ar.off;
+    const int c1 = round_up(29, Prec<_Float16>::CC), c2 = round_up(38, Prec<_Float16>::CC), c3 = round_up(38, Prec<bsplit>::CC);
+    {
+      _Float16* x = lo.talloc((size_t)n * (h / 4) * (w / 4) * c1);
+      lo.prep(in, nullptr, x, n, h, w, 4, c1);
+      lo.level(1, x, c1, n, h / 4, w / 4, l1);
+    }
+    lo.ar.off = mark;
+    {
+      _Float16* x = lo.talloc((size_t)n * (h / 2) * (w / 2) * c2);
+      lo.prep(in, l1, x, n, h, w, 2, c2);
+      lo.level(2, x, c2, n, h / 2, w / 2, l2);
+    }
+    lo.ar.off = mark;
+    if (lo.rc) return lo.rc;
+    const std::string P = "FISRnet/level_3";
+    hi.ar = lo.ar;
+    bsplit* x = hi.talloc((size_t)n * h * w * c3);
+    hi.prep(in, l2, x, n, h, w, 1, c3);
+    bsplit* skip0 = nullptr;
+    const bsplit* pooled = hi.enc_level(P, 0, x, c3, n, h, w, &skip0);
+    lo.ar = hi.ar;
+    const size_t px2 = (size_t)n * (h / 2) * (w / 2);
+    _Float16* cur16 = lo.talloc(px2 * 64);
+    convert(lo, pooled, cur16, px2 * 64);
+    _Float16* skip[3] = {nullptr, nullptr, nullptr};
+    const _Float16* cur = cur16;
+    int cc = 64, hh = h / 2, ww = w / 2;
+    for (int l = 1; l < 3; ++l) {
+      cur = lo.enc_level(P, l, cur, cc, n, hh, ww, &skip[l]);
+      cc = Runner<_Float16>::widths()[l]; hh /= 2; ww /= 2;
+    }
+    cur = lo.bottleneck(P, cur, cc, n, hh, ww);
+    cc = 512;
+    for (int l = 2; l >= 1; --l) {
+      cur = lo.dec_level(P, l, cur, cc, skip[l], n, hh, ww);
+      cc = Runner<_Float16>::widths()[l]; hh *= 2; ww *= 2;
+    }
+    if (lo.rc) return lo.rc;
+    hi.ar = lo.ar;
+    bsplit* curb = hi.talloc(px2 * 128);
+    convert(hi, cur, curb, px2 * 128);
+    const bsplit* top = hi.dec_level(P, 0, curb, 128, skip0, n, hh, ww);
+    hi.heads(P, top, n, h, w, l3);
+    lo.ar = hi.ar;
+    return hi.rc;
+  }
+};
+
+inline size_t ws_bytes_mixed(fisr_ctx* ctx, int n, int h, int w) {
+  MixedRunner r;
+  r.lo.ctx = r.hi.ctx = ctx; r.lo.st = r.hi.st = nullptr; r.lo.ar.dry = true;
+  r.forward(nullptr, n, h, w, (float*)1, nullptr, nullptr);
+  return r.lo.ar.peak + 256;
+}
 
 template <typename T>
 size_t ws_bytes_t(fisr_ctx* ctx, int n, int h, int w) {
@@ -820,7 +937,7 @@ int fisr_num_variables_set(const fisr_ctx* ctx) {
 
 int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_finalize_weights: ctx is NULL");
-  if (!prec_ok(precision)) return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
+  if (!prec_ok(precision) && precision != FISR_PREC_MIXED) return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
   for (auto& s : all_specs()) {
     const ConvW& cw = ctx->convs[s.name];
     if (!cw.have_w) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/w");
@@ -829,8 +946,10 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   DeviceGuard guard(ctx->dev);
   HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
-    int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, precision == FISR_PREC_F32W); });
+    const int lp = layer_prec(precision, kv.first);
+    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, lp == FISR_PREC_F32W); });
     if (rc) return rc;
+    kv.second.prec = lp;
   }
   ctx->wino = precision == FISR_PREC_F32W;
   ctx->precision = precision;
@@ -841,6 +960,7 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
 size_t fisr_workspace_bytes(const fisr_ctx* cctx, int n, int h, int w) {
   fisr_ctx* ctx = const_cast<fisr_ctx*>(cctx);
   if (!ctx || !ctx->finalized || n < 1 || h < 32 || w < 32 || h % 32 || w % 32) return 0;
+  if (ctx->precision == FISR_PREC_MIXED) return ws_bytes_mixed(ctx, n, h, w);
   return with_prec(ctx->precision, [&](auto tag) { return ws_bytes_t<decltype(tag)>(ctx, n, h, w); });
 }
 
@@ -864,6 +984,12 @@ int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out
     r.ar.base = (char*)workspace; r.ar.cap = workspace_bytes;
     return r.forward(in, n, h, w, out_l3, out_l2, out_l1);
   };
+  if (ctx->precision == FISR_PREC_MIXED) {
+    MixedRunner r;
+    r.lo.ctx = r.hi.ctx = ctx; r.lo.st = r.hi.st = st;
+    r.lo.ar.base = (char*)workspace; r.lo.ar.cap = workspace_bytes;
+    return r.forward(in, n, h, w, out_l3, out_l2, out_l1);
+  }
   return with_prec(ctx->precision, run);
 }
 

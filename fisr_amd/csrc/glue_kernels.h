@@ -114,6 +114,27 @@ __global__ void prep_level_input_kernel(const float* __restrict__ img, const flo
   }
 }
 
+// ---- storage format change between two engines' activation tensors (the mixed-precision engine): 16-channel records,
+//      same pixel and channel order on both sides ----
+template <typename TI, typename TO>
+__global__ void convert_records_kernel(const TI* __restrict__ in, TO* __restrict__ out, size_t nrec) {
+  typedef Rec16<TI> RI;
+  typedef Rec16<TO> RO;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4* ib = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(in) + i * 16 * sizeof(TI));
+    uint4 q[RI::NV];
+#pragma unroll
+    for (int k = 0; k < RI::NV; ++k) q[k] = ib[k];
+    float v[16];
+    RI::decode(q, v);
+    uint4 o[RO::NV];
+    RO::encode(v, o);
+    uint4* ob = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + i * 16 * sizeof(TO));
+#pragma unroll
+    for (int k = 0; k < RO::NV; ++k) ob[k] = o[k];
+  }
+}
+
 // ---- 2x2/2 max pool: ops.py:54 tf.nn.max_pool(..., 'SAME') on even sizes ----
 template <typename T>
 __global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {

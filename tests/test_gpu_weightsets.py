@@ -21,7 +21,8 @@ from fisr_amd import weights  # noqa: E402
 from fisr_amd.fisrnet import FISRnet  # noqa: E402
 
 # engine -> (max |err| relative to the largest |oracle value| of the level, allowed PSNR shift in dB)
-ENGINES = {"fp32d": (3e-5, 2e-4), "fp32": (1e-4, 5e-4), "bf16x3": (5e-4, 0.004), "f16f8": (2e-3, 0.01)}
+ENGINES = {"fp32d": (3e-5, 2e-4), "fp32": (1e-4, 5e-4), "bf16x3": (5e-4, 0.004), "f16f8": (2e-3, 0.01),
+           "mixed": (1e-2, 0.012)}     # (levels 1 and 2 of the mixed engine are plain fp16: the relative bound is fp16's)
 
 
 def _psnr_shift(hip, oracle, rng):
@@ -67,7 +68,9 @@ def test_forward_other_weight_sets_vs_oracle(wset, engine):
                            for b in range(n) for f in range(3)) if min(g.shape[1:3]) >= 7 else 1.0
                 print(f"{name} {engine} {lvl} n{n} {h}x{w}: max|err| {err:.3e} (scale {scale:.2f}) dPSNR {shift:.2e} dB  SSIM(hip,oracle) {ssim:.6f}")
                 assert err <= rel_tol * scale, (name, engine, lvl, err, scale)
-                assert shift <= db_tol <= 0.02, (name, engine, lvl, shift)
+                # (the mixed engine runs levels 1 and 2 -- inputs of level 3, not outputs of the network -- in plain fp16)
+                lvl_tol = 0.02 if engine == "mixed" and lvl != "pred_l3" else db_tol
+                assert shift <= lvl_tol <= 0.02, (name, engine, lvl, shift)
                 assert 1.0 - ssim <= 1e-3, (name, engine, lvl, ssim)
     finally:
         net.close()
@@ -117,7 +120,7 @@ def test_full_size_ten_scenes_fast_engines_vs_fp32(syn_weights):
     ref = FISRnet(device="cuda:0", precision="fp32d")
     ref.set_weights(syn_weights)
     engines = {}
-    for p in ("fp32", "bf16x3", "f16f8"):
+    for p in ("fp32", "bf16x3", "f16f8", "mixed"):
         engines[p] = FISRnet(device="cuda:0", precision=p)
         engines[p].set_weights(syn_weights)
     gen = torch.Generator(device=dev).manual_seed(2024)
