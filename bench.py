@@ -192,7 +192,8 @@ def _pmc_conv_traffic(pmc, name):
     try:
         tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
         if name.startswith("conv3x3_wino"):
-            key = "conv3x3_wino8p_kernel<true" if "relu_in" in name else "conv3x3_wino8p_kernel<false"
+            key = "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false",
+                                                             "false" if "nores" in name else "true")
         else:
             nt = name.split("NT")[1][0]
             key = f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in name else 'false'}"

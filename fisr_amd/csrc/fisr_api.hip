@@ -619,7 +619,7 @@ struct Runner {
     if (use_wino) a.wpk = cw.d_wu;
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && !res && head_valu_enabled();
     char cls[96];
-    if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s>", a.relu_in ? "relu_in" : "plain");
+    if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
     std::string cname(cls);
