@@ -968,15 +968,25 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         if constexpr (QT) {
           uint4 (&q4)[4] = reinterpret_cast<uint4 (&)[4]>(q);
           quad_transpose(q4, lane);
+          // no branch per record: the element offset inside image nb is y * A + xc * B + C for the plain and the
+          // depth_to_space layout alike, and buffer stores drop the lanes past the right image border (their offset is
+          // set behind the buffer's end)
+          const unsigned sub = (unsigned)c0 >> cq_shift;
+          const unsigned eB = p.d2s ? 2u << cq_shift : (unsigned)p.Cout;
+          const unsigned e0 = p.d2s ? ((((unsigned)(2 * y) + (sub >> 1)) * (unsigned)(2 * p.W) + (sub & 1u)) << cq_shift) + ((unsigned)c0 & ((1u << cq_shift) - 1u))
+                                    : (unsigned)(y * p.W) * (unsigned)p.Cout + (unsigned)c0;
+          const unsigned img_bytes = (unsigned)((size_t)p.H * p.W * p.Cout * sizeof(T));      // (same for both layouts)
+          const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+              (char*)p.out + (size_t)nb * img_bytes, 0, img_bytes, 0x00020000);
+          typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-          for (int k = 0; k < ((FISR_ABL & 256) ? 2 : 4); ++k)   // ablation 256: half of the store instructions
-            if (xq + k < p.W) {
-              uint4* dst = reinterpret_cast<uint4*>((char*)p.out + record(xq + k) * sizeof(T)) + (li & 3);
-              // streaming store: the activation tensors (GBs) are never re-read from cache by this kernel
-              typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-              u32x4_t nv; nv.x = q4[k].x; nv.y = q4[k].y; nv.z = q4[k].z; nv.w = q4[k].w;
-              __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>(dst));
-            }
+          for (int k = 0; k < ((FISR_ABL & 256) ? 2 : 4); ++k) {   // ablation 256: half of the store instructions
+            const unsigned eo = (e0 + (unsigned)(xq + k) * eB) * (unsigned)sizeof(T) + 16u * (unsigned)(li & 3);
+            const unsigned off = (xq + k < p.W) ? eo : img_bytes;
+            u32x4_t nv; nv.x = q4[k].x; nv.y = q4[k].y; nv.z = q4[k].z; nv.w = q4[k].w;
+            // streaming store: the activation tensors (GBs) are never re-read from cache by this kernel
+            __builtin_amdgcn_raw_buffer_store_b128(nv, os, off, 0, 2);
+          }
         } else {
           uint4* ob = reinterpret_cast<uint4*>((char*)p.out + record(x) * sizeof(T));
 #pragma unroll

@@ -372,6 +372,8 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_done[dev] = true;
   }
+  // the record stores address one output image with 32-bit offsets (buffer stores)
+  if (!OUT_F32 && (double)a.H * a.W * a.Cout * sizeof(T) >= 4294967296.0 - 64.0) return hipErrorInvalidValue;
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
   dim3 grid(tiles * (a.CoutPad / (NT == 0 ? 16 : 32 * NT)));   // 1-D: the kernel orders tiles x N-blocks XCD-aware
   hipLaunchKernelGGL(kern, grid, dim3(64 * (TILE_H / MR)), lds, st, a);
