@@ -114,6 +114,54 @@ __global__ void prep_level_input_kernel(const float* __restrict__ img, const flo
   }
 }
 
+// The same for s = 1 (level 3: 97 % of the pixels of the three levels), staged through LDS: the 116-byte pixels of the
+// packed input and the 36-byte pixels of the prediction are not 16-byte aligned, so a thread that fetches "its" 16
+// channels issues 16 scalar loads; here a block copies the flat span of 256 pixels with aligned 16-byte loads, then
+// every thread assembles records from LDS (odd strides 29 / 9 floats: no bank conflicts).
+template <typename T>
+__global__ __launch_bounds__(256) void prep_level_input_s1_kernel(const float* __restrict__ img, const float* __restrict__ pred,
+                                                                   T* __restrict__ out, size_t npix, int cpad) {
+  typedef Rec16<T> R16;
+  __shared__ __attribute__((aligned(16))) float s_img[256 * 29];
+  __shared__ __attribute__((aligned(16))) float s_pred[256 * 9 + 4];
+  const int tid = threadIdx.x;
+  const int groups = cpad / 16;
+  for (size_t p0 = (size_t)blockIdx.x * 256; p0 < npix; p0 += (size_t)gridDim.x * 256) {
+    const int np = (int)min((size_t)256, npix - p0);
+    {
+      const float* g = img + p0 * 29;                         // 16-byte aligned: p0 % 4 == 0 (and the tensor is)
+      const int nf = np * 29, n4 = ((size_t)img & 15) == 0 ? nf >> 2 : 0;
+      for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(s_img)[j] = reinterpret_cast<const f32x4*>(g)[j];
+      for (int j = 4 * n4 + tid; j < nf; j += 256) s_img[j] = g[j];
+    }
+    if (pred != nullptr) {
+      const float* g = pred + p0 * 9;
+      const int nf = np * 9, n4 = ((size_t)pred & 15) == 0 ? nf >> 2 : 0;
+      for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(s_pred)[j] = reinterpret_cast<const f32x4*>(g)[j];
+      for (int j = 4 * n4 + tid; j < nf; j += 256) s_pred[j] = g[j];
+    }
+    __syncthreads();
+    for (int r = tid; r < np * groups; r += 256) {
+      const int pl = r / groups, g = r - pl * groups;
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int c = 16 * g + k;
+        float t = 0.f;
+        if (c < 29) t = s_img[pl * 29 + c];
+        else if (pred != nullptr && c < 38) t = s_pred[pl * 9 + (c - 29)];
+        v[k] = t;
+      }
+      uint4 q[R16::NV];
+      R16::encode(v, q);
+      uint4* ob = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + ((p0 + pl) * cpad + 16 * g) * sizeof(T));
+#pragma unroll
+      for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- storage format change between two engines' activation tensors (the mixed-precision engine): 16-channel records,
 //      same pixel and channel order on both sides ----
 template <typename TI, typename TO>
@@ -268,62 +316,112 @@ struct PackPtrs {
   const float* wp[4];
 };
 
-__global__ void pack_input_kernel(const PackPtrs pp, int H0, int W0, int H, int W, float* __restrict__ out) {
+// A block assembles 256 consecutive pixels in LDS (odd stride 29: no bank conflicts) and writes the 29 696 contiguous bytes
+// with aligned 16-byte stores: a thread writing "its" 29 floats scatters 4-byte stores over a 116-byte stride (r01: 2.2 x
+// the algorithmic HBM traffic, 0.2 of the HBM peak).
+__global__ __launch_bounds__(256) void pack_input_kernel(const PackPtrs pp, int H0, int W0, int H, int W, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_o[256 * 29];
   const size_t total = (size_t)H * W;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W), y = (int)(i / W);
-    const size_t s = (size_t)y * W0 + x;
-    float* o = out + i * 29;
+  const int tid = threadIdx.x;
+  for (size_t i0 = (size_t)blockIdx.x * 256; i0 < total; i0 += (size_t)gridDim.x * 256) {
+    const size_t i = i0 + tid;
+    if (i < total) {
+      const int x = (int)(i % W), y = (int)(i / W);
+      const size_t s = (size_t)y * W0 + x;
+      float* o = s_o + tid * 29;
 #pragma unroll
-    for (int f = 0; f < 3; ++f)
+      for (int f = 0; f < 3; ++f)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        // np.array(img, dtype=np.double)/255. then clip (FISRnet.py:828-830), fed as float32
-        const double v = (double)pp.fr[f][s * 3 + c] / 255.0;
-        o[f * 3 + c] = (float)fmin(fmax(v, 0.0), 1.0);
-      }
+        for (int c = 0; c < 3; ++c) {
+          // np.array(img, dtype=np.double)/255. then clip (FISRnet.py:828-830), fed as float32
+          const double v = (double)pp.fr[f][s * 3 + c] / 255.0;
+          o[f * 3 + c] = (float)fmin(fmax(v, 0.0), 1.0);
+        }
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        // flow/96/2, clip [-1,1] in float32 (FISRnet.py:835-836)
-        const float v = __fdiv_rn(__fdiv_rn(pp.fl[f][s * 2 + c], 96.f), 2.f);
-        o[9 + f * 2 + c] = fminf(fmaxf(v, -1.f), 1.f);
-      }
+        for (int c = 0; c < 2; ++c) {
+          // flow/96/2, clip [-1,1] in float32 (FISRnet.py:835-836)
+          const float v = __fdiv_rn(__fdiv_rn(pp.fl[f][s * 2 + c], 96.f), 2.f);
+          o[9 + f * 2 + c] = fminf(fmaxf(v, -1.f), 1.f);
+        }
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        // .mat value /255 in float32 (utils.py:51), clip [0,1] (FISRnet.py:840)
-        const float v = __fdiv_rn(pp.wp[f][s * 3 + c], 255.f);
-        o[17 + f * 3 + c] = fminf(fmaxf(v, 0.f), 1.f);
-      }
+        for (int c = 0; c < 3; ++c) {
+          // .mat value /255 in float32 (utils.py:51), clip [0,1] (FISRnet.py:840)
+          const float v = __fdiv_rn(pp.wp[f][s * 3 + c], 255.f);
+          o[17 + f * 3 + c] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    }
+    __syncthreads();
+    const int np = (int)min((size_t)256, total - i0);
+    float* g = out + i0 * 29;                               // 16-byte aligned: i0 % 4 == 0 (and the tensor is)
+    const int nf = np * 29, n4 = ((size_t)out & 15) == 0 ? nf >> 2 : 0;
+    for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(g)[j] = reinterpret_cast<const f32x4*>(s_o)[j];
+    for (int j = 4 * n4 + tid; j < nf; j += 256) g[j] = s_o[j];
+    __syncthreads();
   }
 }
 
 // ---- output post-processing: FISRnet.py:883, 903-909; utils.py:106-115 ----
-__global__ void unpack_output_kernel(const float* __restrict__ pred, int H, int W, uint8_t* __restrict__ yuv_u8,
-                                     uint8_t* __restrict__ rgb_u8, const ColorConsts cc) {
+// Staged through LDS like pack_input: 36-byte pixels in, 9-byte (YUV) and 3 x 3-byte (RGB planes) pixels out, all moved
+// as aligned 16-byte vectors of a block's 256-pixel span (the byte streams of a span are 16-byte aligned when
+// H * W % 16 == 0; otherwise the tail path stores bytes).
+__global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restrict__ pred, int H, int W, uint8_t* __restrict__ yuv_u8,
+                                                            uint8_t* __restrict__ rgb_u8, const ColorConsts cc) {
 #pragma clang fp contract(off)
+  __shared__ __attribute__((aligned(16))) float s_p[256 * 9 + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t s_yuv[256 * 9];
+  __shared__ __attribute__((aligned(16))) uint8_t s_rgb[3][256 * 3];
   const size_t total = (size_t)H * W;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  const bool vec = (total & 15) == 0 && (((size_t)yuv_u8 | (size_t)rgb_u8) & 15) == 0;
+  const int tid = threadIdx.x;
+  for (size_t i0 = (size_t)blockIdx.x * 256; i0 < total; i0 += (size_t)gridDim.x * 256) {
+    const int np = (int)min((size_t)256, total - i0);
+    {
+      const float* g = pred + i0 * 9;                       // 16-byte aligned: i0 % 4 == 0 (and the tensor is)
+      const int nf = np * 9, n4 = ((size_t)pred & 15) == 0 ? nf >> 2 : 0;
+      for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(s_p)[j] = reinterpret_cast<const f32x4*>(g)[j];
+      for (int j = 4 * n4 + tid; j < nf; j += 256) s_p[j] = g[j];
+    }
+    __syncthreads();
+    if (tid < np) {
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
-      float q[3];
+      for (int f = 0; f < 3; ++f) {
+        float q[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v = fminf(fmaxf(pred[i * 9 + f * 3 + c], 0.f), 1.f);  // np.clip(., 0, 1)
-        const uint8_t b = (uint8_t)(int)((double)v * 255.0);               // np.uint8(x*255): truncation
-        if (yuv_u8) yuv_u8[i * 9 + f * 3 + c] = b;
-        q[c] = (float)b;
-      }
-      if (rgb_u8) {
-        double rgb[3];
-        yuv2rgb_d(cc, q, rgb);
+        for (int c = 0; c < 3; ++c) {
+          const float v = fminf(fmaxf(s_p[tid * 9 + f * 3 + c], 0.f), 1.f);  // np.clip(., 0, 1)
+          const uint8_t b = (uint8_t)(int)((double)v * 255.0);               // np.uint8(x*255): truncation
+          s_yuv[tid * 9 + f * 3 + c] = b;
+          q[c] = (float)b;
+        }
+        if (rgb_u8) {
+          double rgb[3];
+          yuv2rgb_d(cc, q, rgb);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb_u8[((size_t)f * total + i) * 3 + c] = (uint8_t)(int)rgb[c];
+          for (int c = 0; c < 3; ++c) s_rgb[f][tid * 3 + c] = (uint8_t)(int)rgb[c];
+        }
       }
     }
+    __syncthreads();
+    if (yuv_u8) {
+      uint8_t* g = yuv_u8 + i0 * 9;
+      const int nb = np * 9, n16 = vec ? nb >> 4 : 0;
+      for (int j = tid; j < n16; j += 256) reinterpret_cast<uint4*>(g)[j] = reinterpret_cast<const uint4*>(s_yuv)[j];
+      for (int j = 16 * n16 + tid; j < nb; j += 256) g[j] = s_yuv[j];
+    }
+    if (rgb_u8) {
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        uint8_t* g = rgb_u8 + ((size_t)f * total + i0) * 3;
+        const int nb = np * 3, n16 = vec ? nb >> 4 : 0;
+        for (int j = tid; j < n16; j += 256) reinterpret_cast<uint4*>(g)[j] = reinterpret_cast<const uint4*>(s_rgb[f])[j];
+        for (int j = 16 * n16 + tid; j < nb; j += 256) g[j] = s_rgb[f][j];
+      }
+    }
+    __syncthreads();
   }
 }
 

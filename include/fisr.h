@@ -57,7 +57,7 @@ enum {
                          rounding only (different summation order). */
   FISR_PREC_MIXED = 5, /* engine only (fisr_finalize_weights; not an op-level precision): FISR_PREC_F16 everywhere
                           except at the full resolution of level 3 -- its first encoder level, its last decoder level
-                          and both heads --, which keep FISR_PREC_BF16X3.  The activation format changes twice, on
+                          and both heads --, which keep a split format (FISR_PREC_F16F8).  The activation format changes twice, on
                           quarter-size tensors.  PSNR shift of the SR channel against the fp64 oracle <= 0.01 dB on
                           the three weight sets of tests/ (all-fp16: 0.026 dB, outside north_star's +-0.02 dB). */
   FISR_PREC_F16F8 = 3  /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels

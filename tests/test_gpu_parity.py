@@ -576,7 +576,7 @@ def test_forward_f16f8_vs_golden(netf8, gold_dir):
 
 def test_forward_mixed_precision_vs_golden(dev, syn_weights, gold_dir):
     """FISR_PREC_MIXED: fp16 everywhere but at the full resolution of level 3 (first encoder level, last decoder level,
-    heads: split bf16).  Levels 1 and 2 are plain fp16; the level-3 prediction -- the one the reference keeps -- must
+    heads: the f16f8 split format).  Levels 1 and 2 are plain fp16; the level-3 prediction -- the one the reference keeps -- must
     sit inside +-0.02 dB with margin on every channel group (all-fp16: 0.026 dB on the SR channel, the next test), and
     the engine must be bit-identical over batch sizes like the others."""
     net = FISRnet(device="cuda:0", precision="mixed")
