@@ -446,6 +446,8 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
                      a.slope == 0.f && d == 1;
   if (d < 1 || (d > 1 && a.d2s)) return hipErrorInvalidValue;
   if (!plain && (variant == 4 || variant == 8 || nch < 4)) return hipErrorInvalidValue;
+  // the epilogue addresses one output (and residual) image with 32-bit byte offsets (buffer loads / stores)
+  if ((double)a.H * a.W * a.rec_cs * 4.0 >= 4294967296.0 - 64.0) return hipErrorInvalidValue;
   if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(items), dim3(256), lds, st, a);
   else if (variant == 8 || nch < 4) {
     if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8_kernel<true>, dim3(items), dim3(512), lds, st, a);
@@ -658,7 +660,7 @@ struct Runner {
   void prep(const float* img, const float* pred, T* out, int n, int H, int W, int s, int cpad) {
     if (rc || ar.dry) return;
     const size_t work = (size_t)n * (H / s) * (W / s) * (cpad / 16);   // one thread per 16-channel record
-    ProfScope ps(ctx, st, "prep_level_input", 0, (double)work * 16 * (4 + sizeof(T)));
+    ProfScope ps(ctx, st, s == 1 ? "prep_level_input_s1" : "prep_level_input", 0, (double)work * 16 * (4 + sizeof(T)));
     if (s == 1)      // (level 3: the staged variant; the strided levels read too sparsely for it)
       hipLaunchKernelGGL(prep_level_input_s1_kernel<T>, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, st, img, pred, out, (size_t)n * H * W, cpad);
     else

@@ -428,6 +428,19 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const float* __restr
 // ---- stitch: trim_patch_boundary (utils.py:138-159) + FISRnet.py:879-880 ----
 __global__ void stitch_kernel(const float* __restrict__ tile, int TW, int sy, int sx, int CH, int CW,
                               float* __restrict__ full, int FW, int dy, int dx) {
+  // rows of CW * 9 floats; 16-byte vectors when every row start is aligned on both sides (tile widths, halos and crop
+  // offsets are multiples of 4 pixels in every call of the harness)
+  const bool vec = ((TW | sx | CW | FW | dx) & 3) == 0 && (((size_t)tile | (size_t)full) & 15) == 0;
+  if (vec) {
+    const int rw = CW * 9 / 4;                       // 16-byte vectors per row
+    const size_t total = (size_t)CH * rw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+      const int v = (int)(i % rw), y = (int)(i / rw);
+      reinterpret_cast<f32x4*>(full + ((size_t)(dy + y) * FW + dx) * 9)[v] =
+          reinterpret_cast<const f32x4*>(tile + ((size_t)(sy + y) * TW + sx) * 9)[v];
+    }
+    return;
+  }
   const size_t total = (size_t)CH * CW * 9;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % 9);
