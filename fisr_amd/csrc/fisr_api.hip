@@ -38,7 +38,7 @@ struct ConvW {
   int cin_pad = 0, cout_pad = 0, nt = 2;
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino.h), else NULL
-  float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][8] for the vector-ALU head kernel (head_conv.h), else NULL
+  float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][4 | 6] for the vector-ALU head kernel (head_conv.h), else NULL
   int prec = -1;          // the precision the device copies are packed for (differs per layer in FISR_PREC_MIXED)
 };
 
@@ -339,10 +339,13 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false) {
   }
   if (cw.d_wh) { (void)hipFree(cw.d_wh); cw.d_wh = nullptr; }
   if (wino && std::is_same<T, float>::value && cw.co <= 6) {
-    std::vector<float> wh((size_t)9 * cw.cin_pad * 8, 0.f);
+    // [9][cin_pad][4 | 6] (outputs padded to the kernel's pairs only): 9 x 64 x 6 floats = 13.8 KB stay resident in the
+    // 16 KB scalar cache the kernel reads them through; padded to 8 (18 KB) every read missed it
+    const int ws = cw.co <= 4 ? 4 : 6;
+    std::vector<float> wh((size_t)9 * cw.cin_pad * ws, 0.f);
     for (int tap = 0; tap < 9; ++tap)
       for (int c = 0; c < cw.ci; ++c)
-        for (int n = 0; n < cw.co; ++n) wh[((size_t)tap * cw.cin_pad + c) * 8 + n] = cw.w[((size_t)tap * cw.ci + c) * cw.co + n];
+        for (int n = 0; n < cw.co; ++n) wh[((size_t)tap * cw.cin_pad + c) * ws + n] = cw.w[((size_t)tap * cw.ci + c) * cw.co + n];
     HIP_OK(ctx, hipMalloc((void**)&cw.d_wh, wh.size() * sizeof(float)));
     HIP_OK(ctx, hipMemcpy(cw.d_wh, wh.data(), wh.size() * sizeof(float), hipMemcpyHostToDevice));
   }
@@ -391,10 +394,10 @@ hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-    for (const void* k : {reinterpret_cast<const void*>(head_conv_f32_kernel<2>), reinterpret_cast<const void*>(head_conv_f32_kernel<3>)}) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds_bytes());
-      if (e != hipSuccess) return e;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds_bytes<2>());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_conv_f32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds_bytes<3>());
+    if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
   HeadArgs h;
@@ -402,8 +405,8 @@ hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st
   h.N = a.N; h.H = a.H; h.W = a.W; h.Cin = a.C0; h.Cout = a.Cout; h.relu_in = a.relu_in; h.relu_out = a.relu_out;
   h.out_cstride = a.out_cstride; h.out_coff = a.out_coff; h.out_split = a.out_split; h.out_gap = a.out_gap;
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
-  if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(256), head_lds_bytes(), st, h);
-  else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(256), head_lds_bytes(), st, h);
+  if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(256), head_lds_bytes<2>(), st, h);
+  else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(256), head_lds_bytes<3>(), st, h);
   return hipGetLastError();
 }
 
@@ -621,7 +624,7 @@ struct Runner {
     const double px = (double)n * h * w;
     const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
-    const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && !res && head_valu_enabled();
+    const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     char cls[96];
     if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
@@ -1165,7 +1168,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
   // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)
-  const bool use_head = precision == FISR_PREC_F32W && out_f32 && cw.d_wh && c1 == 0 && !res && head_valu_enabled();
+  const bool use_head = precision == FISR_PREC_F32W && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
   hipError_t e = use_wino ? launch_conv_wino(a, st)
                  : use_head ? launch_head_valu(a, cw.d_wh, st)
                             : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });

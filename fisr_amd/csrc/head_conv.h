@@ -8,22 +8,34 @@
 //     acc[o .. o+1] += x[tap][c] * w[tap][c][o .. o+1]            one v_pk_fma_f32 per channel and output pair,
 // x from the LDS halo tile (a ds_read_b128 = 4 channels feeds 12 | 8 packed FMAs), the weights -- uniform over the
 // workgroup -- straight from scalar registers (s_load), the op_sel bits broadcasting one x to both halves.
-// Tile 8 x 32 pixels, 256 threads, 16 channels (64 B per pixel, 80-byte LDS records as in conv3x3.h) per K chunk.
+// Tile 8 x 32 pixels, 256 threads, 16 or 32 channels per K chunk (HeadCfg).
 #pragma once
 #include "conv3x3.h"
 
 namespace fisr {
 
 struct HeadArgs {
-  const float* in;    // [N, H, W, Cin] fp32, Cin % 16 == 0
-  const float* w;     // [9][Cin][8]: outputs padded to 8 (zeros)
+  const float* in;    // [N, H, W, Cin] fp32, Cin % 32 == 0
+  const float* w;     // [9][Cin][2 * NPAIR]: outputs padded to the kernel's pairs (zeros)
   const float* bias;  // [8]
   float* out;         // channel n of pixel p at out[p * out_cstride + n + out_coff + (n >= out_split ? out_gap : 0)]
   int N, H, W, Cin, Cout, relu_in, relu_out;
   int out_cstride, out_coff, out_split, out_gap;
 };
 
-constexpr size_t head_lds_bytes() { return (size_t)HALO_PIX * REC_BYTES; }
+// K chunk: the kernel is bound by its read of the 64-channel 4K tensor (6.6 GB per launch at full size: 3.1 TB/s, its
+// FMAs, LDS reads and scalar weight loads can all be ablated without changing the time), so the chunk size is what
+// measured best per variant: 32 channels = one whole 128-byte line of every pixel record per pass (144-byte LDS records,
+// 3 workgroups per CU) for the 3-channel head (2116 -> 1749 us), 16 channels (80-byte records, 5 workgroups per CU) for
+// the 6-channel one, whose longer FMA phases need the extra workgroups (2161 vs 2473 us with 32).
+// Both record sizes put the 16 lanes of a ds_read_b128 phase on 16 distinct bank groups.
+template <int NPAIR> struct HeadCfg {
+  static constexpr int CH = NPAIR == 2 ? 32 : 16;     // channels per K chunk
+  static constexpr int REC = CH * 4 + 16;             // LDS bytes per pixel record
+  static constexpr int SLOTS = CH / 4;                // 16-byte slots per record
+};
+constexpr int HEAD_CH = 32;                           // the engine routes a conv here when Cin % HEAD_CH == 0
+template <int NPAIR> constexpr size_t head_lds_bytes() { return (size_t)HALO_PIX * HeadCfg<NPAIR>::REC; }
 
 template <int NPAIR>   // output pairs: 3 (6 channels) or 2 (3 channels)
 __global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
@@ -40,18 +52,21 @@ __global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
   f2 acc[NPAIR];
 #pragma unroll
   for (int k = 0; k < NPAIR; ++k) acc[k] = f2{p.bias[2 * k], p.bias[2 * k + 1]};
-  // loader: unit u = tid + 256 * i -> halo pixel u >> 2, 16-byte slot u & 3 (records spread as in conv3x3.h: no bank conflicts)
-  constexpr int NU = (HALO_PIX * 4 + 255) / 256;
-  auto spread4 = [](int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); };
+  // loader: unit u = tid + 256 * i -> halo pixel u / SLOTS, 16-byte slot u % SLOTS: consecutive lanes fetch the
+  // contiguous bytes of one pixel's chunk
+  constexpr int HCH = HeadCfg<NPAIR>::CH, HREC = HeadCfg<NPAIR>::REC, SLOTS = HeadCfg<NPAIR>::SLOTS;
+  constexpr int NU = (HALO_PIX * SLOTS + 255) / 256;
+  // (80-byte records: the records of a ds_write_b128 phase are spread over their block of 16 as in conv3x3.h)
+  auto hp_of = [](int r) { return SLOTS == 4 ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r; };
   int src[NU];                                              // pixel index in the image, -1: padding / nothing
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
-    const int hp = spread4((tid >> 2) + 64 * i);
+    const int hp = hp_of(tid / SLOTS + (256 / SLOTS) * i);
     const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     src[i] = (hp < HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (nb * p.H + gy) * p.W + gx : -1;
   }
-  const int slot = tid & 3;
+  const int slot = tid % SLOTS;
   f32x4 r[NU];
   auto load = [&](int c0) {
 #pragma unroll
@@ -61,30 +76,30 @@ __global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
     }
   };
   load(0);
-  for (int c0 = 0; c0 < p.Cin; c0 += 16) {
+  for (int c0 = 0; c0 < p.Cin; c0 += HCH) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      const int hp = spread4((tid >> 2) + 64 * i);
+      const int hp = hp_of(tid / SLOTS + (256 / SLOTS) * i);
       if (hp < HALO_PIX) {
         f32x4 v = r[i];
         if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(hs + hp * REC_BYTES + slot * 16) = v;
+        *reinterpret_cast<f32x4*>(hs + hp * HREC + slot * 16) = v;
       }
     }
     __syncthreads();
-    if (c0 + 16 < p.Cin) load(c0 + 16);                     // the next chunk's loads fly under this chunk's FMAs
+    if (c0 + HCH < p.Cin) load(c0 + HCH);                   // the next chunk's loads fly under this chunk's FMAs
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-      const char* rec = hs + ((py + tap / 3) * HALO_W + px + tap % 3) * REC_BYTES;
-      const float* wt = p.w + ((size_t)tap * p.Cin + c0) * 8;            // uniform: scalar loads
+      const char* rec = hs + ((py + tap / 3) * HALO_W + px + tap % 3) * HREC;
+      const float* wt = p.w + ((size_t)tap * p.Cin + c0) * (2 * NPAIR);  // uniform: scalar loads
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < SLOTS; ++q) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(rec + q * 16);
         const f2 xlo = {x.x, x.y}, xhi = {x.z, x.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float* we = wt + (4 * q + e) * 8;
+          const float* we = wt + (4 * q + e) * (2 * NPAIR);
 #pragma unroll
           for (int k = 0; k < NPAIR; ++k) {
             const f2 wp = {we[2 * k], we[2 * k + 1]};
