@@ -175,13 +175,15 @@ inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
          precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W;
 }
-// FISR_PREC_MIXED: which layers keep a split-precision arithmetic (f16f8) -- everything that works at the full resolution of
-// level 3 (its first encoder level, its last decoder level, both heads); the rest of the network runs in fp16.
+// FISR_PREC_MIXED: which layers keep a split-precision arithmetic (f16f8) -- everything that works at the full and at
+// the half resolution of level 3 (its first two encoder levels, its last two decoder levels, both heads: 55 % of the
+// FLOPs); the rest of the network runs in fp16.
 // (Measured with the fp64 oracle and fp16 rounding injected layer by layer: all-fp16 shifts the SR channel's PSNR by
-// 0.026 dB on the default weight set, this plan by 0.008 dB, 0.005 / 0.0002 dB on the other two sets.)
+// 0.026 dB on the default weight set, full resolution only in the split format by 0.008 dB -- 0.016 dB on the worst
+// full-size window --, this plan by 0.004 dB.)
 inline bool mixed_layer_is_hi(const std::string& name) {
-  static const char* const hi[] = {"FISRnet/level_3/enc/level_0/", "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/FI-SR/",
-                                   "FISRnet/level_3/SR/"};
+  static const char* const hi[] = {"FISRnet/level_3/enc/level_0/", "FISRnet/level_3/enc/level_1/", "FISRnet/level_3/dec/level_1/",
+                                   "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/FI-SR/", "FISRnet/level_3/SR/"};
   for (const char* h : hi)
     if (name.compare(0, strlen(h), h) == 0) return true;
   return false;
@@ -822,30 +824,23 @@ struct MixedRunner {
     hi.ar = lo.ar;
     THi* x = hi.talloc((size_t)n * h * w * c3);
     hi.prep(in, l2, x, n, h, w, 1, c3);
-    THi* skip0 = nullptr;
-    const THi* pooled = hi.enc_level(P, 0, x, c3, n, h, w, &skip0);
+    THi* skiph[2] = {nullptr, nullptr};
+    const THi* pooled = hi.enc_level(P, 0, x, c3, n, h, w, &skiph[0]);
+    pooled = hi.enc_level(P, 1, pooled, 64, n, h / 2, w / 2, &skiph[1]);
     lo.ar = hi.ar;
-    const size_t px2 = (size_t)n * (h / 2) * (w / 2);
-    _Float16* cur16 = lo.talloc(px2 * 64);
-    convert(lo, pooled, cur16, px2 * 64);
-    _Float16* skip[3] = {nullptr, nullptr, nullptr};
-    const _Float16* cur = cur16;
-    int cc = 64, hh = h / 2, ww = w / 2;
-    for (int l = 1; l < 3; ++l) {
-      cur = lo.enc_level(P, l, cur, cc, n, hh, ww, &skip[l]);
-      cc = Runner<_Float16>::widths()[l]; hh /= 2; ww /= 2;
-    }
-    cur = lo.bottleneck(P, cur, cc, n, hh, ww);
-    cc = 512;
-    for (int l = 2; l >= 1; --l) {
-      cur = lo.dec_level(P, l, cur, cc, skip[l], n, hh, ww);
-      cc = Runner<_Float16>::widths()[l]; hh *= 2; ww *= 2;
-    }
+    const size_t px4 = (size_t)n * (h / 4) * (w / 4);
+    _Float16* cur16 = lo.talloc(px4 * 128);
+    convert(lo, pooled, cur16, px4 * 128);
+    _Float16* skip2 = nullptr;
+    const _Float16* cur = lo.enc_level(P, 2, cur16, 128, n, h / 4, w / 4, &skip2);
+    cur = lo.bottleneck(P, cur, 256, n, h / 8, w / 8);
+    cur = lo.dec_level(P, 2, cur, 512, skip2, n, h / 8, w / 8);          // -> 256 channels at h/4 x w/4
     if (lo.rc) return lo.rc;
     hi.ar = lo.ar;
-    THi* curb = hi.talloc(px2 * 128);
-    convert(hi, cur, curb, px2 * 128);
-    const THi* top = hi.dec_level(P, 0, curb, 128, skip0, n, hh, ww);
+    THi* curb = hi.talloc(px4 * 256);
+    convert(hi, cur, curb, px4 * 256);
+    const THi* top = hi.dec_level(P, 1, curb, 256, skiph[1], n, h / 4, w / 4);   // -> 128 channels at h/2 x w/2
+    top = hi.dec_level(P, 0, top, 128, skiph[0], n, h / 2, w / 2);
     hi.heads(P, top, n, h, w, l3);
     lo.ar = hi.ar;
     return hi.rc;

@@ -56,10 +56,11 @@ enum {
                          (3/6-channel heads) use the direct kernel.  Results differ from FISR_PREC_F32 by fp32
                          rounding only (different summation order). */
   FISR_PREC_MIXED = 5, /* engine only (fisr_finalize_weights; not an op-level precision): FISR_PREC_F16 everywhere
-                          except at the full resolution of level 3 -- its first encoder level, its last decoder level
-                          and both heads --, which keep a split format (FISR_PREC_F16F8).  The activation format changes twice, on
-                          quarter-size tensors.  PSNR shift of the SR channel against the fp64 oracle <= 0.01 dB on
-                          the three weight sets of tests/ (all-fp16: 0.026 dB, outside north_star's +-0.02 dB). */
+                          except at the full and the half resolution of level 3 -- its first two encoder levels, its last
+                          two decoder levels and both heads --, which keep a split format (FISR_PREC_F16F8).  The
+                          activation format changes twice, on 1/16-size tensors.  PSNR shift of the SR channel against
+                          the fp64 oracle <= 0.005 dB on the three weight sets of tests/, 0.007 dB on the worst of 30
+                          full-size windows (all-fp16: 0.026 dB, outside north_star's +-0.02 dB). */
   FISR_PREC_F16F8 = 3  /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels
                           16 x fp16 h (32 B), 16 x fp8-e4m3 l8 (16 B), 16 x fp8-e4m3 copy of h (16 B).
                           Product = a_h*w_h (v_mfma_f32_32x32x16_f16) + both cross terms in ONE

@@ -575,8 +575,8 @@ def test_forward_f16f8_vs_golden(netf8, gold_dir):
 
 
 def test_forward_mixed_precision_vs_golden(dev, syn_weights, gold_dir):
-    """FISR_PREC_MIXED: fp16 everywhere but at the full resolution of level 3 (first encoder level, last decoder level,
-    heads: the f16f8 split format).  Levels 1 and 2 are plain fp16; the level-3 prediction -- the one the reference keeps -- must
+    """FISR_PREC_MIXED: fp16 everywhere but at the full and half resolution of level 3 (first two encoder levels, last
+    two decoder levels, heads: the f16f8 split format).  Levels 1 and 2 are plain fp16; the level-3 prediction -- the one the reference keeps -- must
     sit inside +-0.02 dB with margin on every channel group (all-fp16: 0.026 dB on the SR channel, the next test), and
     the engine must be bit-identical over batch sizes like the others."""
     net = FISRnet(device="cuda:0", precision="mixed")
@@ -598,7 +598,7 @@ def test_forward_mixed_precision_vs_golden(dev, syn_weights, gold_dir):
             ref = g96["l3"][s_].astype(np.float64)
             d = _psnr_protocol(hip, ref, rng)
             print(f"mixed window {s_}: rms {np.sqrt(np.mean((hip - ref) ** 2)):.3e} max {np.abs(hip - ref).max():.3e} dPSNR {d}")
-            assert max(d) <= 0.012, d
+            assert max(d) <= 0.008, d
             q_h, q_r = O.quantize_u8(np.clip(hip, 0, 1)), O.quantize_u8(np.clip(ref, 0, 1))
             for f in range(3):
                 assert abs(O.ssim_pil(q_h[..., 3 * f:3 * f + 3], q_r[..., 3 * f:3 * f + 3]) - 1.0) <= 1e-3
