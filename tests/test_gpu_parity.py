@@ -705,6 +705,42 @@ def test_pack_unpack_stitch_bit_exact(net32, gold_dir):
     assert abs(sse - exp_sse) <= 1e-9 * exp_sse
 
 
+@pytest.mark.parametrize("h,w", [(33, 47), (17, 300), (64, 96), (1, 5)])
+def test_pack_unpack_prep_ragged_sizes_bit_exact(net32, h, w):
+    """The LDS-staged glue kernels (a block moves a 256-pixel span with aligned 16-byte vectors) on sizes whose spans end
+    mid-block, whose byte totals are not multiples of 16 and whose crops sit inside larger frames: pack_input and
+    unpack_output bit-exact against the oracle, stitch against numpy slicing."""
+    rng = np.random.default_rng(1000 * h + w)
+    h0, w0 = h + 7, w + 13
+    frames = [rng.integers(0, 256, (h0, w0, 3)).astype(np.uint8) for _ in range(3)]
+    flows = [(rng.standard_normal((h0, w0, 2)) * 60).astype(np.float32) for _ in range(4)]
+    warps = [(rng.random((h0, w0, 3)) * 300 - 20).astype(np.float32) for _ in range(4)]
+    got = net32.pack_input([torch.from_numpy(f).cuda() for f in frames], [torch.from_numpy(f).cuda() for f in flows],
+                           [torch.from_numpy(f).cuda() for f in warps], h, w).cpu().numpy()
+    img9 = np.concatenate(frames, axis=2)[:h, :w]
+    fl8 = np.concatenate(flows, axis=2)[:h, :w]
+    wp12 = (np.concatenate(warps, axis=2) / np.float32(255.))[:h, :w]
+    exp = O.assemble_input(img9, fl8, wp12)
+    assert got.shape == (1, h, w, 29) and np.array_equal(got, exp.astype(np.float32))
+    pred = (rng.random((2 * h, 2 * w, 9)) * 1.4 - 0.2).astype(np.float32)
+    yuv, rgb = net32.unpack_output(torch.from_numpy(pred).cuda())
+    q = O.quantize_u8(np.clip(pred.astype(np.float64), 0, 1))
+    assert np.array_equal(yuv.cpu().numpy(), q)
+    for f in range(3):
+        assert np.array_equal(rgb[f].cpu().numpy(), O.yuv_u8_to_rgb_u8(q[..., 3 * f:3 * f + 3])), f
+    # stitch: an odd-sized, odd-offset crop (the scalar path) and a 4-pixel-aligned one (the vector path)
+    L = flib.lib()
+    tile = torch.from_numpy(rng.random((40, 52, 9)).astype(np.float32)).cuda()
+    for (sy, sx, ch, cw, dy, dx) in ((3, 5, 21, 33, 2, 7), (4, 8, 24, 36, 8, 12)):
+        full = torch.zeros((48, 64, 9), device="cuda")
+        flib.check(L.fisr_stitch(ctypes.c_void_p(tile.data_ptr()), 40, 52, sy, sx, ch, cw, ctypes.c_void_p(full.data_ptr()),
+                                 48, 64, dy, dx, _stream()))
+        torch.cuda.synchronize()
+        ref = np.zeros((48, 64, 9), np.float32)
+        ref[dy:dy + ch, dx:dx + cw] = tile.cpu().numpy()[sy:sy + ch, sx:sx + cw]
+        assert np.array_equal(full.cpu().numpy(), ref)
+
+
 def test_tiled_forward_vs_oracle(net32, syn_blob):
     """FISRnet.py:845-883 tile loop (2x2 patches, 32-px halo, trim, stitch) on a 128x192 frame."""
     rng = np.random.default_rng(14)
