@@ -164,6 +164,8 @@ int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, 
  * c0 (and c1) must be multiples of 16 (f32, bf16x3, f16f8) / 32 (f16) channels; w_host [3,3,c0+c1,cout]
  * and b_host [cout] are HOST float32.  With FISR_CONV_D2S, cout % 4 == 0 and out is
  * [n,2h,2w,cout/4].  out_f32 != 0 stores float32 regardless of precision.
+ * One output image (h * w * cout elements of the activation type) must stay below 4 GB: the kernels address it with
+ * 32-bit byte offsets (FISR_EHIP otherwise; the 2x2 tiles of a 1080p frame are 0.55 GB at most).
  * Synchronous (packs and uploads the weights on every call). */
 int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host,
                     const float* b_host, int cout, const void* res, void* out, int n, int h,
