@@ -115,11 +115,15 @@ class Workload:
     def _step_frame(self, net):
         torch, h, w = self.torch, self.h, self.w
         fr, fl, wp = self.frames, self.flows, self.warps
-        pack = lambda s: self._timed("pack_input", 1, lambda: net.pack_input(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w))
+        pack = lambda s, out=None: self._timed("pack_input", 1, lambda: net.pack_input(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w, out=out))
         if self.batch == "stack":
-            # the 3 sliding windows (FISRnet.py:799) x 4 tiles (:847) are independent -> one batched forward
-            inp = torch.cat([pack(s) for s in range(3)], dim=0)
-            net.forward_tiled(inp, self.patch, full=self.full)
+            # the 3 sliding windows (FISRnet.py:799) x 4 tiles (:847) are independent -> one batched forward; every
+            # window is packed straight into its slot of the batch
+            if getattr(self, "inp3", None) is None:
+                self.inp3 = torch.empty((3, h, w, 29), dtype=torch.float32, device=self.dev)
+            for s in range(3):
+                pack(s, self.inp3[s:s + 1])
+            net.forward_tiled(self.inp3, self.patch, full=self.full)
         else:
             for s in range(3):
                 net.forward_tiled(pack(s), self.patch, full=self.full[s:s + 1], batch_tiles=(self.batch == "window"))

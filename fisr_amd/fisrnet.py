@@ -239,9 +239,10 @@ class FISRnet:
         _lib.check(self._L.fisr_warp(_ptr(src), _ptr(fl), flow_scale, h, w, int(quantized), _ptr(dst), _stream(self.device)))
         return dst
 
-    def pack_input(self, frames_u8: Sequence, flows: Sequence, warps: Sequence, h: int, w: int):
+    def pack_input(self, frames_u8: Sequence, flows: Sequence, warps: Sequence, h: int, w: int, out=None):
         """FISRnet.py:828-843: 3 uint8 YUV frames [h0,w0,3], 4 flows [h0,w0,2] (px), 4 warped frames
-        [h0,w0,3] (0..255 float32) -> [1,h,w,29] float32 (top-left crop to h x w)."""
+        [h0,w0,3] (0..255 float32) -> [1,h,w,29] float32 (top-left crop to h x w).  `out`: an existing contiguous
+        float32 [1,h,w,29] (or [h,w,29]) device tensor to fill instead of a new one (e.g. one window of a batch)."""
         torch = _torch()
         fr = [f.to(device=self.device, dtype=torch.uint8).contiguous() for f in frames_u8]
         fl = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in flows]
@@ -249,7 +250,11 @@ class FISRnet:
         if len(fr) != 3 or len(fl) != 4 or len(wp) != 4:
             raise ValueError("pack_input needs 3 frames, 4 flows, 4 warps")
         fr, fl, wp, h0, w0 = fit_pack_inputs(fr, fl, wp, h, w)
-        out = torch.empty((1, h, w, 29), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((1, h, w, 29), dtype=torch.float32, device=self.device)
+        elif (tuple(out.shape[-3:]) != (h, w, 29) or out.numel() != h * w * 29 or out.dtype != torch.float32
+              or not out.is_contiguous() or out.device != self.device):
+            raise ValueError("pack_input: `out` must be a contiguous float32 [1,h,w,29] tensor on the engine's device")
         a = (ctypes.c_void_p * 3)(*[f.data_ptr() for f in fr])
         b = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in fl])
         c = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in wp])
