@@ -48,8 +48,17 @@ FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md (spec; ~6300 achievable with a float4 copy)
 # dense MFMA peak of the instruction class each engine issues (MI355X_MICROARCH.md), TFLOP/s
 PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0, "mixed": 2500.0}
-# matrix-pipe work per algorithmic product (direct 3x3): Winograd F(2x2,3x3) issues 16/36 of the multiplies
-MFMA_PER_PRODUCT = {"fp32": None, "fp32d": 1, "fp32w": None, "fp16": 1, "bf16x3": 3, "f16f8": 2.11, "mixed": None}
+# matrix-pipe FLOPs EXECUTED per algorithmic (direct 3x3 convolution) FLOP, per kernel class: Winograd F(2x2,3x3) issues 16
+# multiplies per 2x2 outputs instead of 36; split bf16 issues 3 MFMAs per product; fp16 + fp8 remainder one fp16 MFMA per tap
+# and one block-scaled fp8 MFMA (twice the fp16 rate per K element, four times the K) per tap pair: 1 + 5/9 * ... = 2.11 units
+def executed_per_algorithmic(kernel_name):
+    if kernel_name.startswith("conv3x3_wino"):
+        return 16.0 / 36.0
+    if "<bf16x3" in kernel_name:
+        return 3.0
+    if "<f16f8" in kernel_name:
+        return 2.11
+    return 1.0
 DTYPE = {"fp32": "f32", "fp32d": "f32", "fp32w": "f32",
          "fp16": "f16 (f32 accumulate)",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
@@ -151,36 +160,6 @@ class Workload:
         return 3 * sum(t.in_h * t.in_w for t in self.tiles) * FLOP_PER_LR_PX
 
 
-def shader_clock_under_load(precision):
-    """MHz the chip actually runs at while the dominant conv kernel executes: s_memtime ticks per 100 MHz
-    s_memrealtime tick, one sample per workgroup of a 64->64 launch at the bench's batch (diagnostic entry
-    fisr_bench_conv with FISR_TRACE_FILE).  Only meaningful for that one layer shape: reported next to the
-    layer it was sampled in, never multiplied into a step-wide figure."""
-    import ctypes
-    import tempfile
-    from fisr_amd import lib as flib
-    from fisr_amd.fisrnet import _PREC
-    pid = _PREC[precision]
-    with tempfile.TemporaryDirectory() as d:
-        path = os.path.join(d, "trace.bin")
-        os.environ["FISR_TRACE_FILE"] = path
-        try:
-            us = ctypes.c_double()
-            rc = flib.lib().fisr_bench_conv(pid, 12, 544, 992, 64, 64, 3, 1, 3, ctypes.byref(us))
-        finally:
-            os.environ.pop("FISR_TRACE_FILE", None)
-        if rc != 0 or not os.path.isfile(path):
-            return None
-        a = np.fromfile(path, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
-    a = a[(a[:, 2] > a[:, 0]) & (a[:, 6] > a[:, 5])]
-    if not len(a):
-        return None
-    mhz = float(np.median((a[:, 2] - a[:, 0]) / (a[:, 6] - a[:, 5]) * 100.0))
-    flops = 2.0 * 9 * 64 * 64 * 12 * 544 * 992
-    return {"layer": "64->64 @12x544x992, relu in/out + residual", "shader_clock_mhz": round(mhz),
-            "us_per_launch": round(us.value, 1), "tflops": round(flops / us.value / 1e6, 1)}
-
-
 def _pmc_table():
     """HBM bytes per launch of every kernel, from the rocprofv3 PMC passes of this same command
     (scripts/gpu_profile.sh -> profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
@@ -192,21 +171,29 @@ def _pmc_table():
         return {}
 
 
-def _pmc_conv_traffic(pmc, name):
+def _pmc_key(name):
+    tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
+    if name.startswith("conv3x3_wino"):
+        return "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
+    if name.startswith("conv3x3_dma"):
+        return f"conv3x3_dma_kernel<{tname}"
+    nt = name.split("NT")[1][0]
+    return f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in name else 'false'}"
+
+
+def _pmc_field(pmc, name, field):
     try:
-        tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
-        if name.startswith("conv3x3_wino"):
-            key = "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false",
-                                                             "false" if "nores" in name else "true")
-        else:
-            nt = name.split("NT")[1][0]
-            key = f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in name else 'false'}"
-        hits = [v for k, v in pmc.items() if k.startswith(key)]
+        hits = [v for k, v in pmc.items() if k.startswith(_pmc_key(name)) and field in v]
         if hits:
-            return round(max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch"] / 1e9, 4)
+            return round(max(hits, key=lambda v: v.get("dispatches", 0))[field], 4)
     except (KeyError, IndexError, ValueError):
         pass
     return None
+
+
+def _pmc_conv_traffic(pmc, name):
+    v = _pmc_field(pmc, name, "hbm_bytes_per_launch")
+    return None if v is None else round(v / 1e9, 4)
 
 
 def roofline_pass(net, wl, precision, reps, layer_profile=None):
@@ -270,24 +257,32 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
         if glue_bytes.get(name):
             add_hbm(name, ms, launches, glue_bytes[name] * launches, name + "_kernel")
     tot_ms = sum(p["ms"] for p in prof)
-    rl = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak,
-          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": _pmc_conv_traffic(pmc, dom["name"]),
-          "traffic_unit": "GB of HBM per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
+    # `achieved` / `frac`: what the matrix pipe EXECUTED (a roofline fraction, <= 1 by construction): the algorithmic
+    # direct-convolution FLOPs of the launch x the kernel's executed-per-algorithmic factor / its average duration.  The
+    # algorithmic rate itself (which exceeds the fp32 peak for the Winograd kernel: it skips 20 of 36 multiplies) is kept
+    # as `algorithmic_tflops` / `algorithmic_over_peak`.
+    epa = executed_per_algorithmic(dom["name"])
+    busy = _pmc_field(pmc, dom["name"], "mfma_busy_frac")
+    rl = {"bound": "mfma", "kernel": dom["name"], "achieved": round(epa * ach, 2), "peak": peak,
+          "unit": "TFLOP/s", "frac": round(epa * ach / peak, 4),
+          "achieved_is": "matrix-pipe FLOPs executed per second = algorithmic FLOPs x executed_per_algorithmic / duration",
+          "executed_per_algorithmic": round(epa, 4),
+          "algorithmic_tflops": round(ach, 2), "algorithmic_over_peak": round(ach / peak, 4),
+          "pmc_mfma_busy_frac": busy,
+          "traffic": _pmc_conv_traffic(pmc, dom["name"]),
+          "traffic_unit": "GB of HBM per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE in separate passes, profiles/pmc_traffic.json)",
           "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": int(dom["launches"]),
           "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
           "algorithmic_gbyte_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
           "share_of_gpu_time": round(dom["ms"] / tot_ms, 4),
-          "all_conv_tflops": round(sum(p["flops"] for p in convs) / (sum(p["ms"] for p in convs) * 1e-3) / 1e12, 2),
-          "kernels": {p["name"]: {"ms": round(p["ms"], 3), "launches": int(p["launches"])} for p in prof},
+          "all_conv_algorithmic_tflops": round(sum(p["flops"] for p in convs) / (sum(p["ms"] for p in convs) * 1e-3) / 1e12, 2),
+          "all_conv_executed_frac": round(sum(p["flops"] * executed_per_algorithmic(p["name"]) for p in convs) /
+                                          (sum(p["ms"] for p in convs) * 1e-3) / 1e12 / peak, 4),
+          "kernels": {p["name"]: {"ms": round(p["ms"], 3), "launches": int(p["launches"]),
+                                  **({"executed_frac": round(executed_per_algorithmic(p["name"]) * p["flops"] / (p["ms"] * 1e-3) / 1e12 / peak, 4),
+                                      "traffic_gb": _pmc_conv_traffic(pmc, p["name"])} if p["name"].startswith("conv3x3") and p["ms"] > 0 else {})}
+                      for p in prof},
           "hbm_bound_kernels": hbm}
-    mpp = MFMA_PER_PRODUCT.get(precision)
-    if dom["name"].startswith("conv3x3_wino"):
-        mpp = 16.0 / 36.0
-        rl["note"] = ("Winograd F(2x2,3x3): `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs, of which "
-                      "the matrix pipe executes 16/36; `mfma_issue_frac` is the fraction of the fp32 MFMA peak "
-                      "actually issued")
-    if mpp:
-        rl["mfma_issue_frac"] = round(mpp * ach / peak, 4)
     return rl
 
 
@@ -582,7 +577,6 @@ def main():
         wl.gather_world = gw
         if roofline is not None and solo:
             roofline["hbm_bound_kernels"]["warp"] = time_warp(net, wl)
-            roofline["clock_sample"] = shader_clock_under_load(args.precision)
 
     parity_oracle = None
     other = {}
@@ -622,9 +616,10 @@ def main():
             rl = None if args.no_roofline else roofline_pass(eng, wl, alt, 1)
             rec = {"value": round(UNIQUE_PER_STACK / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
                    "steps": nrep, "dtype": DTYPE[alt],
-                   "roofline": {k: rl[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
-                                                   "mfma_issue_frac", "avg_launch_us", "launches", "share_of_gpu_time",
-                                                   "all_conv_tflops") if k in rl} if rl else None,
+                   "roofline": {k: rl[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "executed_per_algorithmic",
+                                                   "algorithmic_tflops", "pmc_mfma_busy_frac", "traffic", "avg_launch_us", "launches",
+                                                   "share_of_gpu_time", "all_conv_algorithmic_tflops", "all_conv_executed_frac",
+                                                   "kernels") if k in rl} if rl else None,
                    "parity_vs_" + args.precision: compare(out_alt, out_main, f"{alt} vs the {args.precision} engine"),
                    "parity_vs_oracle": None if args.no_parity else oracle_tile_check(eng, torch)}
             if cfg5 and "flow_ms" in cfg5:   # cfg5 of BASELINE.json names a 16-bit engine: the same flow + warps in front of THIS engine's step

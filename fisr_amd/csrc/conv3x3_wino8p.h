@@ -1,7 +1,7 @@
 // Winograd F(2x2,3x3) fp32 convolution, 8-wave workgroups, PERSISTENT: one workgroup per CU walks a list of
 // (pixel tile, 64-channel block) work items and never lets its copy / transform pipeline drain.
 //
-// conv3x3_wino8.h spends 7.3k cycles of a 60k-cycle 64->64 tile in its prologue (the first HBM round trip and the
+// The one-item-per-workgroup kernel (diag/conv3x3_wino8.h) spends 7.3k cycles of a 60k-cycle 64->64 tile in its prologue (the first HBM round trip and the
 // first input transform) and cannot hide it: one 64 wtile x 64 channel x 16 position accumulator set is half the CU's
 // register file, so no second workgroup fits beside it.  Here the three streams of the K loop simply continue into
 // the NEXT work item of the same workgroup:
@@ -12,11 +12,10 @@
 // first item of a workgroup pays a prologue.  The epilogue of an item (output transform + stores) runs while those
 // copies are in flight; the row exchange between the two waves of a pair uses the V/U buffers the last chunk has just
 // released (64 KB: the column stage of the output transform is done BEFORE the exchange, which halves it).
-// Everything else -- LDS layout, host-made weight slabs, MFMA mapping, hidden LDS-DMA with counted waits, quad-transposed
-// stores -- is conv3x3_wino8.h's.  Needs Cin >= 32 (at least 4 chunks, so the copy stream never runs more than one work
-// item ahead); the launcher falls back to conv3x3_wino8_kernel otherwise.
+// LDS layout, host-made weight slabs and the LDS-DMA macros: conv3x3_wino_common.h.  Needs Cin >= 32 (at least 4 chunks,
+// so the copy stream never runs more than one work item ahead); layers below that run on the direct kernel (conv3x3.h).
 #pragma once
-#include "conv3x3_wino8.h"
+#include "conv3x3_wino_common.h"
 
 namespace fisr {
 

@@ -1,6 +1,7 @@
-// Winograd F(2x2,3x3) fp32 convolution, 8-wave workgroups (two waves per SIMD).
+// Winograd F(2x2,3x3) fp32 convolution, 8-wave workgroups (two waves per SIMD), ONE work item per workgroup: the
+// predecessor of conv3x3_wino8p.h, kept for A/B runs and compiled into -DFISR_DIAG builds only.
 //
-// Same algorithm, LDS layout, host-made weight slabs and LDS-DMA pipeline as conv3x3_wino.h; what changes is who
+// Same algorithm, LDS layout, host-made weight slabs and LDS-DMA pipeline as diag/conv3x3_wino4.h; what changes is who
 // holds the accumulators.  Measured on MI355X (r02, per-workgroup s_memtime traces + ablation builds): with ONE
 // wave per SIMD nothing overlaps with the fp32 MFMAs of that wave -- every s_waitcnt, every VALU instruction of the
 // input transform and every copy set-up is added to the 64 x 64 cycles of MFMA per chunk (6.7k instead of 4.1k
@@ -21,7 +22,7 @@
 // are free by then): the ph = 0 wave receives m2 and finishes output row 0, the ph = 1 wave receives m1 and
 // finishes row 1.
 #pragma once
-#include "conv3x3_wino.h"
+#include "../conv3x3_wino_common.h"
 
 namespace fisr {
 

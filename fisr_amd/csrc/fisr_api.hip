@@ -17,8 +17,20 @@
 #include <vector>
 
 #include "../../include/fisr.h"
+// FISR_DIAG builds (scripts/gpu_*.sh, lib.build(diag=True) -> build_ab/libfisr_hip_diag.so) add what the shipped library
+// must not have: environment switches that change which kernel runs (FISR_WINO_VARIANT, FISR_CONV_MR, FISR_HEAD_VALU,
+// FISR_CONV_HEAD16), the two superseded Winograd kernels, the compile-time ablations (-DFISR_ABL / -DFISR_WABL) and the
+// per-workgroup timeline trace of fisr_diag_bench_conv.  The shipped .so reads no environment variable at all.
+#ifndef FISR_DIAG
+#undef FISR_ABL
+#undef FISR_WABL
+#endif
 #include "conv3x3.h"
 #include "conv3x3_wino8p.h"
+#ifdef FISR_DIAG
+#include "diag/conv3x3_wino4.h"
+#include "diag/conv3x3_wino8.h"
+#endif
 #include "head_conv.h"
 #include "glue_kernels.h"
 
@@ -37,7 +49,7 @@ struct ConvW {
   float* d_b = nullptr;
   int cin_pad = 0, cout_pad = 0, nt = 2;
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
-  void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino.h), else NULL
+  void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino_common.h), else NULL
   float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][4 | 6] for the vector-ALU head kernel (head_conv.h), else NULL
   int prec = -1;          // the precision the device copies are packed for (differs per layer in FISR_PREC_MIXED)
 };
@@ -269,7 +281,7 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
 }
 
 // Winograd F(2x2,3x3) weights: U = G g G^T per (ci, co), computed in double and rounded once to fp32, stored as
-// the kernel's LDS image (conv3x3_wino.h): [Cin/8][Cout/64][position 16][row 64][32-byte record], the two 16-byte
+// the kernel's LDS image (conv3x3_wino_common.h): [Cin/8][Cout/64][position 16][row 64][32-byte record], the two 16-byte
 // halves of a record swapped when bit 3 of the row is set; rows in the MFMA row order of pack_weights.
 inline bool wino_eligible(int ci, int co) { (void)ci; return co >= W_BN && co % W_BN == 0; }
 // the kernel addresses its input tensors, and one image of its output, with 32-bit byte offsets
@@ -304,9 +316,13 @@ void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<
 }
 
 // N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16,
-// always fp32 output; FISR_CONV_HEAD16=0 turns it off for A/B runs).
+// always fp32 output; FISR_DIAG builds: FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
+#ifdef FISR_DIAG
   static const bool head16 = [] { const char* e = getenv("FISR_CONV_HEAD16"); return !(e && e[0] == '0'); }();
+#else
+  constexpr bool head16 = true;
+#endif
   if (co < 16 && head16) return 0;
   return co <= 32 ? 1 : 2;
 }
@@ -358,10 +374,13 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false) {
 
 // Rows per wave of the conv kernel: 1 = 512-thread workgroups, 2 = 256-thread.  Measured on
 // MI355X (r01): equal within 2 %; fp32 is marginally faster with 1, the 16-bit modes with 2.
-// FISR_CONV_MR=1|2 in the environment forces one build for A/B runs.
+// (FISR_DIAG builds: FISR_CONV_MR=1|2 in the environment forces one for A/B runs.)
 template <typename T> inline int conv_mr() {
+#ifdef FISR_DIAG
   static int forced = [] { const char* e = getenv("FISR_CONV_MR"); return e ? (e[0] == '2' ? 2 : 1) : 0; }();
-  return forced ? forced : (std::is_same<T, float>::value ? 1 : 2);
+  if (forced) return forced;
+#endif
+  return std::is_same<T, float>::value ? 1 : 2;
 }
 
 template <typename T, int NT, bool OUT_F32, int MR>
@@ -385,11 +404,15 @@ hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// The 3 / 6-channel heads of the fp32 engine on the vector ALU (head_conv.h); FISR_HEAD_VALU=0 keeps them on the 16-row MFMA
-// variant for A/B runs.
+// The 3 / 6-channel heads of the fp32 engine on the vector ALU (head_conv.h); FISR_DIAG builds: FISR_HEAD_VALU=0 keeps them
+// on the 16-row MFMA variant for A/B runs.
 inline bool head_valu_enabled() {
+#ifdef FISR_DIAG
   static const bool on = [] { const char* e = getenv("FISR_HEAD_VALU"); return !(e && e[0] == '0'); }();
   return on;
+#else
+  return true;
+#endif
 }
 hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st) {
   static bool attr_done[64] = {};
@@ -412,11 +435,11 @@ hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st
   return hipGetLastError();
 }
 
-// Winograd kernels (fp32 only; a.wpk = the conv's d_wu).  Default: the persistent 8-wave kernel (conv3x3_wino8p.h) for
-// Cin >= 32, the one-item-per-workgroup 8-wave kernel (conv3x3_wino8.h) below that; FISR_WINO_VARIANT=8 forces the
-// latter, =4 the 4-wave kernel (conv3x3_wino.h), for A/B runs.
+// The persistent Winograd kernel (conv3x3_wino8p.h; fp32 only; a.wpk = the conv's d_wu).  Needs at least four 8-channel
+// K chunks: wino_chunks_ok() is part of every caller's eligibility test.  FISR_DIAG builds: FISR_WINO_VARIANT=8 / =4 run
+// the two superseded kernels instead (A/B runs).
+inline bool wino_chunks_ok(int c0, int c1) { return (c0 + c1) / W_CH >= 4; }
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
-  static const int variant = [] { const char* e = getenv("FISR_WINO_VARIANT"); return e ? atoi(e) : 0; }();
   static bool attr_done[64] = {};
   static int n_cu[64] = {};
   constexpr size_t lds = wino_lds_bytes();
@@ -424,15 +447,18 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    const void* kerns[9] = {reinterpret_cast<const void*>(conv3x3_wino_kernel),
-                            reinterpret_cast<const void*>(conv3x3_wino8_kernel<false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false, false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false, true>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false, false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false, true>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true, false>),
-                            reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true, true>)};
+    const void* kerns[] = {reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false, false>),
+                           reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, false, true>),
+                           reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false, false>),
+                           reinterpret_cast<const void*>(conv3x3_wino8p_kernel<true, false, true>),
+                           reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true, false>),
+                           reinterpret_cast<const void*>(conv3x3_wino8p_kernel<false, true, true>),
+#ifdef FISR_DIAG
+                           reinterpret_cast<const void*>(conv3x3_wino_kernel),
+                           reinterpret_cast<const void*>(conv3x3_wino8_kernel<false>),
+                           reinterpret_cast<const void*>(conv3x3_wino8_kernel<true>),
+#endif
+    };
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
@@ -445,35 +471,36 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   const int d = a.dil;
   const int tiles = (((a.W + d - 1) / d + TILE_W - 1) / TILE_W) * (((a.H + d - 1) / d + TILE_H - 1) / TILE_H) * d * d * a.N;
   const int items = tiles * (a.CoutPad / W_BN);
-  const int nch = (a.C0 + a.C1) / W_CH;
-  // channel-range input / output, leaky relu and dilation exist in the persistent kernel only
+  // channel-range input / output, leaky relu and dilation: the GENERAL instantiation
   const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 &&
                      a.slope == 0.f && d == 1;
-  if (d < 1 || (d > 1 && a.d2s)) return hipErrorInvalidValue;
-  if (!plain && (variant == 4 || variant == 8 || nch < 4)) return hipErrorInvalidValue;
+  if (d < 1 || (d > 1 && a.d2s) || !wino_chunks_ok(a.C0, a.C1)) return hipErrorInvalidValue;
   // the epilogue addresses one output (and residual) image with 32-bit byte offsets (buffer loads / stores)
   if ((double)a.H * a.W * a.rec_cs * 4.0 >= 4294967296.0 - 64.0) return hipErrorInvalidValue;
-  if (variant == 4) hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(items), dim3(256), lds, st, a);
-  else if (variant == 8 || nch < 4) {
+#ifdef FISR_DIAG
+  static const int variant = [] { const char* e = getenv("FISR_WINO_VARIANT"); return e ? atoi(e) : 0; }();
+  if (plain && variant == 4) { hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(items), dim3(256), lds, st, a); return hipGetLastError(); }
+  if (plain && variant == 8) {
     if (a.relu_in) hipLaunchKernelGGL(conv3x3_wino8_kernel<true>, dim3(items), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(conv3x3_wino8_kernel<false>, dim3(items), dim3(512), lds, st, a);
-  } else {
-    // one workgroup per CU (the kernel needs all of a CU's LDS and half its registers), a multiple of 8 so that the
-    // items of a workgroup stay on one XCD
-    const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
-    const bool res = a.res != nullptr;                 // (its own instantiation: see conv3x3_wino8p.h)
+    return hipGetLastError();
+  }
+#endif
+  // one workgroup per CU (the kernel needs all of a CU's LDS and half its registers), a multiple of 8 so that the
+  // items of a workgroup stay on one XCD
+  const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
+  const bool res = a.res != nullptr;                 // (its own instantiation: see conv3x3_wino8p.h)
 #define FISR_W8P_LAUNCH(RI, GEN)                                                                              \
   do {                                                                                                        \
     if (res) hipLaunchKernelGGL((conv3x3_wino8p_kernel<RI, GEN, true>), dim3(grid), dim3(512), lds, st, a, items);  \
     else hipLaunchKernelGGL((conv3x3_wino8p_kernel<RI, GEN, false>), dim3(grid), dim3(512), lds, st, a, items);     \
   } while (0)
-    if (!plain) {
-      if (a.relu_in) return hipErrorInvalidValue;      // (not instantiated: PWC-Net's activations come out of the producer)
-      FISR_W8P_LAUNCH(false, true);
-    } else if (a.relu_in) FISR_W8P_LAUNCH(true, false);
-    else FISR_W8P_LAUNCH(false, false);
+  if (!plain) {
+    if (a.relu_in) return hipErrorInvalidValue;      // (not instantiated: PWC-Net's activations come out of the producer)
+    FISR_W8P_LAUNCH(false, true);
+  } else if (a.relu_in) FISR_W8P_LAUNCH(true, false);
+  else FISR_W8P_LAUNCH(false, false);
 #undef FISR_W8P_LAUNCH
-  }
   return hipGetLastError();
 }
 
@@ -624,7 +651,7 @@ struct Runner {
     a.out_cstride = cstride ? cstride : cw.co;
     a.out_coff = coff; a.out_split = split; a.out_gap = gap; a.trace = nullptr; a.wexp = cw.wexp;
     const double px = (double)n * h * w;
-    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cw.co);
+    const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     char cls[96];
@@ -868,7 +895,16 @@ size_t ws_bytes_t(fisr_ctx* ctx, int n, int h, int w) {
 
 extern "C" {
 
-const char* fisr_version(void) { return "fisr_hip 0.2 (gfx950)"; }
+// FISR_SRC_HASH: sha256 (first 16 hex digits) over csrc/ + include/fisr.h, passed by the build (fisr_amd/lib.py) so that a
+// bench line or a profile can be tied to the sources of the binary that produced it
+#ifndef FISR_SRC_HASH
+#define FISR_SRC_HASH "unhashed"
+#endif
+#ifdef FISR_DIAG
+const char* fisr_version(void) { return "fisr_hip 0.3 (gfx950) src " FISR_SRC_HASH " DIAG"; }
+#else
+const char* fisr_version(void) { return "fisr_hip 0.3 (gfx950) src " FISR_SRC_HASH; }
+#endif
 
 const char* fisr_last_error(const fisr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -1151,7 +1187,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.b.assign(b_host, b_host + cout);
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_fits(n, h, w, c0, c1, cout);
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cout);
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
@@ -1212,8 +1248,8 @@ int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int
 // Micro-benchmark of one conv shape (not part of the product path): allocates its own buffers,
 // runs `iters` launches back to back on the default stream and returns the mean microseconds per
 // launch (HIP events) in *out_us.  Weights/activations are pseudo-random bit patterns.
-int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters,
-                    double* out_us) {
+static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters,
+                           double* out_us, bool zero_fill, unsigned lomask, const char* trace_file) {
   if (!prec_ok(precision) || !out_us || iters < 1) return fail(nullptr, FISR_EINVAL, "fisr_bench_conv: bad argument");
   const int cc = prec_chunk(precision);
   if (cin % cc || cout % 8) return fail(nullptr, FISR_EINVAL, "fisr_bench_conv: channels must be whole chunks");
@@ -1224,11 +1260,10 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   cw.w.resize((size_t)9 * cin * cout);
   cw.b.assign(cout, 0.01f);
   uint32_t st = 12345u;
-  const bool zero_fill = getenv("FISR_BENCH_ZERO") != nullptr;   // DVFS probe: zero operands draw less power
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
   int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_fits(n, h, w, cin, 0, cout);
+  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
   HIP_OK(nullptr, hipMalloc(&d_out, out_b));
@@ -1236,10 +1271,8 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   {
     std::vector<uint16_t> hbuf(1 << 20);
     for (auto& v : hbuf) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0 : ((uint16_t)(0x3c00 + ((st >> 12) & 0x3ff)) ^ (uint16_t)((st >> 31) << 15)); }
-    if (const char* lm = getenv("FISR_BENCH_LOMASK")) {   // DVFS probe: fewer toggling bits in the lo planes
-      const uint16_t mask = (uint16_t)strtoul(lm, nullptr, 16);
-      for (size_t i = 0; i < hbuf.size(); ++i) if ((i >> 4) & 1) hbuf[i] &= mask;
-    }
+    if (lomask != 0xffffu)   // DVFS probe: fewer toggling bits in the lo planes
+      for (size_t i = 0; i < hbuf.size(); ++i) if ((i >> 4) & 1) hbuf[i] &= (uint16_t)lomask;
     for (size_t o = 0; o < in_b; o += hbuf.size() * 2)
       HIP_OK(nullptr, hipMemcpy((char*)d_in + o, hbuf.data(), std::min(hbuf.size() * 2, in_b - o), hipMemcpyHostToDevice));
     if (d_res)
@@ -1255,7 +1288,6 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
-  const char* trace_file = getenv("FISR_TRACE_FILE");
   unsigned long long* d_trace = nullptr;
   const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
                          (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
@@ -1293,6 +1325,19 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
   return 0;
 }
+
+int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters, double* out_us) {
+  return bench_conv_impl(precision, n, h, w, cin, cout, flags, with_res, iters, out_us, false, 0xffffu, nullptr);
+}
+
+#ifdef FISR_DIAG
+// FISR_DIAG builds only: the micro-benchmark with zero-filled operands / masked lo planes (DVFS probes: zero operands draw
+// less power) and a per-workgroup {start, main-loop end, end, HW_ID, ...} timeline written to trace_file (scripts/trace_conv.py)
+int fisr_diag_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters, double* out_us,
+                         int zero_fill, unsigned lomask, const char* trace_file) {
+  return bench_conv_impl(precision, n, h, w, cin, cout, flags, with_res, iters, out_us, zero_fill != 0, lomask, trace_file);
+}
+#endif
 
 }  // extern "C"
 

@@ -167,6 +167,20 @@ int pwc_pack_deconv(fisr_pwc* ctx, const std::string& name, const std::vector<in
   return 0;
 }
 
+hipError_t launch_costvol(const float* c1, const float* c2, int C, float* out, int out_cs, int out_co, int n, int h, int w, hipStream_t st) {
+  static bool cv_attr[64] = {};
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !cv_attr[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_costvol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)costvol_lds_bytes());
+    if (e != hipSuccess) return e;
+    cv_attr[dev] = true;
+  }
+  const int cv_tiles = ((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n;
+  hipLaunchKernelGGL(pwc_costvol_kernel, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, c2, C, out, out_cs, out_co, n, h, w);
+  return hipGetLastError();
+}
+
 std::vector<int> iota_map(int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; }
 
 struct PwcRunner {
@@ -177,13 +191,21 @@ struct PwcRunner {
     if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string(what) + ": " + hipGetErrorString(e));
   }
   void zero(float* p, size_t n) { if (!ar.dry && !rc) (void)hipMemsetAsync(p, 0, n * sizeof(float), st); }
+  // which kernel runs a layer: 2 = FISRnet's persistent Winograd kernel (stride 1, Cout >= 32, any dilation), 3 = FISRnet's
+  // direct kernel (stride 1, dilation 1, Cout < 32), 1 = the generic implicit GEMM (stride 2, the residual dc_conv7)
+  int conv_route(const std::string& name, int n, int h, int w, int in_cs, int out_cs, int stride, int dil, float slope, bool has_add) {
+    const PwcConv& pc = ctx->convs[name];
+    const bool act_ok = slope == 1.f || (slope > 0.f && slope < 1.f);
+    if (pc.d_wu && stride == 1 && !has_add && act_ok && wino_fits(n, h, w, in_cs, 0, out_cs)) return 2;
+    if (pc.have_dw && stride == 1 && dil == 1 && !has_add && act_ok) return 3;
+    return 1;
+  }
   void conv(const std::string& name, const float* in, int in_cs, int in_co, float* out, int out_cs, int out_co,
             int n, int h, int w, int stride, int dil, float slope, const float* add = nullptr, int add_cs = 0, int add_co = 0) {
     if (rc || ar.dry) return;
     const PwcConv& pc = ctx->convs[name];
-    static const bool no_wino = [] { const char* e = getenv("FISR_PWC_WINO"); return e && e[0] == '0'; }();
-    if (pc.d_wu && !no_wino && stride == 1 && !add && (slope == 1.f || (slope > 0.f && slope < 1.f)) &&
-        wino_fits(n, h, w, in_cs, 0, out_cs)) {
+    const int route = conv_route(name, n, h, w, in_cs, out_cs, stride, dil, slope, add != nullptr);
+    if (route == 2) {
       // FISRnet's persistent Winograd kernel on a channel range of the buffer (fisr_api.hip: launch_conv_wino)
       ConvArgs a;
       a.in0 = in + in_co; a.in1 = nullptr; a.wpk = pc.d_wu; a.bias = pc.d_b; a.res = nullptr; a.out = out;
@@ -196,7 +218,7 @@ struct PwcRunner {
       if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (winograd): " + hipGetErrorString(e));
       return;
     }
-    if (pc.have_dw && !no_wino && stride == 1 && dil == 1 && !add && (slope == 1.f || (slope > 0.f && slope < 1.f))) {
+    if (route == 3) {
       ConvArgs a;
       a.in0 = in + in_co; a.in1 = nullptr; a.wpk = pc.dw.d_w; a.bias = pc.dw.d_b; a.res = nullptr; a.out = out;
       a.C0 = pc.dw.cin_pad; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = pc.cout; a.CoutPad = pc.dw.cout_pad;
@@ -281,17 +303,8 @@ struct PwcRunner {
           cv2 = Wp;
         }
         if (!rc && !ar.dry) {
-          static bool cv_attr[64] = {};
-          int dev = 0; (void)hipGetDevice(&dev);
-          if (dev >= 0 && dev < 64 && !cv_attr[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_costvol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)costvol_lds_bytes());
-            cv_attr[dev] = true;
-          }
-          const int cv_tiles = ((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H);
-          hipLaunchKernelGGL(pwc_costvol_kernel, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, cv2, PWC_CH[l], D, L.total,
-                             L.off_corr, 1, h, w);                   // :1277 (leaky relu inside core_costvol)
-          check("cost volume");
+          hipError_t e = launch_costvol(c1, cv2, PWC_CH[l], D, L.total, L.off_corr, 1, h, w, st);   // :1277 (leaky relu inside core_costvol)
+          if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string("cost volume: ") + hipGetErrorString(e));
         }
         for (int i = 0; i < 5; ++i)                                  // predict_flow :1426-1445 (dense connections)
           conv("pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i), D, L.total, i == 0 ? L.off_corr : L.off_act[i - 1],
@@ -482,6 +495,96 @@ int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, 
     hipLaunchKernelGGL(pwc_flow_out_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, r.st, f2[d], 4, 0, H / 4, W / 4, outs[d], h, w);
     HIP_OK(nullptr, hipGetLastError());
   }
+  return 0;
+}
+
+// ---- op-level entries (parity tests of the flow network's kernels at the sizes the bench runs them at) ----
+// One tf.layers.conv2d 3x3 'same' (+ bias, leaky relu, optional add) exactly as the network launches it: the input is the
+// channel range [in_co, in_co + cin_buf) of a buffer with pixel stride in_cs, the output the range [out_co, out_co + cout)
+// of a buffer with pixel stride out_cs.  w_host: TF HWIO [3,3,ci,cout]; chmap (nullable = identity, then ci == cin_buf):
+// buffer channel, relative to in_co, of TF input channel j (the dense blocks' padded channel groups).  route 0: the
+// network's own choice (persistent Winograd kernel / FISRnet's direct kernel / generic implicit GEMM), 1: generic, 2:
+// Winograd or error, 3: direct or error.  Returns the route taken (1, 2, 3) or a negative error.
+int fisr_pwc_op_conv(const float* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
+                     const int* chmap, float* out, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
+                     int stride, int dil, float slope, int route, void* stream) {
+  if (!in || !w_host || !b_host || !out || ci < 1 || cout < 1 || cin_buf < ci || n < 1 || h < 1 || w < 1 || stride < 1 || stride > 2 || dil < 1)
+    return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: bad argument");
+  if ((in_cs | in_co | out_cs | out_co | cin_buf) & 3) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: channel strides / offsets / cin_buf must be multiples of 4");
+  fisr_pwc tmp;
+  tmp.dev = device_of(out);
+  DeviceGuard guard(tmp.dev);
+  HIP_OK(nullptr, guard.err);
+  PwcVar& kw = tmp.vars["op/kernel"]; PwcVar& kb = tmp.vars["op/bias"];
+  kw.shape = {3, 3, ci, cout}; kw.v.assign(w_host, w_host + (size_t)9 * ci * cout);
+  kb.shape = {cout}; kb.v.assign(b_host, b_host + cout);
+  std::vector<int> m = chmap ? std::vector<int>(chmap, chmap + ci) : iota_map(ci);
+  for (int c : m) if (c < 0 || c >= cin_buf) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: chmap entry out of range");
+  PwcConv& pc = tmp.convs["op"];
+  int rc = pwc_pack_conv(&tmp, "op", m, cin_buf, pc, route != 1);
+  auto release = [&]() {
+    if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu);
+    if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
+  };
+  if (rc) { release(); return rc; }
+  PwcRunner r; r.ctx = &tmp; r.st = (hipStream_t)stream;
+  const int took = r.conv_route("op", n, h, w, in_cs, out_cs, stride, dil, slope, add != nullptr);
+  if ((route == 2 || route == 3) && took != route) { release(); return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: the requested kernel does not take this layer"); }
+  r.conv("op", in, in_cs, in_co, out, out_cs, out_co, n, h, w, stride, dil, slope, add, add_cs, add_co);
+  hipError_t e = hipStreamSynchronize(r.st);
+  release();
+  if (r.rc) return r.rc;
+  if (e != hipSuccess) return pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_conv: ") + hipGetErrorString(e));
+  return took;
+}
+
+// tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (model_pwcnet.py:1196): in = range [in_co, in_co + cin4) of a buffer with pixel
+// stride in_cs, [n,h,w]; w_host TF layout [4,4,2,ci]; chmap as above; out channels [out_co, out_co + 2) of [n,2h,2w] x out_cs.
+int fisr_pwc_op_deconv(const float* in, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci, const int* chmap,
+                       float* out, int out_cs, int out_co, int n, int h, int w, void* stream) {
+  if (!in || !w_host || !b_host || !out || ci < 1 || cin4 < ci || (cin4 & 3) || (in_cs & 3) || (in_co & 3) || n < 1 || h < 1 || w < 1)
+    return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_deconv: bad argument");
+  fisr_pwc tmp;
+  tmp.dev = device_of(out);
+  DeviceGuard guard(tmp.dev);
+  HIP_OK(nullptr, guard.err);
+  PwcVar& kw = tmp.vars["op/kernel"]; PwcVar& kb = tmp.vars["op/bias"];
+  kw.shape = {4, 4, 2, ci}; kw.v.assign(w_host, w_host + (size_t)32 * ci);
+  kb.shape = {2}; kb.v.assign(b_host, b_host + 2);
+  std::vector<int> m = chmap ? std::vector<int>(chmap, chmap + ci) : iota_map(ci);
+  for (int c : m) if (c < 0 || c >= cin4) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_deconv: chmap entry out of range");
+  PwcDeconv& pd = tmp.deconvs["op"];
+  int rc = pwc_pack_deconv(&tmp, "op", m, cin4, pd);
+  if (!rc) {
+    PwcRunner r; r.ctx = &tmp; r.st = (hipStream_t)stream;
+    r.deconv("op", in, in_cs, in_co, out, out_cs, out_co, n, h, w);
+    hipError_t e = hipStreamSynchronize(r.st);
+    rc = r.rc ? r.rc : (e != hipSuccess ? pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_deconv: ") + hipGetErrorString(e)) : 0);
+  }
+  if (pd.d_w) (void)hipFree(pd.d_w); if (pd.d_b) (void)hipFree(pd.d_b);
+  return rc;
+}
+
+// core_costvol.cost_volume + leaky relu (model_pwcnet.py:1277): c1, c2 dense [n,h,w,c] (c % 4 == 0) -> 81 channels at out_co of a
+// buffer with pixel stride out_cs
+int fisr_pwc_op_costvol(const float* c1, const float* c2, int c, float* out, int out_cs, int out_co, int n, int h, int w, void* stream) {
+  if (!c1 || !c2 || !out || c < 4 || (c & 3) || (out_cs & 3) || (out_co & 3) || n < 1 || h < 1 || w < 1)
+    return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_costvol: bad argument");
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
+  hipError_t e = launch_costvol(c1, c2, c, out, out_cs, out_co, n, h, w, (hipStream_t)stream);
+  if (e != hipSuccess) return pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_costvol: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// core_warp.dense_image_warp (model_pwcnet.py:1178): img dense [n,h,w,c] sampled at (x + scale*u, y + scale*v), (u, v) = channels
+// f_co, f_co + 1 of a buffer with pixel stride f_cs -> out dense [n,h,w,c]
+int fisr_pwc_op_warp(const float* img, int c, const float* flow, int f_cs, int f_co, float scale, float* out, int n, int h, int w, void* stream) {
+  if (!img || !flow || !out || c < 4 || (c & 3) || n < 1 || h < 2 || w < 2) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_warp: bad argument");
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
+  hipLaunchKernelGGL(pwc_warp_kernel, dim3(grid_for((size_t)n * h * w * c / 4)), dim3(256), 0, (hipStream_t)stream, img, c, flow, f_cs, f_co, scale, out, n, h, w);
+  HIP_OK(nullptr, hipGetLastError());
   return 0;
 }
 

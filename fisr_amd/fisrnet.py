@@ -326,7 +326,7 @@ class FISRnet:
                 t0 = time.time()
             try:
                 _, _, pred = self.model(simg, sf, want_all=False)
-            except torch.OutOfMemoryError:
+            except getattr(torch, "OutOfMemoryError", torch.cuda.OutOfMemoryError):   # (torch < 2.5 has only the cuda one)
                 if len(grp) == 1:
                     raise
                 # workspace of the batched group does not fit: run its tiles one by one instead

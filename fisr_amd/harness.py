@@ -81,6 +81,12 @@ def warp_img(net, frame_paths, flow, out_path=None):
     return pred
 
 
+def flow_file_name(args):
+    """`<folder>/<folder name>_test_ss1_fr<frame_num>.flo` (flow script :143-144)."""
+    folder = args.frame_folder_path.rstrip("/")
+    return os.path.join(folder, os.path.basename(folder) + "_test_ss{}_fr{}.flo".format(1, args.frame_num))
+
+
 def compute_flow(net, args):
     """`FISR_for_video_Compute_Flow(args)` (FISR_tfoptflow/FISR_for_video_pwcnet_predict_from_img_test.py:84-147) on the
     GPU: the first frame_num YUV frames of the folder, PWC-Net-large in both directions per consecutive pair, written
@@ -108,9 +114,10 @@ def compute_flow(net, args):
     finally:
         pwc.close()
     print(pred.shape)
-    folder = args.frame_folder_path.rstrip("/")
-    name = os.path.join(folder, os.path.basename(folder) + "_test_ss{}_fr{}.flo".format(1, num_fr))
-    fio.write_flow(pred, name)
+    name = flow_file_name(args)
+    tmp = name + ".tmp%d" % os.getpid()
+    fio.write_flow(pred, tmp)
+    os.replace(tmp, name)                      # atomic: a concurrent reader sees the old file or the whole new one
     return name
 
 

@@ -30,6 +30,7 @@ EXPORTS = [
     "fisr_pwc_create", "fisr_pwc_destroy", "fisr_pwc_last_error", "fisr_pwc_num_variables", "fisr_pwc_variable",
     "fisr_pwc_set_weight", "fisr_pwc_finalize", "fisr_pwc_flow_workspace_bytes", "fisr_pwc_flow_pair",
     "fisr_pwc_nn_workspace_bytes", "fisr_pwc_nn", "fisr_pwc_prep", "fisr_pwc_flow_out",
+    "fisr_pwc_op_conv", "fisr_pwc_op_deconv", "fisr_pwc_op_costvol", "fisr_pwc_op_warp",
     "fisr_train_packed_bytes", "fisr_train_pack", "fisr_train_wino_bytes", "fisr_train_pack_wino", "fisr_train_conv3x3", "fisr_train_wgrad", "fisr_train_bgrad",
     "fisr_train_relu_bwd", "fisr_train_axpy", "fisr_train_maxpool2_bwd", "fisr_train_upsample2_bwd", "fisr_train_s2d",
     "fisr_train_copy_channels", "fisr_train_loss", "fisr_train_adam",
@@ -49,7 +50,21 @@ def hipcc_path() -> str:
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(_ROOT, "include", "fisr.h")]
+    out = []
+    for d, _, files in sorted(os.walk(CSRC)):
+        out += [os.path.join(d, f) for f in sorted(files)]
+    return out + [os.path.join(_ROOT, "include", "fisr.h")]
+
+
+def source_hash() -> str:
+    """sha256 (16 hex digits) over csrc/ and include/fisr.h: compiled into the library (`fisr_version()`), printed by bench.py."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sources():
+        h.update(os.path.relpath(p, _ROOT).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build() -> bool:
@@ -59,16 +74,21 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> fisr_amd/libfisr_hip.so (in-tree; cross-compiles without a GPU)."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, diag: bool = False, defines=(), out: str | None = None) -> str:
+    """hipcc --offload-arch=gfx950 -> fisr_amd/libfisr_hip.so (in-tree; cross-compiles without a GPU).
+    diag=True: the diagnostics build (-DFISR_DIAG: environment switches, superseded kernels, ablations, traces) ->
+    build_ab/libfisr_hip_diag.so, loaded through FISR_HIP_SO by the scripts under scripts/; never the product."""
+    target = out or (os.path.join(_ROOT, "build_ab", "libfisr_hip_diag.so") if diag else SO_PATH)
+    if not diag and not out and not force and not needs_build():
         return SO_PATH
+    os.makedirs(os.path.dirname(target), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", SO_PATH, os.path.join(CSRC, "fisr_api.hip")]
+           f'-DFISR_SRC_HASH="{source_hash()}"'] + (["-DFISR_DIAG"] if diag else []) + [f"-D{d}" for d in defines] + \
+          ["-o", target, os.path.join(CSRC, "fisr_api.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return SO_PATH
+    return target
 
 
 _lib = None
@@ -135,6 +155,12 @@ def lib():
     L.fisr_pwc_nn.argtypes = [vp, vp, c_int, c_int, vp, POINTER(vp), vp, c_size_t, vp]
     L.fisr_pwc_prep.argtypes = [vp, c_int, c_int, vp, c_int, c_int, vp]
     L.fisr_pwc_flow_out.argtypes = [vp, c_int, c_int, vp, c_int, c_int, vp]
+    L.fisr_pwc_op_conv.argtypes = [vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, POINTER(c_int), vp, c_int,
+                                   c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, vp]
+    L.fisr_pwc_op_deconv.argtypes = [vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, POINTER(c_int), vp, c_int, c_int,
+                                     c_int, c_int, c_int, vp]
+    L.fisr_pwc_op_costvol.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_pwc_op_warp.argtypes = [vp, c_int, vp, c_int, c_int, c_float, vp, c_int, c_int, c_int, vp]
     L.fisr_train_packed_bytes.argtypes = [c_int, c_int, c_int]
     L.fisr_train_packed_bytes.restype = c_size_t
     L.fisr_train_pack.argtypes = [vp, c_int, c_int, c_int, vp, vp]

@@ -171,8 +171,17 @@ def main(argv=None):
     # FISR_for_video (main.py:207-235)
     flow_file = args.flow_file
     if not flow_file:
-        # FISR_for_video_Compute_Flow (main.py:210): PWC-Net-large on the GPU, both directions of every frame pair
-        flow_file = harness.compute_flow(net, args)
+        # FISR_for_video_Compute_Flow (main.py:210): PWC-Net-large on the GPU, both directions of every frame pair.
+        # With several ranks rank 0 computes and writes the file (to a temporary name, then os.replace: a reader never
+        # sees a truncated file); the others wait at the barrier and read it afterwards.
+        if world > 1:
+            import torch.distributed as dist
+            if dist.get_rank() == 0:
+                flow_file = harness.compute_flow(net, args)
+            dist.barrier()
+            flow_file = harness.flow_file_name(args)
+        else:
+            flow_file = harness.compute_flow(net, args)
         print("[*] Flow file saved!")
     warp_file = args.warp_file
     if warp_file is None:

@@ -117,6 +117,33 @@ class TrainNet:
             out[c.name + "/b"] = c.b.cpu().numpy()
         return out
 
+    def optimizer_state_numpy(self, b1=0.9, b2=0.999):
+        """Adam's state under TensorFlow's names: `<var>/Adam` (m), `<var>/Adam_1` (v), `beta1_power`, `beta2_power`
+        (TF 1.13 keeps b^(t+1) after t steps: initialised to b, multiplied once per step)."""
+        out = OrderedDict()
+        for c in self.convs.values():
+            out[c.name + "/w/Adam"] = c.mw.cpu().numpy()
+            out[c.name + "/w/Adam_1"] = c.vw.cpu().numpy()
+            out[c.name + "/b/Adam"] = c.mb.cpu().numpy()
+            out[c.name + "/b/Adam_1"] = c.vb.cpu().numpy()
+        out["beta1_power"] = np.float64(b1 ** (self.step_count + 1))
+        out["beta2_power"] = np.float64(b2 ** (self.step_count + 1))
+        return out
+
+    def load_optimizer_state(self, state, b2=0.999, fallback_step=0):
+        """Restore what optimizer_state_numpy() wrote; the step count of the bias correction comes from beta2_power
+        (`fallback_step` -- the step in the checkpoint's file name -- when a float32 beta power has underflowed to 0, which
+        TensorFlow's own does after ~88 000 steps: the correction is 1 by then)."""
+        torch = self.torch
+        for c in self.convs.values():
+            for dst, key in ((c.mw, "/w/Adam"), (c.vw, "/w/Adam_1"), (c.mb, "/b/Adam"), (c.vb, "/b/Adam_1")):
+                a = np.ascontiguousarray(state[c.name + key], np.float32)
+                if tuple(a.shape) != tuple(dst.shape):
+                    raise ValueError(f"{c.name}{key}: shape {a.shape} != {tuple(dst.shape)}")
+                dst.copy_(torch.from_numpy(a))
+        p2 = float(state["beta2_power"])
+        self.step_count = max(0, int(round(math.log(p2) / math.log(b2))) - 1) if 0.0 < p2 < 1.0 else int(fallback_step)
+
     def grads_numpy(self):
         out = OrderedDict()
         for c in self.convs.values():

@@ -70,7 +70,7 @@ def load_train_set(args):
 def learning_rate(args, epoch, step, train_iter):
     """FISRnet.py:227-245, 637-640."""
     if args.lr_type == "stair_decay":
-        k = sum(1 for p in args.lr_stair_decay_points if step >= p * train_iter)      # tf.train.piecewise_constant on global_step
+        k = sum(1 for p in args.lr_stair_decay_points if step > p * train_iter)       # tf.train.piecewise_constant: values[i] while x <= boundaries[i]
         return args.init_lr * args.lr_decreasing_factor ** k
     if args.lr_type == "linear_decay":
         return args.init_lr if epoch < args.lr_linear_decay_point else args.init_lr * (args.epoch - epoch) / (args.epoch - args.lr_linear_decay_point)
@@ -122,16 +122,27 @@ def run_train(args):
     ckpt_dir = os.path.join(args.checkpoint_dir, model_dir)
     os.makedirs(ckpt_dir, exist_ok=True)
     path, kind, counter = _weights.find_checkpoint(args.checkpoint_dir, model_dir)
+    opt_state = None
     if path:
         W = _weights.load_weights(path, kind)
+        opt_state = _weights.load_optimizer_state(path, kind)
         print(" [*] Load SUCCESS")
     else:
-        W = _weights.synthetic_weights(2020 if args.synthetic_weights is None else args.synthetic_weights)   # stands in for tf.global_variables_initializer
+        # tf.global_variables_initializer (FISRnet.py:588): Xavier-normal kernels, zero biases (ops.py:8-9);
+        # --synthetic_weights SEED keeps the damped parity-test set instead
+        W = _weights.xavier_weights(args.exp_num) if args.synthetic_weights is None else _weights.synthetic_weights(args.synthetic_weights)
         counter = 0
         print(" [!] Load failed...")
     lam = dict(recn=args.recn_lambda, tm1=args.tm1_lambda, tm2=args.tm2_lambda, tmm=args.tmm_lambda, td=args.td_lambda, ss2=args.ss2_lambda)
     net = ft.TrainNet(W, device=dev, lambdas=lam)
-    net.step_count = counter
+    if opt_state is not None:
+        net.load_optimizer_state(opt_state, fallback_step=counter)   # Adam moments + the step of the bias correction (saver.restore, FISRnet.py:1108)
+    else:
+        # weights only (an inference checkpoint): the moments start at zero, so the bias correction must start at t = 0
+        # too -- with t = counter the first updates would be ~3x the nominal step
+        net.step_count = 0
+        if path:
+            print(" [!] the checkpoint holds no Adam slots: the optimizer state starts from zero")
     net.grad_scale = 1.0 / world
     if world > 1:
         np.random.seed(1234 + args.exp_num)          # every rank must draw the same permutations
@@ -158,6 +169,10 @@ def run_train(args):
                 v /= world
                 total, t = float(v[0]), dict(zip(sorted(t), v[1:].tolist()))
             psnr = _psnr(_ovlp([p[2] for p in net.last_preds[:3]]), batch["label21"])
+            if world > 1:                             # ... and so is the PSNR (same samples as the losses)
+                pv = torch.tensor([psnr], dtype=torch.float64)
+                dist.all_reduce(pv)
+                psnr = float(pv[0]) / world
             s1 = lam["recn"] * t["recn"] + lam["tm1"] * t["tm"] + lam["tmm"] * t["tmm"] + lam["td"] * t["td"]
             s2 = lam["recn"] * t["recn_ss2"] + lam["td"] * t["td_ss2"] + lam["tm2"] * t["tm_ss2"]
             row = (psnr, t["recn"], t["tm"], t["tmm"], t["td"], s1, t["recn_ss2"], t["td_ss2"], t["tm_ss2"], s2, total)
@@ -196,8 +211,10 @@ def run_train(args):
         # save_checkpoint (FISRnet.py:1091-1099): <checkpoint_dir>/<model_dir>/FISRnet-<global_step>
         name = f"FISRnet-{counter}"
         if rank == 0:
+            # weights + Adam slots + beta powers, as the reference's Saver (created after build_model, FISRnet.py:585) stores them
             Wn = net.weights_numpy()
-            _weights.save_npz(os.path.join(ckpt_dir, name + ".npz"), Wn)
+            Wn.update(net.optimizer_state_numpy())
+            np.savez(os.path.join(ckpt_dir, name + ".npz"), **Wn)
             if getattr(args, "save_tf_bundle", False):
                 # tf.train.Saver's checkpoint-V2 files (<name>.index / .data-00000-of-00001) under the reference's variable
                 # names, so that the reference's FISRnet.load (FISRnet.py:1101-1115) restores what was trained here
@@ -205,4 +222,12 @@ def run_train(args):
                 tf_bundle.write_bundle(os.path.join(ckpt_dir, name), Wn)
             with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
                 f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
+            # Saver(max_to_keep=1) (FISRnet.py:585): the previous step's files go once the state file names the new ones
+            for fn in os.listdir(ckpt_dir):
+                stem = fn.split(".")[0]
+                if stem.startswith("FISRnet-") and stem != name and fn != "checkpoint":
+                    try:
+                        os.remove(os.path.join(ckpt_dir, fn))
+                    except OSError:
+                        pass
     return last

@@ -144,6 +144,24 @@ WEIGHT_SETS = {
 }
 
 
+def xavier_weights(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """The reference's initialiser for a run from scratch (ops.py:8-9): `w` = tf.contrib.layers.xavier_initializer(
+    uniform=False) = variance_scaling_initializer(factor=1, mode='FAN_AVG', uniform=False), i.e. a normal truncated at two
+    standard deviations with stddev = sqrt(1.3 / ((fan_in + fan_out) / 2)), fan = 9 * channels; `b` = zeros."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, ci, co in conv_specs():
+        std = np.sqrt(1.3 * 2.0 / (9.0 * (ci + co)))
+        w = rng.standard_normal((3, 3, ci, co))
+        bad = np.abs(w) > 2.0
+        while bad.any():                                     # tf.truncated_normal re-draws the samples beyond 2 sigma
+            w[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(w) > 2.0
+        out[name + "/w"] = (w * std).astype(np.float32)
+        out[name + "/b"] = np.zeros(co, np.float32)
+    return out
+
+
 def check_complete(weights) -> None:
     """Raise KeyError/ValueError unless every one of the 276 tensors is present with
     the reference's shape (what `saver.restore` would enforce, FISRnet.py:1108)."""
@@ -200,6 +218,37 @@ def find_checkpoint(checkpoint_dir: str, model_dir: str):
             print(f" [!] no 'checkpoint' state file in {d}: falling back to the highest step found, {name}")
             return os.path.join(d, name if kind == "npz" else stem), kind, step_of(stem)
     return None, None, 0
+
+
+ADAM_SLOTS = ("/Adam", "/Adam_1")          # tf.train.AdamOptimizer's slot variables m and v of `<var>` (FISRnet.py:490-491)
+
+
+def load_optimizer_state(path_or_prefix: str, kind: str | None = None):
+    """The Adam state a training checkpoint holds next to the weights -- `<var>/Adam`, `<var>/Adam_1` for all 276
+    variables and the scalars `beta1_power`, `beta2_power` (the reference creates its tf.train.Saver after build_model,
+    FISRnet.py:585, so these are saved and restored with the weights).  None when the file holds weights only."""
+    if kind is None:
+        kind = "npz" if path_or_prefix.endswith(".npz") else "tf_bundle"
+    if kind == "npz":
+        with np.load(path_or_prefix) as z:
+            names = set(z.files)
+            want = [v + s for v in variable_shapes() for s in ADAM_SLOTS]
+            if not all(n in names for n in want) or "beta1_power" not in names or "beta2_power" not in names:
+                return None
+            out = OrderedDict((n, np.asarray(z[n], np.float32)) for n in want)
+            out["beta1_power"], out["beta2_power"] = np.float64(z["beta1_power"]), np.float64(z["beta2_power"])
+            return out
+    from . import tf_bundle
+    try:
+        w = tf_bundle.read_bundle(path_or_prefix)
+    except (OSError, ValueError, KeyError):
+        return None
+    want = [v + s for v in variable_shapes() for s in ADAM_SLOTS]
+    if not all(n in w for n in want) or "beta1_power" not in w or "beta2_power" not in w:
+        return None
+    out = OrderedDict((n, np.asarray(w[n], np.float32)) for n in want)
+    out["beta1_power"], out["beta2_power"] = np.float64(w["beta1_power"]), np.float64(w["beta2_power"])
+    return out
 
 
 def load_weights(path_or_prefix: str, kind: str | None = None):

@@ -230,6 +230,23 @@ int fisr_pwc_nn(fisr_pwc* ctx, const float* im, int H, int W, float* flow_pred, 
 /* the two pre/post-processing kernels on their own (parity tests): yuv [h,w,3] -> out [PH,PW,4]; flow2 [FH,FW,2] -> out [h,w,2] */
 int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream);
 int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream);
+/* Op-level entries: one layer of the flow network exactly as the network launches it (parity tests at the sizes the
+ * bench runs).  fisr_pwc_op_conv = tf.layers.conv2d(x, cout, 3, stride, 'same', dilation_rate=dil) + leaky relu (slope; 1 =
+ * linear) (+ add) of model_pwcnet.py:1092-1097, 1426-1449, 1506-1521 on the channel range [in_co, in_co + cin_buf) of a buffer
+ * with pixel stride in_cs, written to the range [out_co, out_co + cout) of a buffer with pixel stride out_cs; w_host TF HWIO
+ * [3,3,ci,cout]; chmap (nullable = identity): buffer channel, relative to in_co, of TF input channel j.  route 0 = the
+ * network's own choice, 1 = generic implicit GEMM, 2 = persistent Winograd kernel, 3 = FISRnet's direct kernel (2, 3: error if
+ * the layer is not eligible).  Returns the route taken (1..3) or a negative error.  Synchronises the stream.
+ * fisr_pwc_op_deconv = tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196), w_host [4,4,2,ci];
+ * fisr_pwc_op_costvol = core_costvol.cost_volume + leaky relu (:1277), 81 channels; fisr_pwc_op_warp = core_warp.dense_image_warp
+ * (:1178) at (x + scale*u, y + scale*v). */
+int fisr_pwc_op_conv(const float* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
+                     const int* chmap, float* out, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
+                     int stride, int dil, float slope, int route, void* stream);
+int fisr_pwc_op_deconv(const float* in, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci, const int* chmap,
+                       float* out, int out_cs, int out_co, int n, int h, int w, void* stream);
+int fisr_pwc_op_costvol(const float* c1, const float* c2, int c, float* out, int out_cs, int out_co, int n, int h, int w, void* stream);
+int fisr_pwc_op_warp(const float* img, int c, const float* flow, int f_cs, int f_co, float scale, float* out, int n, int h, int w, void* stream);
 
 /* ---- training graph: the ops the reference gets from TensorFlow's autodiff and optimizer ----
  * FISRnet.build_model (FISRnet.py:175-497) builds forward passes, seven loss terms and tf.train.AdamOptimizer in Python;

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of Winograd kernel builds: per-workgroup traces of one launch with the in-tree library and each build in build_ab/
+# A/B of Winograd kernel builds: per-workgroup traces of one launch with each FISR_DIAG build in build_ab/
+# (python -c "from fisr_amd import lib; lib.build(diag=True, defines=['FISR_WABL=2'], out='build_ab/abl2.so')")
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -9,7 +10,7 @@ if [ -n "$PARITY" ]; then
     FISR_HIP_SO=$PWD/$so timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q --no-header -rf -p no:cacheprovider -x -k "${PARITY_K:-winograd}" > gpurun_out/pytest_wino.log 2>&1; echo "pytest $so rc=$?"; tail -3 gpurun_out/pytest_wino.log | cut -c1-600
   done
 fi
-for so in fisr_amd/libfisr_hip.so build_ab/*.so; do
+for so in build_ab/*.so; do
   [ -f "$so" ] || continue
   for res in 1 0; do
     echo "== $so res=$res 64->64"

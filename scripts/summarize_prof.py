@@ -84,6 +84,29 @@ for k, d in traffic.items():
             out[k]["avg_duration_us_trace_pass"] = durations[k][1] / 1e3
             out[k]["hbm_gbps"] = out[k]["hbm_bytes_per_launch"] / durations[k][1]
             out[k]["frac_of_8tbps"] = out[k]["hbm_gbps"] / 8000.0
+# ---- share of the matrix pipe busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) per kernel, and the shader
+# clock while it ran (GRBM_GUI_ACTIVE of one XCD / duration) -- bench.py's roofline.pmc_mfma_busy_frac
+for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+    cur = sqlite3.connect(f).cursor()
+    try:
+        rows = list(cur.execute("select name, counter_name, count(*), sum(counter_value), sum(duration) from pmc_events "
+                                "where counter_name in ('SQ_VALU_MFMA_BUSY_CYCLES','GRBM_GUI_ACTIVE') group by name, counter_name"))
+    except sqlite3.Error:
+        try:
+            rows = [r + (None,) for r in cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
+                                                     "where counter_name in ('SQ_VALU_MFMA_BUSY_CYCLES','GRBM_GUI_ACTIVE') group by name, counter_name")]
+        except sqlite3.Error:
+            continue
+    agg = defaultdict(dict)
+    for n, cn, c, s_, _ in rows:
+        agg[short(n)][cn] = (c, s_)
+    for k, d in agg.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"][1] > 0:
+            e = out.setdefault(k, {"dispatches": d["GRBM_GUI_ACTIVE"][0]})
+            e["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (1024.0 * d["GRBM_GUI_ACTIVE"][1] / 8.0)
+            e["gui_active_cycles_per_launch"] = d["GRBM_GUI_ACTIVE"][1] / max(d["GRBM_GUI_ACTIVE"][0], 1)
+            if k in durations:
+                e["shader_clock_mhz"] = e["gui_active_cycles_per_launch"] / (durations[k][1] / 1e3)
 if out:
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)

@@ -4,11 +4,17 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, n, h, w, ci, co, fl, rs = sys.argv[1], *map(int, sys.argv[2:9])
 prec = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
-os.environ["FISR_TRACE_FILE"] = out
+# needs a diagnostics build (-DFISR_DIAG: the shipped library has no trace hook): FISR_HIP_SO=build_ab/libfisr_hip_diag.so,
+# made by `python -c "from fisr_amd import lib; lib.build(diag=True)"` (or any A/B build of scripts/gpu_ablate.sh)
+os.environ.setdefault("FISR_HIP_SO", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_ab", "libfisr_hip_diag.so"))
 from fisr_amd import lib
 L = lib.lib()
+if not hasattr(L, "fisr_diag_bench_conv"):
+    sys.exit(f"{lib.SO_PATH} is not a FISR_DIAG build")
+L.fisr_diag_bench_conv.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_uint, ctypes.c_char_p]
 us = ctypes.c_double()
-rc = L.fisr_bench_conv(prec, n, h, w, ci, co, fl, rs, 3, ctypes.byref(us))
+rc = L.fisr_diag_bench_conv(prec, n, h, w, ci, co, fl, rs, 3, ctypes.byref(us), int(os.environ.get("BENCH_ZERO", "0")),
+                            int(os.environ.get("BENCH_LOMASK", "ffff"), 16), out.encode())
 print("rc", rc, "us", us.value, L.fisr_last_error(None) if rc else "")
 
 import numpy as np

@@ -152,6 +152,60 @@ def test_phase_fisr_for_video_with_on_gpu_flow(scene):
                     "--FISR_test_patch", "1,1", "--FISR_input_size", "96,96", "--frame_num", "5"])
 
 
+def test_phase_fisr_for_video_full_size_with_on_gpu_flow(tmp_path_factory, syn_weights, gold_dir):
+    """cfg5 at full size through the CLI: five 1080x1920 frames, no flow file -> PWC-Net on the GPU (2176x3840 network input),
+    GPU warp, FISRnet with the reference's 2x2 tiling, 7 frames of 2048x3840.  Frames 0 and 1 are the pair of the full-size
+    flow golden, so the written .flo is checked against the float64 oracle; the output frames against the engine driven by
+    hand with the flows read back from that file."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fisr_amd import pwcnet
+    from fisr_amd.fisrnet import FISRnet
+    from fisr_amd.harness import sorted_pngs, warp_img
+    from tests_support import make_flow_frames
+    root = tmp_path_factory.mktemp("cfg5")
+    lr = root / "LR_LFR"; ck = root / "checkpoint_dir" / "FISRnet_exp1"
+    for d in (lr, ck):
+        d.mkdir(parents=True)
+    g = np.load(os.path.join(gold_dir, "pwc_flow_1080p_sparse.npz"))
+    fa, fb = make_flow_frames(int(g["seed"]), 1080, 1920)
+    rng = np.random.default_rng(9)
+    frames = [fa, fb] + [np.clip(np.roll(fb, (3 * k, -5 * k), (0, 1)).astype(np.int16) + rng.integers(-4, 5, fb.shape), 0, 255).astype(np.uint8)
+                         for k in (1, 2, 3)]
+    for i, f in enumerate(frames):
+        fio.write_png(str(lr / f"fr_{i}.png"), f)
+    weights.save_npz(str(ck / "FISRnet-1.npz"), syn_weights)
+    np.savez(str(root / "pwc.npz"), **pwcnet.synthetic_weights(595000, flow_gain=float(g["flow_gain"])))
+    argv = ["--phase", "FISR_for_video", "--frame_folder_path", str(lr), "--pwc_ckpt", str(root / "pwc.npz"),
+            "--checkpoint_dir", str(root / "checkpoint_dir"), "--test_img_dir", str(root / "test_img_dir"),
+            "--text_dir", str(root / "text_dir"), "--log_dir", str(root / "logdir"), "--frame_num", "5", "--precision", "fp32"]
+    assert fmain.main(argv) == 0
+    flow = fio.read_flo_file_5dim(str(lr / "LR_LFR_test_ss1_fr5.flo"))
+    assert flow.shape == (4, 2, 1080, 1920, 2) and np.isfinite(flow).all()
+    st = int(g["stride"])
+    d = np.abs(flow[0][:, ::st, ::st].astype(np.float64) - g["flow_sparse"])
+    print(f"full-size .flo vs the oracle golden: max|err| {d.max():.2e} px")
+    assert d.max() < 5e-3
+    out_dir = lr / "FISR_frames"
+    assert sorted(os.listdir(out_dir)) == sorted([f"pred_{k}.png" for k in range(7)] + [f"pred_YUV_{k}.png" for k in range(7)])
+    # the same window by hand: flows from the file, GPU warp, pack, tiled forward, quantise
+    net = FISRnet(fmain.parse_args(argv))
+    net.load(net.checkpoint_dir)
+    warp = warp_img(net, sorted_pngs(str(lr)), flow)
+    fl = np.concatenate((flow[0:3], flow[1:4]), axis=1)
+    wp = np.concatenate((warp[0:3], warp[1:4]), axis=1)
+    fr = 2
+    dev = net.device
+    inp = net.pack_input([torch.from_numpy(frames[fr + k]).to(dev) for k in range(3)],
+                         [torch.from_numpy(np.ascontiguousarray(fl[fr, k])).to(dev) for k in range(4)],
+                         [torch.from_numpy(np.ascontiguousarray(wp[fr, k])).to(dev) for k in range(4)], 1024, 1920)
+    yuv, _ = net.unpack_output(net.forward_tiled(inp, (2, 2)))
+    got = fio.read_png(str(out_dir / "pred_YUV_6.png"))
+    assert got.shape == (2048, 3840, 3)
+    assert np.array_equal(got, yuv.cpu().numpy()[:, :, 6:9])
+    net.close()
+
+
 def test_phase_test_full_size_precisions_agree(tmp_path_factory, syn_weights):
     """cfg2/cfg3 plumbing at full size: `--phase test` on one synthetic 1080x1920 5-frame scene with the
     reference's default 2x2 tiling (crop to 1024x1920, four 544x992 tiles, 2048x3840 outputs).  The exact

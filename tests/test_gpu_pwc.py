@@ -138,3 +138,43 @@ def test_pwc_errors(pwc):
     with pytest.raises(KeyError):
         n2.set_weights(bad)
     n2.close()
+
+
+def test_flow_pair_full_size_vs_oracle_golden(pwc, gold_dir):
+    """cfg5 at the size the bench times it: one 1080x1920 frame pair -> x2 up-scaled 2176x3840 network input, levels of
+    544x960 .. 34x60 (every dilated context layer runs on sub-images of many 8x32 tiles), both directions, against the float64
+    oracle's flows committed on every 8th LR pixel (tests/golden/pwc_flow_1080p_sparse.npz, made once in the build container
+    by oracle/make_golden_pwc_fullsize.py) and against its refined level-6 .. level-2 flows of direction a->b."""
+    import zlib
+    from tests_support import make_flow_frames
+    path = os.path.join(gold_dir, "pwc_flow_1080p_sparse.npz")
+    if not os.path.isfile(path):
+        pytest.fail("tests/golden/pwc_flow_1080p_sparse.npz missing: run oracle/make_golden_pwc_fullsize.py")
+    g = np.load(path)
+    fa, fb = make_flow_frames(int(g["seed"]), 1080, 1920)
+    assert zlib.crc32(fa.tobytes() + fb.tobytes()) == int(g["frames_crc"]), "the frame generator drifted from the golden's"
+    assert float(g["flow_gain"]) == 3.0                      # the fixture's weight set
+    net, W = pwc
+    ab, ba = net.flow_pair(torch.from_numpy(fa), torch.from_numpy(fb))
+    torch.cuda.synchronize()
+    st = int(g["stride"])
+    for name, got, exp in (("a->b", ab, g["flow_sparse"][0]), ("b->a", ba, g["flow_sparse"][1])):
+        d = np.abs(got[::st, ::st].cpu().numpy().astype(np.float64) - exp)
+        print(f"1080p {name}: max|err| {d.max():.2e} rms {np.sqrt((d ** 2).mean()):.2e} px, |flow| max {np.abs(exp).max():.2f} px")
+        # a uint8 flip of the pre-processing (value within fp rounding of an integer) moves the flow locally by ~1e-3 px
+        assert d.max() < 5e-3 and np.sqrt((d ** 2).mean()) < 2e-4
+    # the pyramid of direction a->b through the same pre-processing kernel
+    H, Wd = 2176, 3840
+    im = torch.empty((2, H, Wd, 4), device="cuda")
+    for k, f in enumerate((fa, fb)):
+        flib.check(flib.lib().fisr_pwc_prep(ctypes.c_void_p(torch.from_numpy(f).cuda().data_ptr()), 1080, 1920,
+                                            ctypes.c_void_p(im[k].data_ptr()), H, Wd, _stream()))
+    _, pyr = net.nn(im, want_pyramid=True)
+    torch.cuda.synchronize()
+    for k, lvl in enumerate(range(6, 1, -1)):
+        s2 = 2 if k > 2 else 1
+        exp = g[f"flow{lvl}_ab_sparse"]
+        got = pyr[0][k][::s2, ::s2].cpu().numpy()
+        err = np.abs(got - exp).max()
+        print(f"1080p flow{lvl} ({pyr[0][k].shape[0]}x{pyr[0][k].shape[1]}): max|err| {err:.2e}, |flow| max {np.abs(exp).max():.3f}")
+        assert err < 2e-3, (lvl, err)

@@ -1,0 +1,260 @@
+"""Op-level GPU parity of the flow network's kernels at the sizes the cfg5 bench runs them at (run with `-m gpu`).
+
+At 2176x3840 (a x2 up-scaled 1080p frame, padded to 64) the levels are 544x960 (2), 272x480 (3), 136x240 (4), 68x120
+(5), 34x60 (6).  test_gpu_pwc.py checks the whole network at <= 128x192, where a dilation-16 layer sees 2x3-pixel
+sub-images and no sub-image spans more than one 8x32 Winograd tile; here every layer TYPE runs through its own kernel
+on maps of the level-3 / level-4 size, so that every d x d sub-image of the dilated layers spans several tiles, with
+channel-range inputs / outputs of a wider buffer as the dense blocks use them, against the float64 oracle ops of
+oracle/pwcnet_oracle.py (model_pwcnet.py:1084-1100 stride-2 pyramid, :1178 warp, :1196 transpose conv, :1277 cost volume,
+:1426-1449 dense estimator, :1506-1519 dilated context network)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import pwcnet_oracle as P  # noqa: E402
+from fisr_amd import lib as flib  # noqa: E402
+
+F32P = ctypes.POINTER(ctypes.c_float)
+I32P = ctypes.POINTER(ctypes.c_int)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _oracle_conv(x_nhwc, w, b, stride, dil, slope, add=None):
+    """tf.layers.conv2d 'same' + leaky relu (+ add) in float64 through the oracle's conv2d_same."""
+    W = {"op/kernel": w, "op/bias": b}
+    y = P.conv2d_same(torch.from_numpy(x_nhwc).double().permute(0, 3, 1, 2), W, "op", stride=stride, dilation=dil)
+    if slope != 1.0:
+        y = torch.nn.functional.leaky_relu(y, slope)
+    y = y.permute(0, 2, 3, 1).numpy()
+    return y + add if add is not None else y
+
+
+def _run_conv(x_buf, in_co, cin_buf, w, b, chmap, out_buf, out_co, n, h, wd, stride, dil, slope, route, add_buf=None, add_co=0):
+    ci, cout = w.shape[2], w.shape[3]
+    wc = np.ascontiguousarray(w, np.float32)
+    bc = np.ascontiguousarray(b, np.float32)
+    cm = None if chmap is None else (ctypes.c_int * ci)(*[int(v) for v in chmap])
+    rc = flib.lib().fisr_pwc_op_conv(_ptr(x_buf), x_buf.shape[-1], in_co, cin_buf, wc.ctypes.data_as(F32P), bc.ctypes.data_as(F32P),
+                                     ci, cout, cm, _ptr(out_buf), out_buf.shape[-1], out_co, _ptr(add_buf),
+                                     0 if add_buf is None else add_buf.shape[-1], add_co, n, h, wd, stride, dil, slope, route, _stream())
+    flib.check(rc)
+    torch.cuda.synchronize()
+    return rc
+
+
+# (h, w): level 3 and level 4 of the 2176x3840 bench frame, plus a ragged size (not a multiple of the 8x32 tile or of the dilation)
+@pytest.mark.parametrize("dil,shape", [(1, (272, 480)), (2, (272, 480)), (4, (272, 480)), (8, (136, 240)), (16, (136, 240)),
+                                       (16, (272, 480)), (4, (75, 133)), (8, (139, 251))])
+def test_winograd_general_dilated_vs_oracle(dil, shape):
+    """The GENERAL instantiation of the persistent Winograd kernel (97 % of the flow's FLOPs): dilation as d x d interleaved
+    sub-images, every sub-image several 8x32 tiles wide and high, channel-range input and output, leaky relu, a Cout that is not a
+    multiple of the 64-channel block."""
+    h, wd = shape
+    rng = np.random.default_rng(100 * dil + h)
+    in_cs, in_co, cin = 160, 32, 96            # reads channels 32..127 of a 160-wide buffer
+    out_cs, out_co, cout = 192, 64, 96         # writes channels 64..159 of a 192-wide buffer (96: one and a half N blocks)
+    x = (rng.standard_normal((1, h, wd, in_cs)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    xb = torch.from_numpy(x).cuda()
+    ob = torch.full((1, h, wd, out_cs), 7.25, dtype=torch.float32, device="cuda")
+    took = _run_conv(xb, in_co, cin, w, b, None, ob, out_co, 1, h, wd, 1, dil, 0.1, 2)
+    assert took == 2
+    got = ob.cpu().numpy()
+    exp = _oracle_conv(x[..., in_co:in_co + cin], w, b, 1, dil, 0.1)
+    err = np.abs(got[..., out_co:out_co + cout] - exp).max()
+    print(f"wino GENERAL dil {dil} {h}x{wd}: max|err| {err:.2e} (|y| max {np.abs(exp).max():.2f})")
+    assert err < 2e-5
+    assert (got[..., :out_co] == 7.25).all() and (got[..., out_co + cout:] == 7.25).all()     # neighbours of the range untouched
+
+
+def test_winograd_general_batch_and_padded_groups_vs_oracle():
+    """Two images (the two flow directions of the feature pyramid run as one batch), a dense block's input with zero-weight
+    padding channels between its groups (chmap), Cout = 32 (half an N block)."""
+    h, wd, n = 136, 240, 2
+    rng = np.random.default_rng(5)
+    cin_buf = 128
+    chmap = list(range(0, 40)) + list(range(48, 48 + 41)) + list(range(96, 96 + 30))        # three groups with gaps
+    ci, cout = len(chmap), 32
+    x = (rng.standard_normal((n, h, wd, cin_buf)) * 0.5).astype(np.float32)
+    x[..., 40:48] = np.nan_to_num(x[..., 40:48]) * 0 + 3.0         # padding channels hold finite garbage: their weights are zero
+    w = (rng.standard_normal((3, 3, ci, cout)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    xb = torch.from_numpy(x).cuda()
+    ob = torch.zeros((n, h, wd, cout), dtype=torch.float32, device="cuda")
+    took = _run_conv(xb, 0, cin_buf, w, b, chmap, ob, 0, n, h, wd, 1, 1, 0.1, 0)
+    assert took == 2
+    exp = _oracle_conv(x[..., chmap], w, b, 1, 1, 0.1)
+    err = np.abs(ob.cpu().numpy() - exp).max()
+    print(f"wino GENERAL batch 2, padded groups: max|err| {err:.2e}")
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(272, 480), (271, 479), (136, 241), (137, 240)])
+def test_stride2_generic_kernel_vs_oracle(shape):
+    """pwc_convg_kernel, stride 2 (the pyramid's conv{l}a, model_pwcnet.py:1092): TF 'SAME' pads (0, 1) on an even size and (1, 1)
+    on an odd one."""
+    h, wd = shape
+    rng = np.random.default_rng(h * 7 + wd)
+    cin, cout = 32, 64
+    x = (rng.standard_normal((2, h, wd, cin)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    oh, ow = -(-h // 2), -(-wd // 2)
+    ob = torch.zeros((2, oh, ow, cout), dtype=torch.float32, device="cuda")
+    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin, w, b, None, ob, 0, 2, h, wd, 2, 1, 0.1, 0)
+    assert took == 1
+    exp = _oracle_conv(x, w, b, 2, 1, 0.1)
+    assert exp.shape == (2, oh, ow, cout)
+    err = np.abs(ob.cpu().numpy() - exp).max()
+    print(f"stride 2 {h}x{wd}: max|err| {err:.2e}")
+    assert err < 2e-5
+
+
+def test_generic_kernel_residual_add_and_dilation_vs_oracle():
+    """dc_conv7 (2 channels, linear, + the predicted flow: refine_flow model_pwcnet.py:1519-1521) and a dilated layer forced
+    through the generic kernel (the Winograd path's fall-back), 272x480."""
+    h, wd = 272, 480
+    rng = np.random.default_rng(11)
+    cin = 32
+    x = (rng.standard_normal((1, h, wd, cin)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, 2)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(2) * 0.05).astype(np.float32)
+    flow = (rng.standard_normal((1, h, wd, 4)) * 2).astype(np.float32)
+    ob = torch.zeros((1, h, wd, 4), dtype=torch.float32, device="cuda")
+    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin, w, b, None, ob, 0, 1, h, wd, 1, 1, 1.0, 0, add_buf=torch.from_numpy(flow).cuda())
+    assert took == 1
+    exp = _oracle_conv(x, w, b, 1, 1, 1.0, add=flow[..., :2])
+    err = np.abs(ob.cpu().numpy()[..., :2] - exp).max()
+    assert err < 2e-5, err
+    w2 = (rng.standard_normal((3, 3, cin, 64)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b2 = (rng.standard_normal(64) * 0.05).astype(np.float32)
+    ob2 = torch.zeros((1, h, wd, 64), dtype=torch.float32, device="cuda")
+    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin, w2, b2, None, ob2, 0, 1, h, wd, 1, 4, 0.1, 1)
+    assert took == 1
+    err = np.abs(ob2.cpu().numpy() - _oracle_conv(x, w2, b2, 1, 4, 0.1)).max()
+    print(f"generic kernel, dilation 4: max|err| {err:.2e}")
+    assert err < 2e-5
+
+
+def test_flow_head_direct_kernel_vs_oracle():
+    """The 2-channel flow heads (predict_flow/flow{l}, model_pwcnet.py:1447) on FISRnet's direct kernel: a 565-channel dense-block
+    buffer (level 3 layout: 448 + 88 + 64 + 4 + 4 = 608 padded) read whole, linear output into a 4-wide flow buffer."""
+    h, wd = 272, 480
+    rng = np.random.default_rng(12)
+    cin_buf = 608
+    chmap = list(range(0, 448)) + list(range(448, 448 + 81)) + list(range(536, 600)) + [600, 601, 604, 605]
+    ci = len(chmap)
+    x = (rng.standard_normal((1, h, wd, cin_buf)) * 0.3).astype(np.float32)
+    w = (rng.standard_normal((3, 3, ci, 2)) * 0.01).astype(np.float32)
+    b = (rng.standard_normal(2) * 0.05).astype(np.float32)
+    ob = torch.zeros((1, h, wd, 4), dtype=torch.float32, device="cuda")
+    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin_buf, w, b, chmap, ob, 0, 1, h, wd, 1, 1, 1.0, 0)
+    assert took == 3
+    exp = _oracle_conv(x[..., chmap], w, b, 1, 1, 1.0)
+    got = ob.cpu().numpy()
+    err = np.abs(got[..., :2] - exp).max()
+    print(f"flow head on the direct kernel: max|err| {err:.2e}")
+    assert err < 2e-5 and not got[..., 2:].any()
+
+
+@pytest.mark.parametrize("shape", [(136, 240), (67, 119)])
+def test_deconv_vs_oracle(shape):
+    """pwc_deconv_kernel = tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (model_pwcnet.py:1196) on a padded dense-block buffer
+    (up_feat) and on the 4-wide flow buffer (up_flow)."""
+    h, wd = shape
+    rng = np.random.default_rng(h)
+    cin4 = 96
+    chmap = list(range(0, 50)) + list(range(56, 56 + 33))
+    ci = len(chmap)
+    x = (rng.standard_normal((1, h, wd, cin4 + 8)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((4, 4, 2, ci)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(2) * 0.05).astype(np.float32)
+    ob = torch.full((1, 2 * h, 2 * wd, 12), -3.0, dtype=torch.float32, device="cuda")
+    cm = (ctypes.c_int * ci)(*chmap)
+    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(torch.from_numpy(x).cuda()), cin4 + 8, 4, cin4, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P),
+                                             ci, cm, _ptr(ob), 12, 8, 1, h, wd, _stream()))
+    torch.cuda.synchronize()
+    xs = x[..., 4:4 + cin4][..., chmap]
+    exp = P.deconv(torch.from_numpy(xs).double().permute(0, 3, 1, 2), {"op/kernel": w, "op/bias": b}, "op").permute(0, 2, 3, 1).numpy()
+    got = ob.cpu().numpy()
+    err = np.abs(got[..., 8:10] - exp).max()
+    print(f"deconv {h}x{wd}: max|err| {err:.2e}")
+    assert err < 2e-5 and (got[..., :8] == -3.0).all() and (got[..., 10:] == -3.0).all()
+
+
+@pytest.mark.parametrize("shape,c", [((136, 240), 96), ((272, 480), 64), ((35, 61), 196), ((67, 119), 128)])
+def test_costvol_vs_oracle(shape, c):
+    """pwc_costvol_kernel = core_costvol.cost_volume + leaky relu (model_pwcnet.py:1277): 81 displacements, zero outside the image,
+    on level-sized maps incl. ragged ones (the 8x32 tiles + 4-pixel halo straddle every border) and the 196-channel top level."""
+    h, wd = shape
+    rng = np.random.default_rng(h + c)
+    c1 = (rng.standard_normal((2, h, wd, c)) * 0.7).astype(np.float32)
+    c2 = (rng.standard_normal((2, h, wd, c)) * 0.7).astype(np.float32)
+    ob = torch.full((2, h, wd, 96), 9.5, dtype=torch.float32, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_costvol(_ptr(torch.from_numpy(c1).cuda()), _ptr(torch.from_numpy(c2).cuda()), c, _ptr(ob), 96, 8,
+                                              2, h, wd, _stream()))
+    torch.cuda.synchronize()
+    t = lambda a: torch.from_numpy(a).double().permute(0, 3, 1, 2)
+    exp = P.lrelu(P.cost_volume(t(c1), t(c2))).permute(0, 2, 3, 1).numpy()
+    got = ob.cpu().numpy()
+    err = np.abs(got[..., 8:89] - exp).max()
+    print(f"cost volume {h}x{wd}x{c}: max|err| {err:.2e}")
+    assert err < 1e-5 and (got[..., :8] == 9.5).all() and (got[..., 89:] == 9.5).all()
+
+
+@pytest.mark.parametrize("shape", [(136, 240), (67, 119)])
+def test_warp_with_flows_leaving_the_image_vs_oracle(shape):
+    """pwc_warp_kernel = core_warp.dense_image_warp (model_pwcnet.py:1178): queries far outside every border (clamped), exactly
+    on the last row / column, and sub-pixel everywhere else; the flow is read from channels 4, 5 of a wider buffer and scaled
+    (20 / 2^lvl, :1560)."""
+    h, wd = shape
+    rng = np.random.default_rng(wd)
+    c = 96
+    img = rng.standard_normal((2, h, wd, c)).astype(np.float32)
+    flow = (rng.standard_normal((2, h, wd, 8)) * 6).astype(np.float32)
+    flow[:, : h // 4, :, 4:6] *= 40                                  # far outside
+    flow[0, h // 2, :, 4] = (wd - 1 - np.arange(wd)) / 2.5           # x + scale*u == wd - 1 exactly
+    flow[0, :, wd // 2, 5] = (h - 1 - np.arange(h)) / 2.5
+    ob = torch.zeros((2, h, wd, c), dtype=torch.float32, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_warp(_ptr(torch.from_numpy(img).cuda()), c, _ptr(torch.from_numpy(flow).cuda()), 8, 4, 2.5,
+                                           _ptr(ob), 2, h, wd, _stream()))
+    torch.cuda.synchronize()
+    f = torch.from_numpy(flow[..., 4:6].astype(np.float32) * np.float32(2.5)).double().permute(0, 3, 1, 2)
+    exp = P.dense_image_warp(torch.from_numpy(img).double().permute(0, 3, 1, 2), f).permute(0, 2, 3, 1).numpy()
+    err = np.abs(ob.cpu().numpy() - exp).max()
+    print(f"warp {h}x{wd}: max|err| {err:.2e}")
+    # the query position is computed in fp32 on the GPU (x + u: ~1e-5 px at these magnitudes), times the image gradient
+    assert err < 2e-4
+
+
+def test_op_entry_errors():
+    x = torch.zeros((1, 16, 32, 32), device="cuda")
+    o = torch.zeros((1, 16, 32, 64), device="cuda")
+    w = np.zeros((3, 3, 32, 64), np.float32)
+    b = np.zeros(64, np.float32)
+    L = flib.lib()
+    assert L.fisr_pwc_op_conv(_ptr(x), 32, 0, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None, _ptr(o), 64, 0, None, 0, 0,
+                              1, 16, 32, 3, 1, 0.1, 0, _stream()) < 0                      # stride 3
+    assert L.fisr_pwc_op_conv(_ptr(x), 32, 0, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None, _ptr(o), 64, 0, None, 0, 0,
+                              1, 16, 32, 2, 1, 0.1, 2, _stream()) < 0                      # Winograd forced on a stride-2 layer
+    assert L.fisr_pwc_op_conv(_ptr(x), 32, 2, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None, _ptr(o), 64, 0, None, 0, 0,
+                              1, 16, 32, 1, 1, 0.1, 0, _stream()) < 0                      # unaligned channel offset

@@ -200,6 +200,34 @@ def test_repeated_steps_reduce_the_loss(env):
     assert losses[-1] < 0.9 * losses[0]
 
 
+def test_resume_restores_the_adam_state(env):
+    """A checkpoint carries Adam's moments and step (the reference's Saver stores the slots and beta powers, FISRnet.py:585):
+    2 steps + save + load + 1 step must equal 3 steps in a row; without the state the third update differs."""
+    torch, L, lib = env
+    import fisr_train_oracle as fo
+    from fisr_amd import train, weights
+    W = weights.synthetic_weights(2020)
+    batch = train.to_device_batch(fo.synthetic_batch(3, 2, 32, 32))
+    a = train.TrainNet(W)
+    for _ in range(3):
+        a.train_step(batch, lr=1e-4)
+    b = train.TrainNet(W)
+    for _ in range(2):
+        b.train_step(batch, lr=1e-4)
+    Wb, Sb = b.weights_numpy(), b.optimizer_state_numpy()
+    c = train.TrainNet(Wb)
+    c.load_optimizer_state(Sb)
+    assert c.step_count == 2
+    c.train_step(batch, lr=1e-4)
+    cold = train.TrainNet(Wb)                                      # what the advisor's finding describes: zero moments
+    cold.train_step(batch, lr=1e-4)
+    Wa, Wc, Wcold = a.weights_numpy(), c.weights_numpy(), cold.weights_numpy()
+    k = "FISRnet/level_3/enc/level_0/conv/0/w"
+    upd = np.abs(Wa[k] - Wb[k]).mean()
+    assert np.abs(Wa[k] - Wc[k]).max() < 0.02 * upd, (np.abs(Wa[k] - Wc[k]).max(), upd)     # (weight-gradient atomics: not bit-exact)
+    assert np.abs(Wa[k] - Wcold[k]).mean() > 0.2 * upd
+
+
 def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp_path):
     """main.py --phase train (FISRnet.py:583-745) on synthetic samples: two epochs, validation, checkpoint; then the
     inference engine restores that checkpoint the way FISRnet.load does."""
@@ -217,8 +245,19 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     from fisr_amd import tf_bundle                                  # the TF checkpoint-V2 twin holds the same tensors
     Wb = tf_bundle.read_bundle(os.path.join(d, "ck", "FISRnet_exp1", "FISRnet-4"), name_filter="FISRnet")
     assert all(np.array_equal(Wb[k], W[k]) for k in W)
-    W0 = weights.synthetic_weights(2020)
+    W0 = weights.xavier_weights(1)                                  # the from-scratch initialiser (ops.py:8-9), seed = exp_num
     assert any(not np.array_equal(W[k], W0[k]) for k in W)
+    # Saver(max_to_keep=1): only the last step's files are left; they hold the Adam slots and beta powers
+    left = sorted(f for f in os.listdir(os.path.join(d, "ck", "FISRnet_exp1")) if f != "checkpoint")
+    assert left == ["FISRnet-4.data-00000-of-00001", "FISRnet-4.index", "FISRnet-4.npz"], left
+    st = weights.load_optimizer_state(path, kind)
+    assert st is not None and len(st) == 2 * 276 + 2
+    assert abs(float(st["beta2_power"]) - 0.999 ** 5) < 1e-9 and any(np.abs(v).max() > 0 for k, v in st.items() if k.endswith("/Adam"))
+    stb = weights.load_optimizer_state(os.path.join(d, "ck", "FISRnet_exp1", "FISRnet-4"), "tf_bundle")
+    assert stb is not None and all(np.array_equal(stb[k], st[k]) for k in st if "beta" not in k)
+    # resuming for one more epoch continues from step 4 with that state
+    assert main.main(argv[:4] + ["--epoch", "3"] + argv[6:]) == 0
+    assert weights.find_checkpoint(d + "/ck", "FISRnet_exp1")[2] == 6
     net = FISRnet(device="cuda:0", precision="fp32")
     net.set_weights(W)
     x = torch.rand(1, 32, 32, 29, device="cuda:0")

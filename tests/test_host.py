@@ -172,3 +172,40 @@ def test_one_default_precision_everywhere():
     assert main.parse_args(["--phase", "test"]).precision == fisrnet.DEFAULT_PRECISION
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'ap.add_argument("--precision", default="fp32"' in src
+
+
+def test_xavier_initialiser_and_lr_schedule():
+    """ops.py:8-9: xavier_initializer(uniform=False) = truncated normal, stddev sqrt(1.3 * 2 / (fan_in + fan_out)), zero
+    biases; FISRnet.py:227-245: tf.train.piecewise_constant switches one step AFTER a boundary."""
+    import types
+    from fisr_amd import train_harness, weights
+    W = weights.xavier_weights(3)
+    weights.check_complete(W)
+    w = W["FISRnet/level_3/enc/level_1/res_block/0/conv/0/w"]            # 128 -> 128
+    std = np.sqrt(1.3 * 2.0 / (9 * 256))
+    assert np.abs(w).max() <= 2.0 * std + 1e-7                           # truncated at two sigma
+    assert abs(w.std() / (std * 0.8796) - 1) < 0.02                      # std of a unit normal truncated at 2: 0.8796
+    assert not W["FISRnet/level_1/SR/conv/2/b"].any()
+    a = types.SimpleNamespace(lr_type="stair_decay", lr_stair_decay_points=[2, 3], init_lr=1e-4, lr_decreasing_factor=0.1, epoch=4,
+                              lr_linear_decay_point=2)
+    lr = lambda step: train_harness.learning_rate(a, 0, step, 10)
+    assert lr(20) == 1e-4 and abs(lr(21) - 1e-5) < 1e-12 and abs(lr(30) - 1e-5) < 1e-12 and abs(lr(31) - 1e-6) < 1e-13
+
+
+def test_optimizer_state_lookup(tmp_path, syn_weights):
+    """A weights-only container has no optimizer state; one with `<var>/Adam`, `<var>/Adam_1` and the beta powers has."""
+    from fisr_amd import weights
+    p0 = str(tmp_path / "a.npz")
+    weights.save_npz(p0, syn_weights)
+    assert weights.load_optimizer_state(p0) is None
+    full = dict(syn_weights)
+    for k, v in syn_weights.items():
+        full[k + "/Adam"] = np.full_like(v, 0.5)
+        full[k + "/Adam_1"] = np.full_like(v, 0.25)
+    full["beta1_power"], full["beta2_power"] = np.float64(0.9 ** 3), np.float64(0.999 ** 3)
+    p1 = str(tmp_path / "b.npz")
+    np.savez(p1, **full)
+    st = weights.load_optimizer_state(p1)
+    assert st is not None and len(st) == 2 * 276 + 2 and float(st["beta2_power"]) == 0.999 ** 3
+    W = weights.load_weights(p1)                                          # the slots do not disturb the weight loader
+    assert len(W) == 276
