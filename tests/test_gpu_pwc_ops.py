@@ -120,7 +120,8 @@ def test_stride2_generic_kernel_vs_oracle(shape):
     b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
     oh, ow = -(-h // 2), -(-wd // 2)
     ob = torch.zeros((2, oh, ow, cout), dtype=torch.float32, device="cuda")
-    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin, w, b, None, ob, 0, 2, h, wd, 2, 1, 0.1, 0)
+    xb = torch.from_numpy(x).cuda()
+    took = _run_conv(xb, 0, cin, w, b, None, ob, 0, 2, h, wd, 2, 1, 0.1, 0)
     assert took == 1
     exp = _oracle_conv(x, w, b, 2, 1, 0.1)
     assert exp.shape == (2, oh, ow, cout)
@@ -140,7 +141,8 @@ def test_generic_kernel_residual_add_and_dilation_vs_oracle():
     b = (rng.standard_normal(2) * 0.05).astype(np.float32)
     flow = (rng.standard_normal((1, h, wd, 4)) * 2).astype(np.float32)
     ob = torch.zeros((1, h, wd, 4), dtype=torch.float32, device="cuda")
-    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin, w, b, None, ob, 0, 1, h, wd, 1, 1, 1.0, 0, add_buf=torch.from_numpy(flow).cuda())
+    xb, fb = torch.from_numpy(x).cuda(), torch.from_numpy(flow).cuda()
+    took = _run_conv(xb, 0, cin, w, b, None, ob, 0, 1, h, wd, 1, 1, 1.0, 0, add_buf=fb)
     assert took == 1
     exp = _oracle_conv(x, w, b, 1, 1, 1.0, add=flow[..., :2])
     err = np.abs(ob.cpu().numpy()[..., :2] - exp).max()
@@ -148,7 +150,7 @@ def test_generic_kernel_residual_add_and_dilation_vs_oracle():
     w2 = (rng.standard_normal((3, 3, cin, 64)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
     b2 = (rng.standard_normal(64) * 0.05).astype(np.float32)
     ob2 = torch.zeros((1, h, wd, 64), dtype=torch.float32, device="cuda")
-    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin, w2, b2, None, ob2, 0, 1, h, wd, 1, 4, 0.1, 1)
+    took = _run_conv(xb, 0, cin, w2, b2, None, ob2, 0, 1, h, wd, 1, 4, 0.1, 1)
     assert took == 1
     err = np.abs(ob2.cpu().numpy() - _oracle_conv(x, w2, b2, 1, 4, 0.1)).max()
     print(f"generic kernel, dilation 4: max|err| {err:.2e}")
@@ -167,7 +169,8 @@ def test_flow_head_direct_kernel_vs_oracle():
     w = (rng.standard_normal((3, 3, ci, 2)) * 0.01).astype(np.float32)
     b = (rng.standard_normal(2) * 0.05).astype(np.float32)
     ob = torch.zeros((1, h, wd, 4), dtype=torch.float32, device="cuda")
-    took = _run_conv(torch.from_numpy(x).cuda(), 0, cin_buf, w, b, chmap, ob, 0, 1, h, wd, 1, 1, 1.0, 0)
+    xb = torch.from_numpy(x).cuda()
+    took = _run_conv(xb, 0, cin_buf, w, b, chmap, ob, 0, 1, h, wd, 1, 1, 1.0, 0)
     assert took == 3
     exp = _oracle_conv(x[..., chmap], w, b, 1, 1, 1.0)
     got = ob.cpu().numpy()
@@ -190,7 +193,8 @@ def test_deconv_vs_oracle(shape):
     b = (rng.standard_normal(2) * 0.05).astype(np.float32)
     ob = torch.full((1, 2 * h, 2 * wd, 12), -3.0, dtype=torch.float32, device="cuda")
     cm = (ctypes.c_int * ci)(*chmap)
-    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(torch.from_numpy(x).cuda()), cin4 + 8, 4, cin4, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P),
+    xb = torch.from_numpy(x).cuda()          # (named: a temporary would be freed, and its block re-used, before the launch)
+    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(xb), cin4 + 8, 4, cin4, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P),
                                              ci, cm, _ptr(ob), 12, 8, 1, h, wd, _stream()))
     torch.cuda.synchronize()
     xs = x[..., 4:4 + cin4][..., chmap]
@@ -210,7 +214,8 @@ def test_costvol_vs_oracle(shape, c):
     c1 = (rng.standard_normal((2, h, wd, c)) * 0.7).astype(np.float32)
     c2 = (rng.standard_normal((2, h, wd, c)) * 0.7).astype(np.float32)
     ob = torch.full((2, h, wd, 96), 9.5, dtype=torch.float32, device="cuda")
-    flib.check(flib.lib().fisr_pwc_op_costvol(_ptr(torch.from_numpy(c1).cuda()), _ptr(torch.from_numpy(c2).cuda()), c, _ptr(ob), 96, 8,
+    c1b, c2b = torch.from_numpy(c1).cuda(), torch.from_numpy(c2).cuda()
+    flib.check(flib.lib().fisr_pwc_op_costvol(_ptr(c1b), _ptr(c2b), c, _ptr(ob), 96, 8,
                                               2, h, wd, _stream()))
     torch.cuda.synchronize()
     t = lambda a: torch.from_numpy(a).double().permute(0, 3, 1, 2)
@@ -235,7 +240,8 @@ def test_warp_with_flows_leaving_the_image_vs_oracle(shape):
     flow[0, h // 2, :, 4] = (wd - 1 - np.arange(wd)) / 2.5           # x + scale*u == wd - 1 exactly
     flow[0, :, wd // 2, 5] = (h - 1 - np.arange(h)) / 2.5
     ob = torch.zeros((2, h, wd, c), dtype=torch.float32, device="cuda")
-    flib.check(flib.lib().fisr_pwc_op_warp(_ptr(torch.from_numpy(img).cuda()), c, _ptr(torch.from_numpy(flow).cuda()), 8, 4, 2.5,
+    imb, flb = torch.from_numpy(img).cuda(), torch.from_numpy(flow).cuda()
+    flib.check(flib.lib().fisr_pwc_op_warp(_ptr(imb), c, _ptr(flb), 8, 4, 2.5,
                                            _ptr(ob), 2, h, wd, _stream()))
     torch.cuda.synchronize()
     f = torch.from_numpy(flow[..., 4:6].astype(np.float32) * np.float32(2.5)).double().permute(0, 3, 1, 2)

@@ -223,9 +223,15 @@ def test_resume_restores_the_adam_state(env):
     cold.train_step(batch, lr=1e-4)
     Wa, Wc, Wcold = a.weights_numpy(), c.weights_numpy(), cold.weights_numpy()
     k = "FISRnet/level_3/enc/level_0/conv/0/w"
-    upd = np.abs(Wa[k] - Wb[k]).mean()
-    assert np.abs(Wa[k] - Wc[k]).max() < 0.02 * upd, (np.abs(Wa[k] - Wc[k]).max(), upd)     # (weight-gradient atomics: not bit-exact)
-    assert np.abs(Wa[k] - Wcold[k]).mean() > 0.2 * upd
+    # mean |difference| over all weights relative to the mean third update (the weight-gradient kernel's atomics make a run not
+    # bit-reproducible, and Adam's g / sqrt(v) turns rounding noise on near-zero gradients into a visible fraction of lr on a
+    # few elements: means, not maxima)
+    num = lambda A, B: sum(float(np.abs(A[n] - B[n]).sum()) for n in A)
+    upd = num(Wa, Wb)
+    warm, cold_ = num(Wa, Wc) / upd, num(Wa, Wcold) / upd
+    print(f"resume: |3 steps - (2 + restore + 1)| / |third update| = {warm:.4f}; without the Adam state {cold_:.4f}")
+    assert warm < 0.03 and cold_ > 0.3
+    assert float(np.abs(Wa[k] - Wc[k]).mean()) < 0.05 * float(np.abs(Wa[k] - Wb[k]).mean())
 
 
 def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp_path):
@@ -252,7 +258,7 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     assert left == ["FISRnet-4.data-00000-of-00001", "FISRnet-4.index", "FISRnet-4.npz"], left
     st = weights.load_optimizer_state(path, kind)
     assert st is not None and len(st) == 2 * 276 + 2
-    assert abs(float(st["beta2_power"]) - 0.999 ** 5) < 1e-9 and any(np.abs(v).max() > 0 for k, v in st.items() if k.endswith("/Adam"))
+    assert abs(float(st["beta2_power"]) - 0.999 ** 5) < 1e-6 and any(np.abs(v).max() > 0 for k, v in st.items() if k.endswith("/Adam"))
     stb = weights.load_optimizer_state(os.path.join(d, "ck", "FISRnet_exp1", "FISRnet-4"), "tf_bundle")
     assert stb is not None and all(np.array_equal(stb[k], st[k]) for k in st if "beta" not in k)
     # resuming for one more epoch continues from step 4 with that state
