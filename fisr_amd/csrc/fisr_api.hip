@@ -27,6 +27,7 @@
 #endif
 #include "conv3x3.h"
 #include "conv3x3_wino8p.h"
+#include "conv3x3_dma.h"
 #ifdef FISR_DIAG
 #include "diag/conv3x3_wino4.h"
 #include "diag/conv3x3_wino8.h"
@@ -51,6 +52,8 @@ struct ConvW {
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino_common.h), else NULL
   float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][4 | 6] for the vector-ALU head kernel (head_conv.h), else NULL
+  void* d_wd = nullptr;   // FISR_PREC_F16, Cout > 32: the weight slabs of the LDS-DMA kernel (conv3x3_dma.h), else NULL
+  int cout_pad_d = 0;     // ... and its Cout padded to the 64-channel block
   int prec = -1;          // the precision the device copies are packed for (differs per layer in FISR_PREC_MIXED)
 };
 
@@ -179,13 +182,13 @@ template <> struct PrecName<fsplit> { static const char* get() { return "f16f8";
 template <typename F>
 auto with_prec(int precision, F&& f) {
   if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W) return f(float());
-  if (precision == FISR_PREC_F16) return f(_Float16());
+  if (precision == FISR_PREC_F16 || precision == FISR_PREC_F16R) return f(_Float16());
   if (precision == FISR_PREC_F16F8) return f(fsplit());
   return f(bsplit());
 }
 inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
-         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W;
+         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W || precision == FISR_PREC_F16R;
 }
 // FISR_PREC_MIXED: which layers keep a split-precision arithmetic (f16f8) -- everything that works at the full and at
 // the half resolution of level 3 (its first two encoder levels, its last two decoder levels, both heads: 55 % of the
@@ -200,8 +203,10 @@ inline bool mixed_layer_is_hi(const std::string& name) {
     if (name.compare(0, strlen(h), h) == 0) return true;
   return false;
 }
+inline bool prec_mixed(int precision) { return precision == FISR_PREC_MIXED || precision == FISR_PREC_MIXEDR; }
 inline int layer_prec(int precision, const std::string& name) {
-  return precision != FISR_PREC_MIXED ? precision : (mixed_layer_is_hi(name) ? FISR_PREC_F16F8 : FISR_PREC_F16);
+  if (!prec_mixed(precision)) return precision;
+  return mixed_layer_is_hi(name) ? FISR_PREC_F16F8 : (precision == FISR_PREC_MIXED ? FISR_PREC_F16 : FISR_PREC_F16R);
 }
 inline bool prec_grouped16(int precision) { return precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8; }
 
@@ -220,7 +225,7 @@ inline uint8_t host_fp8_e4m3(float f) {
   if (ex > 8) return sign | 0x7e;
   return sign | (uint8_t)(((ex + 7) << 3) | ((int)r - 8));
 }
-inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 ? 32 : 16; }
+inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 || precision == FISR_PREC_F16R ? 32 : 16; }
 inline int prec_unit(int precision) { return precision == FISR_PREC_F32 || precision == FISR_PREC_F32W ? 4 : 8; }   // glue kernels: channels per 16 bytes
 constexpr int CONV_REC = 16;   // the conv kernel stores whole 16-channel records
 
@@ -315,6 +320,28 @@ void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<
     }
 }
 
+// fp16 weights for the LDS-DMA kernel (conv3x3_dma.h): [Cin/16][CoutPad/64][tap 9][row 64][32-byte record] -- a slab is the
+// kernel's LDS image: rows in the MFMA row order of pack_weights, the two 16-byte halves (channels 0-7 | 8-15 of the chunk)
+// swapped when bit 3 of the row is set.
+void pack_weights_dma(const float* w, int ci, int co, int cin_pad, int cout_pad, std::vector<char>& wp) {
+  const int nb = cout_pad / D_BN, nch = cin_pad / D_CH;
+  wp.assign((size_t)nch * nb * D_W_BYTES, 0);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < ci; ++c)
+      for (int n = 0; n < co; ++n) {
+        const int kc = c / D_CH, cc = c % D_CH, h = cc >> 3, e = cc & 7;
+        const int blk = n / D_BN, nl = n % D_BN, wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+        const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+        char* rec = wp.data() + ((size_t)kc * nb + blk) * D_W_BYTES + ((size_t)tap * D_BN + row) * D_REC + ((h ^ ((row >> 3) & 1)) * 16);
+        reinterpret_cast<_Float16*>(rec)[e] = (_Float16)w[((size_t)tap * ci + c) * co + n];
+      }
+}
+// what the LDS-DMA kernel takes: dense or channel-range fp16 tensors whose image fits 31-bit byte offsets, both concat
+// sources with the same pixel stride, whole 16-channel chunks
+inline bool dma_fits(int h, int w, int c0, int c1, int cs0, int cs1) {
+  return c0 % D_CH == 0 && c1 % D_CH == 0 && c0 > 0 && (c1 == 0 || cs0 == cs1) && (double)h * w * cs0 * 2.0 < 2147483648.0;
+}
+
 // N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16,
 // always fp32 output; FISR_DIAG builds: FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
@@ -328,7 +355,7 @@ template <typename T> inline int nt_for(int co) {
 }
 
 template <typename T>
-int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false) {
+int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false) {
   constexpr int CC = Prec<T>::CC;
   cw.nt = nt_for<T>(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
@@ -354,6 +381,13 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false) {
     pack_weights_wino(cw.w.data(), cw.ci, cw.co, cw.cin_pad, wp);
     HIP_OK(ctx, hipMalloc(&cw.d_wu, wp.size()));
     HIP_OK(ctx, hipMemcpy(cw.d_wu, wp.data(), wp.size(), hipMemcpyHostToDevice));
+  }
+  if (cw.d_wd) { (void)hipFree(cw.d_wd); cw.d_wd = nullptr; }
+  if (dma && std::is_same<T, _Float16>::value && cw.co > 32) {
+    cw.cout_pad_d = round_up(cw.co, D_BN);
+    pack_weights_dma(cw.w.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad_d, wp);
+    HIP_OK(ctx, hipMalloc(&cw.d_wd, wp.size()));
+    HIP_OK(ctx, hipMemcpy(cw.d_wd, wp.data(), wp.size(), hipMemcpyHostToDevice));
   }
   if (cw.d_wh) { (void)hipFree(cw.d_wh); cw.d_wh = nullptr; }
   if (wino && std::is_same<T, float>::value && cw.co <= 6) {
@@ -501,6 +535,30 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   } else if (a.relu_in) FISR_W8P_LAUNCH(true, false);
   else FISR_W8P_LAUNCH(false, false);
 #undef FISR_W8P_LAUNCH
+  return hipGetLastError();
+}
+
+// The LDS-DMA fp16 kernel (conv3x3_dma.h; a.wpk = the conv's d_wd, a.CoutPad = its cout_pad_d).
+hipError_t launch_conv_dma(const ConvArgs& a, hipStream_t st) {
+  static bool attr_done[64] = {};
+  constexpr size_t lds = dma_lds_bytes();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    for (const void* k : {reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<false>), reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<true>)}) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    attr_done[dev] = true;
+  }
+  const int d = a.dil;
+  if (d < 1 || (d > 1 && a.d2s) || !dma_fits(a.H, a.W, a.C0, a.C1, a.in0_cs, a.in1_cs)) return hipErrorInvalidValue;
+  const int tiles = (((a.W + d - 1) / d + D_TW - 1) / D_TW) * (((a.H + d - 1) / d + D_TH - 1) / D_TH) * d * d * a.N;
+  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && d == 1;
+  const dim3 grid(tiles * (a.CoutPad / D_BN));
+  if (plain) hipLaunchKernelGGL(conv3x3_dma_f16_kernel<false>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(conv3x3_dma_f16_kernel<true>, grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -654,8 +712,11 @@ struct Runner {
     const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
+    const bool use_dma = std::is_same<T, _Float16>::value && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
+    if (use_dma) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
     char cls[96];
-    if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
+    if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
+    else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
     std::string cname(cls);
@@ -666,7 +727,8 @@ struct Runner {
     }
     ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
                  px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
-    check(use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
+    check(use_dma ? launch_conv_dma(a, st)
+                  : use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
   }
 
   // ops.py:39-44 res_block, in place on X with scratch A.
@@ -937,6 +999,7 @@ void fisr_destroy(fisr_ctx* ctx) {
     if (kv.second.d_b) (void)hipFree(kv.second.d_b);
     if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
     if (kv.second.d_wh) (void)hipFree(kv.second.d_wh);
+    if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
   }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
@@ -979,7 +1042,7 @@ int fisr_num_variables_set(const fisr_ctx* ctx) {
 
 int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_finalize_weights: ctx is NULL");
-  if (!prec_ok(precision) && precision != FISR_PREC_MIXED) return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
+  if (!prec_ok(precision) && precision != FISR_PREC_MIXED && precision != FISR_PREC_MIXEDR) return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
   for (auto& s : all_specs()) {
     const ConvW& cw = ctx->convs[s.name];
     if (!cw.have_w) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/w");
@@ -989,7 +1052,7 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
     const int lp = layer_prec(precision, kv.first);
-    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, lp == FISR_PREC_F32W); });
+    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, lp == FISR_PREC_F32W, lp == FISR_PREC_F16); });
     if (rc) return rc;
     kv.second.prec = lp;
   }
@@ -1002,7 +1065,7 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
 size_t fisr_workspace_bytes(const fisr_ctx* cctx, int n, int h, int w) {
   fisr_ctx* ctx = const_cast<fisr_ctx*>(cctx);
   if (!ctx || !ctx->finalized || n < 1 || h < 32 || w < 32 || h % 32 || w % 32) return 0;
-  if (ctx->precision == FISR_PREC_MIXED) return ws_bytes_mixed(ctx, n, h, w);
+  if (prec_mixed(ctx->precision)) return ws_bytes_mixed(ctx, n, h, w);
   return with_prec(ctx->precision, [&](auto tag) { return ws_bytes_t<decltype(tag)>(ctx, n, h, w); });
 }
 
@@ -1026,7 +1089,7 @@ int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out
     r.ar.base = (char*)workspace; r.ar.cap = workspace_bytes;
     return r.forward(in, n, h, w, out_l3, out_l2, out_l1);
   };
-  if (ctx->precision == FISR_PREC_MIXED) {
+  if (prec_mixed(ctx->precision)) {
     MixedRunner r;
     r.lo.ctx = r.hi.ctx = ctx; r.lo.st = r.hi.st = st;
     r.lo.ar.base = (char*)workspace; r.lo.ar.cap = workspace_bytes;
@@ -1176,7 +1239,9 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   }
   if (out_f32 && (res || (flags & FISR_CONV_D2S)))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: the fp32-output store has no residual / d2s");
-  if (c0 % cc || c1 % cc || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
+  // (FISR_PREC_F16: the LDS-DMA kernel, which takes the convolutions with Cout > 32, works in 16-channel chunks)
+  const bool dma_op = precision == FISR_PREC_F16 && cout > 32 && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
+  if (((c0 % cc || c1 % cc) && !dma_op) || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
   if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4) || cout / 4 < CONV_REC))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two >= 16 (whole 16-channel records)");
   DeviceGuard guard(device_of(out));
@@ -1185,12 +1250,13 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
   cw.b.assign(b_host, b_host + cout);
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W, precision == FISR_PREC_F16); });
   if (rc) return rc;
   const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cout);
+  const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = res; a.out = out;
-  a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
+  a.in0 = in0; a.in1 = in1; a.wpk = use_dma ? cw.d_wd : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
+  a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
@@ -1200,7 +1266,8 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   hipStream_t st = (hipStream_t)stream;
   // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)
   const bool use_head = precision == FISR_PREC_F32W && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
-  hipError_t e = use_wino ? launch_conv_wino(a, st)
+  hipError_t e = use_dma ? launch_conv_dma(a, st)
+                 : use_wino ? launch_conv_wino(a, st)
                  : use_head ? launch_head_valu(a, cw.d_wh, st)
                             : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
   hipError_t e2 = hipStreamSynchronize(st);
@@ -1208,6 +1275,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   (void)hipFree(cw.d_b);
   if (cw.d_wu) (void)hipFree(cw.d_wu);
   if (cw.d_wh) (void)hipFree(cw.d_wh);
+  if (cw.d_wd) (void)hipFree(cw.d_wd);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv sync: ") + hipGetErrorString(e2));
   return 0;
@@ -1253,7 +1321,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   if (!prec_ok(precision) || !out_us || iters < 1) return fail(nullptr, FISR_EINVAL, "fisr_bench_conv: bad argument");
   const int cc = prec_chunk(precision);
   if (cin % cc || cout % 8) return fail(nullptr, FISR_EINVAL, "fisr_bench_conv: channels must be whole chunks");
-  const size_t abytes = precision == FISR_PREC_F16 ? 2 : 4;
+  const size_t abytes = precision == FISR_PREC_F16 || precision == FISR_PREC_F16R ? 2 : 4;
   const size_t in_b = (size_t)n * h * w * cin * abytes, out_b = (size_t)n * h * w * cout * abytes;
   ConvW cw;
   cw.ci = cin; cw.co = cout;
@@ -1261,9 +1329,10 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   cw.b.assign(cout, 0.01f);
   uint32_t st = 12345u;
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W, precision == FISR_PREC_F16); });
   if (rc) return rc;
   const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
+  const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && dma_fits(h, w, cin, 0, cin, 0);
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
   HIP_OK(nullptr, hipMalloc(&d_out, out_b));
@@ -1280,8 +1349,8 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
         HIP_OK(nullptr, hipMemcpy((char*)d_res + o, hbuf.data(), std::min(hbuf.size() * 2, out_b - o), hipMemcpyHostToDevice));
   }
   ConvArgs a;
-  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_wino ? cw.d_wu : cw.d_w; a.bias = cw.d_b; a.res = d_res; a.out = d_out;
-  a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = cw.cout_pad;
+  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma ? cw.d_wd : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
+  a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
@@ -1289,8 +1358,9 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   unsigned long long* d_trace = nullptr;
-  const size_t nblocks = (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
-                         (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
+  const size_t nblocks = use_dma ? (size_t)(((w + D_TW - 1) / D_TW) * ((h + D_TH - 1) / D_TH) * n) * (cw.cout_pad_d / D_BN)
+                                 : (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
+                                       (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
   if (trace_file) {
     HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 64));
     HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 64));
@@ -1301,6 +1371,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   HIP_OK(nullptr, hipEventCreate(&e1));
   hipError_t e = hipSuccess;
   auto launch = [&]() -> hipError_t {
+    if (use_dma) return launch_conv_dma(a, nullptr);
     if (use_wino) return launch_conv_wino(a, nullptr);
     return with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
   };
@@ -1321,7 +1392,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
-  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wh) (void)hipFree(cw.d_wh);
+  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wh) (void)hipFree(cw.d_wh); if (cw.d_wd) (void)hipFree(cw.d_wd);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
   return 0;
 }

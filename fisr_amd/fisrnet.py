@@ -34,13 +34,14 @@ from .lib import FisrError
 _PREC = {"fp32": _lib.PREC_F32W, "f32": _lib.PREC_F32W, "float32": _lib.PREC_F32W, "fp32w": _lib.PREC_F32W,
          "fp32d": _lib.PREC_F32,
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
-         "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8, "mixed": _lib.PREC_MIXED}
+         "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8, "mixed": _lib.PREC_MIXED,
+         "fp16r": _lib.PREC_F16R, "mixedr": _lib.PREC_MIXEDR}          # round 1's register-staged fp16 kernel (A/B runs)
 
 
 # ONE default arithmetic for every entry point (FISRnet(), main.py, bench.py): the reference computes in
 # fp32 (cfg2 of BASELINE.json), so the default is the fp32 engine; the split-precision modes are opt-in.
 DEFAULT_PRECISION = "fp32"
-PRECISIONS = ("fp32", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16")     # CLI names
+PRECISIONS = ("fp32", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16", "fp16r", "mixedr")     # CLI names
 
 
 def _torch():

@@ -61,12 +61,16 @@ enum {
                           activation format changes twice, on 1/16-size tensors.  PSNR shift of the SR channel against
                           the fp64 oracle <= 0.005 dB on the three weight sets of tests/, 0.007 dB on the worst of 30
                           full-size windows (all-fp16: 0.026 dB, outside north_star's +-0.02 dB). */
-  FISR_PREC_F16F8 = 3  /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels
+  FISR_PREC_F16F8 = 3, /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels
                           16 x fp16 h (32 B), 16 x fp8-e4m3 l8 (16 B), 16 x fp8-e4m3 copy of h (16 B).
                           Product = a_h*w_h (v_mfma_f32_32x32x16_f16) + both cross terms in ONE
                           block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per pair of taps: ~2^-15
                           relative per product at 2.1 instead of 3 MFMA-units (fp32 accumulate).  Values beyond
                           the fp16 range saturate to +-65504 when stored (no inf). */
+  FISR_PREC_F16R = 6,  /* FISR_PREC_F16 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h);
+                          FISR_PREC_F16 itself runs the convolutions with Cout > 32 on the LDS-DMA kernel (conv3x3_dma.h: same
+                          products, another summation order inside a chunk -> results agree to fp32 rounding).  For A/B runs. */
+  FISR_PREC_MIXEDR = 7 /* engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
 };
 
 /* flags of fisr_op_conv3x3 */

@@ -21,7 +21,7 @@ SHAPES = [  # n, h, w, cin, cout, flags, res
 ]
 if os.environ.get("CONV_SHAPES"):   # "n,h,w,cin,cout,flags,res;..."
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["CONV_SHAPES"].split(";")]
-PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}
+PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4, "fp16r": 6}
 L = lib.lib()
 for prec in (sys.argv[1:] or ["bf16x3"]):
     for (n, h, w, ci, co, fl, rs) in SHAPES:
@@ -32,7 +32,7 @@ for prec in (sys.argv[1:] or ["bf16x3"]):
             print(prec, (n, h, w, ci, co), "ERR", L.fisr_last_error(None))
             continue
         fl_ = 2.0 * 9 * ci * co * n * h * w
-        ab = 2 if prec == "fp16" else 4
+        ab = 2 if prec.startswith("fp16") else 4
         by = n * h * w * (ci * 1.0 + co * (2 if rs else 1)) * ab
         print(f"{os.environ.get('TAG', '')} {prec:7s} {n:2d}x{h}x{w} {ci:3d}->{co:3d} f{fl} r{rs}: {us.value:9.1f} us  {fl_ / us.value / 1e6:7.1f} TF  "
               f"alg {by / us.value / 1e3:6.0f} GB/s")
