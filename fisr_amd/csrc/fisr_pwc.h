@@ -48,9 +48,11 @@ struct PwcVar {
 };
 
 struct PwcConv {                 // one packed convolution
-  float* d_w = nullptr; float* d_b = nullptr;
-  char* d_wu = nullptr;          // Winograd slabs for conv3x3_wino8p_kernel (stride 1, dilation 1, Cout >= 32 only)
-  ConvW dw;                      // FISRnet's direct fp32 kernel (stride 1, dilation 1, Cout < 32: flow heads, level 1)
+  float* d_w = nullptr; float* d_b = nullptr;     // generic implicit-GEMM kernel (fp32 weights, any stride / dilation)
+  char* d_wu = nullptr;          // fp32 engine: Winograd slabs for conv3x3_wino8p_kernel (stride 1, Cout >= 32)
+  void* d_wd = nullptr;          // fp16 engine: weight slabs of the LDS-DMA kernel conv3x3_dma.h (stride 1, Cout >= 16)
+  int cout_pad_d = 0;
+  ConvW dw;                      // FISRnet's direct kernel in the engine's arithmetic (stride 1, dilation 1: the 2-channel flow heads; fp32: also level 1)
   bool have_dw = false;
   int cin_buf = 0, cout = 0, cout_pad = 0;
 };
@@ -61,6 +63,7 @@ struct PwcDeconv { float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0; };
 struct fisr_pwc {
   int dev = 0;
   bool finalized = false;
+  int precision = FISR_PREC_F32W;  // FISR_PREC_F32W: fp32 tensors and arithmetic (Winograd for the dense layers); FISR_PREC_F16: fp16 features
   std::map<std::string, PwcVar> vars;
   std::map<std::string, PwcConv> convs;
   std::map<std::string, PwcDeconv> deconvs;
@@ -123,29 +126,44 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
   HIP_OK(nullptr, hipMalloc((void**)&pc.d_b, bp.size() * 4));
   HIP_OK(nullptr, hipMemcpy(pc.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(nullptr, hipMemcpy(pc.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
-  // The stride-1, dilation-1 layers with 32 or more output channels (the dense flow estimators, the first and sixth
-  // context convs: 85 % of the network's FLOPs) also get FISRnet's Winograd slabs: G g G^T of the kernel scattered to
-  // the buffer channels it reads.
-  const bool as_wino = wino && co >= 32 && co % 16 == 0 && cin_buf >= 32 && cin_buf % W_CH == 0;
-  // ... and the ones with fewer (the 2-channel flow heads, which the 64-wide generic kernel computes 32 times over,
-  // and the 16-channel level-1 features) the weights of FISRnet's direct kernel (16- and 32-wide N blocks).
-  const bool as_direct = wino && !as_wino && co < 32 && cin_buf % 16 == 0;
-  if (as_wino || as_direct) {
-    std::vector<float> dense((size_t)9 * cin_buf * co, 0.f);
-    for (int tap = 0; tap < 9; ++tap)
-      for (int j = 0; j < ci; ++j)
-        for (int n = 0; n < co; ++n) dense[((size_t)tap * cin_buf + chmap[j]) * co + n] = kw.v[((size_t)tap * ci + j) * co + n];
-    if (as_wino) {
-      std::vector<char> wu;
-      pack_weights_wino(dense.data(), cin_buf, co, cin_buf, wu);
-      HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu, wu.size()));
-      HIP_OK(nullptr, hipMemcpy(pc.d_wu, wu.data(), wu.size(), hipMemcpyHostToDevice));
-    } else {
+  if (!wino) return 0;
+  // the same kernel scattered to the buffer channels it reads, for FISRnet's fast kernels
+  std::vector<float> dense((size_t)9 * cin_buf * co, 0.f);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int j = 0; j < ci; ++j)
+      for (int n = 0; n < co; ++n) dense[((size_t)tap * cin_buf + chmap[j]) * co + n] = kw.v[((size_t)tap * ci + j) * co + n];
+  if (ctx->precision == FISR_PREC_F16) {
+    // fp16 engine: every stride-1 layer with 16 or more output channels (any dilation) on the LDS-DMA kernel; the 2-channel flow
+    // heads on FISRnet's 16-row direct kernel with fp32 output
+    if (co >= 16 && co % 16 == 0 && cin_buf % D_CH == 0) {
+      std::vector<char> wd;
+      pc.cout_pad_d = round_up(co, D_BN);
+      pack_weights_dma(dense.data(), cin_buf, co, cin_buf, pc.cout_pad_d, wd);
+      HIP_OK(nullptr, hipMalloc(&pc.d_wd, wd.size()));
+      HIP_OK(nullptr, hipMemcpy(pc.d_wd, wd.data(), wd.size(), hipMemcpyHostToDevice));
+    } else if (co < 16 && cin_buf % 32 == 0) {
       pc.dw.ci = cin_buf; pc.dw.co = co; pc.dw.w = std::move(dense); pc.dw.b = kb.v;
-      int rc = upload_conv<float>(nullptr, pc.dw, false);
+      int rc = upload_conv<_Float16>(nullptr, pc.dw, false, false);
       if (rc) return rc;
       pc.have_dw = true;
     }
+    return 0;
+  }
+  // fp32 engine: the stride-1 layers with 32 or more output channels (the dense flow estimators, the context convs incl. the
+  // dilated ones: 97 % of the network's FLOPs) get FISRnet's Winograd slabs, the ones with fewer (the 2-channel flow heads, which
+  // the 64-wide generic kernel computes 32 times over, and the 16-channel level-1 features) the weights of its direct kernel
+  const bool as_wino = co >= 32 && co % 16 == 0 && cin_buf >= 32 && cin_buf % W_CH == 0;
+  const bool as_direct = !as_wino && co < 32 && cin_buf % 16 == 0;
+  if (as_wino) {
+    std::vector<char> wu;
+    pack_weights_wino(dense.data(), cin_buf, co, cin_buf, wu);
+    HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu, wu.size()));
+    HIP_OK(nullptr, hipMemcpy(pc.d_wu, wu.data(), wu.size(), hipMemcpyHostToDevice));
+  } else if (as_direct) {
+    pc.dw.ci = cin_buf; pc.dw.co = co; pc.dw.w = std::move(dense); pc.dw.b = kb.v;
+    int rc = upload_conv<float>(nullptr, pc.dw, false);
+    if (rc) return rc;
+    pc.have_dw = true;
   }
   return 0;
 }
@@ -167,173 +185,282 @@ int pwc_pack_deconv(fisr_pwc* ctx, const std::string& name, const std::vector<in
   return 0;
 }
 
-hipError_t launch_costvol(const float* c1, const float* c2, int C, float* out, int out_cs, int out_co, int n, int h, int w, hipStream_t st) {
+inline PwcItems identity_items(int n) { PwcItems it; it.n = n; for (int i = 0; i < PWC_MAX_ITEMS; ++i) it.a[i] = it.b[i] = i < n ? i : 0; return it; }
+inline PwcItems swapped(const PwcItems& x) { PwcItems it = x; for (int i = 0; i < PWC_MAX_ITEMS; ++i) { it.a[i] = x.b[i]; it.b[i] = x.a[i]; } return it; }
+
+template <typename TE>
+hipError_t launch_costvol(const TE* c1, int c1_cs, int c1_co, const PwcItems& c1_img, const TE* c2, const PwcItems& c2_img, int C, TE* out,
+                          int out_cs, int out_co, int n, int h, int w, hipStream_t st) {
   static bool cv_attr[64] = {};
   int dev = 0; (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !cv_attr[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_costvol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_costvol_kernel<TE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)costvol_lds_bytes());
     if (e != hipSuccess) return e;
     cv_attr[dev] = true;
   }
   const int cv_tiles = ((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n;
-  hipLaunchKernelGGL(pwc_costvol_kernel, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, c2, C, out, out_cs, out_co, n, h, w);
+  hipLaunchKernelGGL(pwc_costvol_kernel<TE>, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, c1_cs, c1_co, c1_img, c2, c2_img, C, out,
+                     out_cs, out_co, n, h, w);
   return hipGetLastError();
 }
 
 std::vector<int> iota_map(int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; }
 
+// float32 [n] -> TE [n] (the network entry fisr_pwc_nn takes a float32 image pair)
+template <typename TE>
+__global__ void pwc_cast_kernel(const float* __restrict__ src, TE* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    PwcElem<TE>::st4(dst + 4 * i, reinterpret_cast<const f32x4*>(src)[i]);
+}
+
+// The flow network on feature tensors of element type TE (float: the exact engine; _Float16: FISR_PREC_F16).  Flows -- the
+// outputs of the flow heads, the refined flows handed to the next level and to the caller -- are float32 in both.
+template <typename TE>
 struct PwcRunner {
   fisr_pwc* ctx; hipStream_t st; Arena ar; int rc = 0;
+  static constexpr bool HALF = std::is_same<TE, _Float16>::value;
+  TE* ealloc(size_t n) { return (TE*)ar.alloc(n * sizeof(TE)); }
   float* falloc(size_t n) { return (float*)ar.alloc(n * sizeof(float)); }
   void check(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string(what) + ": " + hipGetErrorString(e));
   }
-  void zero(float* p, size_t n) { if (!ar.dry && !rc) (void)hipMemsetAsync(p, 0, n * sizeof(float), st); }
-  // which kernel runs a layer: 2 = FISRnet's persistent Winograd kernel (stride 1, Cout >= 32, any dilation), 3 = FISRnet's
-  // direct kernel (stride 1, dilation 1, Cout < 32), 1 = the generic implicit GEMM (stride 2, the residual dc_conv7)
-  int conv_route(const std::string& name, int n, int h, int w, int in_cs, int out_cs, int stride, int dil, float slope, bool has_add) {
+  void zero(void* p, size_t bytes) { if (!ar.dry && !rc) (void)hipMemsetAsync(p, 0, bytes, st); }
+
+  // which kernel runs a layer: 2 = FISRnet's persistent fp32 Winograd kernel (stride 1, Cout >= 32, any dilation), 4 = its fp16
+  // LDS-DMA kernel (stride 1, Cout >= 16, any dilation), 3 = its direct kernel (stride 1, dilation 1: the 2-channel flow heads;
+  // fp32 engine: also the 16-channel level-1 features), 1 = the generic implicit GEMM (stride 2, the residual dc_conv7)
+  int conv_route(const std::string& name, int n, int h, int w, int in_cs, int out_cs, bool out_f32, int stride, int dil, float slope, bool has_add) {
     const PwcConv& pc = ctx->convs[name];
     const bool act_ok = slope == 1.f || (slope > 0.f && slope < 1.f);
-    if (pc.d_wu && stride == 1 && !has_add && act_ok && wino_fits(n, h, w, in_cs, 0, out_cs)) return 2;
+    if (HALF) {
+      if (pc.d_wd && stride == 1 && !has_add && !out_f32 && act_ok && dma_fits(h, w, pc.cin_buf, 0, in_cs, 0)) return 4;
+      if (pc.have_dw && stride == 1 && dil == 1 && !has_add && out_f32 && act_ok) return 3;
+      return 1;
+    }
+    (void)n;
+    if (pc.d_wu && stride == 1 && !has_add && act_ok && wino_fits(1, h, w, in_cs, 0, out_cs)) return 2;
     if (pc.have_dw && stride == 1 && dil == 1 && !has_add && act_ok) return 3;
     return 1;
   }
-  void conv(const std::string& name, const float* in, int in_cs, int in_co, float* out, int out_cs, int out_co,
+  // out: TE (out_f32 = false) or float32 (out_f32 = true: the flow heads and dc_conv7); add: float32
+  void conv(const std::string& name, const TE* in, int in_cs, int in_co, void* out, bool out_f32, int out_cs, int out_co,
             int n, int h, int w, int stride, int dil, float slope, const float* add = nullptr, int add_cs = 0, int add_co = 0) {
     if (rc || ar.dry) return;
+    if (!HALF) out_f32 = true;
     const PwcConv& pc = ctx->convs[name];
-    const int route = conv_route(name, n, h, w, in_cs, out_cs, stride, dil, slope, add != nullptr);
-    if (route == 2) {
-      // FISRnet's persistent Winograd kernel on a channel range of the buffer (fisr_api.hip: launch_conv_wino)
-      ConvArgs a;
-      a.in0 = in + in_co; a.in1 = nullptr; a.wpk = pc.d_wu; a.bias = pc.d_b; a.res = nullptr; a.out = out;
-      a.C0 = pc.cin_buf; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = pc.cout; a.CoutPad = round_up(pc.cout, W_BN);
-      a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
-      a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
-      a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = out_cs; a.rec_co = out_co; a.slope = slope != 1.f ? slope : 0.f;
-      a.dil = dil; a.trace = nullptr;
-      hipError_t e = launch_conv_wino(a, st);
-      if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (winograd): " + hipGetErrorString(e));
+    const int route = conv_route(name, n, h, w, in_cs, out_cs, HALF ? out_f32 : false, stride, dil, slope, add != nullptr);
+    ConvArgs a;
+    a.in0 = in + in_co; a.in1 = nullptr; a.bias = pc.d_b; a.res = nullptr; a.out = out;
+    a.N = n; a.H = h; a.W = w; a.Cout = pc.cout;
+    a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
+    a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
+    a.in0_cs = in_cs; a.in1_cs = 0; a.slope = slope != 1.f ? slope : 0.f; a.trace = nullptr;
+    if (route == 2 || route == 4) {
+      // FISRnet's persistent Winograd kernel / LDS-DMA kernel on a channel range of the buffer
+      a.wpk = route == 2 ? (const void*)pc.d_wu : pc.d_wd;
+      a.C0 = pc.cin_buf; a.C1 = 0; a.CoutPad = route == 2 ? round_up(pc.cout, W_BN) : pc.cout_pad_d;
+      a.rec_cs = out_cs; a.rec_co = out_co; a.dil = dil;
+      hipError_t e = hipSuccess;
+      if (route == 4) e = launch_conv_dma(a, st);
+      else if (wino_fits(n, h, w, in_cs, 0, out_cs)) e = launch_conv_wino(a, st);
+      else {
+        // the Winograd kernel addresses its whole input batch with 32-bit byte offsets: one image per launch when the batch is too big
+        a.N = 1;
+        for (int k = 0; k < n && e == hipSuccess; ++k) {
+          a.in0 = in + in_co + (size_t)k * h * w * in_cs;
+          a.out = (float*)out + (size_t)k * h * w * out_cs;
+          e = launch_conv_wino(a, st);
+        }
+      }
+      if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + (route == 2 ? " (winograd): " : " (lds-dma): ") + hipGetErrorString(e));
       return;
     }
     if (route == 3) {
-      ConvArgs a;
-      a.in0 = in + in_co; a.in1 = nullptr; a.wpk = pc.dw.d_w; a.bias = pc.dw.d_b; a.res = nullptr; a.out = out;
-      a.C0 = pc.dw.cin_pad; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = pc.cout; a.CoutPad = pc.dw.cout_pad;
-      a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
-      a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
-      a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = pc.cout; a.rec_co = 0; a.slope = slope != 1.f ? slope : 0.f;
-      a.dil = 1; a.trace = nullptr;
-      const bool scatter = !(out_cs == pc.cout && out_co == 0);     // dense records, or per-channel fp32 stores
-      hipError_t e = launch_conv<float>(a, pc.dw.nt, scatter, st);
+      a.wpk = pc.dw.d_w; a.bias = pc.dw.d_b;
+      a.C0 = pc.dw.cin_pad; a.C1 = 0; a.CoutPad = pc.dw.cout_pad;
+      a.rec_cs = pc.cout; a.rec_co = 0; a.dil = 1;
+      const bool scatter = HALF || !(out_cs == pc.cout && out_co == 0);     // dense records, or per-channel fp32 stores
+      hipError_t e = launch_conv<TE>(a, pc.dw.nt, scatter, st);
       if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (direct): " + hipGetErrorString(e));
       return;
     }
     static bool attr_done[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_convg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)convg_lds_bytes());
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_convg_kernel<TE, TE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)convg_lds_bytes());
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_convg_kernel<TE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)convg_lds_bytes());
       if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
-    ConvGArgs a;
-    a.in = in; a.in_cs = in_cs; a.in_co = in_co; a.Cin = pc.cin_buf; a.w = pc.d_w; a.bias = pc.d_b;
-    a.out = out; a.out_cs = out_cs; a.out_co = out_co; a.Cout = pc.cout; a.CoutPad = pc.cout_pad;
-    a.add = add; a.add_cs = add_cs; a.add_co = add_co;
-    a.N = n; a.H = h; a.W = w; a.stride = stride; a.dil = dil; a.slope = slope;
-    a.OH = (h + stride - 1) / stride; a.OW = (w + stride - 1) / stride;
-    const int tot_h = std::max((a.OH - 1) * stride + 2 * dil + 1 - h, 0), tot_w = std::max((a.OW - 1) * stride + 2 * dil + 1 - w, 0);
-    a.pad_t = tot_h / 2; a.pad_l = tot_w / 2;                      // TF 'SAME': the smaller half goes first
-    const int tiles = ((a.OW + TILE_W - 1) / TILE_W) * ((a.OH + TILE_H - 1) / TILE_H) * n;
-    hipLaunchKernelGGL(pwc_convg_kernel, dim3(tiles * (pc.cout_pad / G_BN)), dim3(256), convg_lds_bytes(), st, a);
+    ConvGArgs g;
+    g.in = in; g.in_cs = in_cs; g.in_co = in_co; g.Cin = pc.cin_buf; g.w = pc.d_w; g.bias = pc.d_b;
+    g.out = out; g.out_cs = out_cs; g.out_co = out_co; g.Cout = pc.cout; g.CoutPad = pc.cout_pad;
+    g.add = add; g.add_cs = add_cs; g.add_co = add_co;
+    g.N = n; g.H = h; g.W = w; g.stride = stride; g.dil = dil; g.slope = slope;
+    g.OH = (h + stride - 1) / stride; g.OW = (w + stride - 1) / stride;
+    const int tot_h = std::max((g.OH - 1) * stride + 2 * dil + 1 - h, 0), tot_w = std::max((g.OW - 1) * stride + 2 * dil + 1 - w, 0);
+    g.pad_t = tot_h / 2; g.pad_l = tot_w / 2;                      // TF 'SAME': the smaller half goes first
+    const int tiles = ((g.OW + TILE_W - 1) / TILE_W) * ((g.OH + TILE_H - 1) / TILE_H) * n;
+    if (out_f32) hipLaunchKernelGGL((pwc_convg_kernel<TE, float>), dim3(tiles * (pc.cout_pad / G_BN)), dim3(256), convg_lds_bytes(), st, g);
+    else hipLaunchKernelGGL((pwc_convg_kernel<TE, TE>), dim3(tiles * (pc.cout_pad / G_BN)), dim3(256), convg_lds_bytes(), st, g);
     check(name.c_str());
   }
-  void deconv(const std::string& name, const float* in, int in_cs, int in_co, float* out, int out_cs, int out_co, int n, int h, int w) {
+  template <typename TI>
+  void deconv(const std::string& name, const TI* in, int in_cs, int in_co, TE* out, int out_cs, int out_co, int n, int h, int w) {
     if (rc || ar.dry) return;
     const PwcDeconv& pd = ctx->deconvs[name];
-    hipLaunchKernelGGL(pwc_deconv_kernel, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
+    hipLaunchKernelGGL((pwc_deconv_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
                        pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w);
     check(name.c_str());
   }
 
-  // model_pwcnet.py:1525-1593 on a pre-processed pair.  im: [2, H, W, 4] (image a, image b; RGB/255 + a zero channel),
-  // H, W multiples of 64.  flow2[d]: refined level-2 flow of direction d (0: a->b, 1: b->a), [H/4, W/4] x stride 4 floats.
-  // pyr_out[d][k] (nullable): refined flows of levels 6..2, [h_l, w_l, 2] dense.
-  int nn(const float* im, int H, int W, float* flow2[2], float* const* pyr_out) {
-    float* F[7];
-    F[0] = const_cast<float*>(im);
-    int hh[7], ww[7];
+  int hh[7], ww[7];
+  TE* F[7];
+
+  // extract_features (model_pwcnet.py:1012-1101) of nf prepared frames at once: im [nf, H, W, 4] (RGB / 255 + a zero channel;
+  // H, W multiples of 64) -> F[1..6] [nf, H/2^l, W/2^l, C_l]
+  void pyramid(const TE* im, int nf, int H, int W) {
+    F[0] = const_cast<TE*>(im);
     hh[0] = H; ww[0] = W;
-    for (int l = 1; l <= PWC_LVLS; ++l) {                            // extract_features :1012-1101, both images at once
+    for (int l = 1; l <= PWC_LVLS; ++l) {
       hh[l] = hh[l - 1] / 2; ww[l] = ww[l - 1] / 2;
-      const size_t px = (size_t)2 * hh[l] * ww[l];
-      float* A = falloc(px * PWC_CH[l]); float* B = falloc(px * PWC_CH[l]); F[l] = falloc(px * PWC_CH[l]);
+      const size_t px = (size_t)nf * hh[l] * ww[l];
+      const size_t mark = ar.off;
+      F[l] = ealloc(px * PWC_CH[l]);
+      const size_t keep = ar.off;
+      TE* A = ealloc(px * PWC_CH[l]); TE* B = ealloc(px * PWC_CH[l]);
       const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
-      conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, PWC_CH[l], 0, 2, hh[l - 1], ww[l - 1], 2, 1, 0.1f);
-      conv(p + "aa", A, PWC_CH[l], 0, B, PWC_CH[l], 0, 2, hh[l], ww[l], 1, 1, 0.1f);
-      conv(p + "b", B, PWC_CH[l], 0, F[l], PWC_CH[l], 0, 2, hh[l], ww[l], 1, 1, 0.1f);
+      conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, false, PWC_CH[l], 0, nf, hh[l - 1], ww[l - 1], 2, 1, 0.1f);
+      conv(p + "aa", A, PWC_CH[l], 0, B, false, PWC_CH[l], 0, nf, hh[l], ww[l], 1, 1, 0.1f);
+      conv(p + "b", B, PWC_CH[l], 0, F[l], false, PWC_CH[l], 0, nf, hh[l], ww[l], 1, 1, 0.1f);
+      (void)mark;
+      ar.off = keep;                                       // the two temporaries of a level are dead once its features exist
     }
-    for (int d = 0; d < 2; ++d) {
-      float* Dprev = nullptr; int prev_total = 0;
-      float* flow_prev = nullptr;
-      for (int l = PWC_LVLS; l >= PWC_PRED; --l) {
-        const DecLayout L(l);
-        const int h = hh[l], w = ww[l];
-        const size_t px = (size_t)h * w;
-        const float* c1 = F[l] + (size_t)d * px * PWC_CH[l];
-        const float* c2 = F[l] + (size_t)(1 - d) * px * PWC_CH[l];
-        float* D = falloc(px * L.total);
-        zero(D, px * L.total);                                       // channel padding must read as finite zeros
-        const std::string ls = std::to_string(l);
-        const float* cv2 = c2;
-        if (l != PWC_LVLS) {
-          // up-sampled flow / features of the level above land directly in this level's buffer (:1577-1578, :1424)
-          deconv("pwcnet/upsample/up_flow" + std::to_string(l + 1), flow_prev, 4, 0, D, L.total, L.off_upflow, 1, hh[l + 1], ww[l + 1]);
-          deconv("pwcnet/upsample/up_feat" + std::to_string(l + 1), Dprev, prev_total, 0, D, L.total, L.off_upfeat, 1, hh[l + 1], ww[l + 1]);
-          float* Wp = falloc(px * PWC_CH[l]);
-          if (!rc && !ar.dry) {
-            hipLaunchKernelGGL(pwc_warp_kernel, dim3(grid_for(px * PWC_CH[l] / 4)), dim3(256), 0, st, c2, PWC_CH[l], D, L.total,
-                               L.off_upflow, 20.f / (float)(1 << l), Wp, 1, h, w);      // :1560-1561
-            check("warp");
-            hipLaunchKernelGGL(pwc_copy_channels_kernel, dim3(grid_for(px * PWC_CH[l] / 4)), dim3(256), 0, st, c1, PWC_CH[l], D,
-                               L.total, L.off_c1, px);
-            check("copy c1");
-          }
-          cv2 = Wp;
-        }
+  }
+
+  // The coarse-to-fine decoder (model_pwcnet.py:1546-1593) for items.n (frame a, frame b) items at once (batch axis = item).
+  // flow2: refined level-2 flows [items.n, H/4, W/4] x stride 4 floats.  pyr_out (nullable): 5 pointers per item, the refined
+  // flows of levels 6..2 as dense [h_l, w_l, 2].
+  int decode(const PwcItems& items, float** flow2, float* const* pyr_out) {
+    const int N = items.n;
+    const PwcItems ident = identity_items(N), items_b = swapped(items);
+    TE* Dprev = nullptr; int prev_total = 0;
+    float* flow_prev = nullptr;
+    for (int l = PWC_LVLS; l >= PWC_PRED; --l) {
+      const DecLayout L(l);
+      const int h = hh[l], w = ww[l];
+      const size_t px = (size_t)h * w, npx = px * N;
+      TE* D = ealloc(npx * L.total);
+      zero(D, npx * L.total * sizeof(TE));                           // channel padding must read as finite zeros
+      const std::string ls = std::to_string(l);
+      if (l != PWC_LVLS) {
+        // up-sampled flow / features of the level above land directly in this level's buffer (:1577-1578, :1424)
+        deconv<float>("pwcnet/upsample/up_flow" + std::to_string(l + 1), flow_prev, 4, 0, D, L.total, L.off_upflow, N, hh[l + 1], ww[l + 1]);
+        deconv<TE>("pwcnet/upsample/up_feat" + std::to_string(l + 1), Dprev, prev_total, 0, D, L.total, L.off_upfeat, N, hh[l + 1], ww[l + 1]);
+        TE* Wp = ealloc(npx * PWC_CH[l]);
         if (!rc && !ar.dry) {
-          hipError_t e = launch_costvol(c1, cv2, PWC_CH[l], D, L.total, L.off_corr, 1, h, w, st);   // :1277 (leaky relu inside core_costvol)
+          hipLaunchKernelGGL(pwc_warp_kernel<TE>, dim3(grid_for(npx * PWC_CH[l] / 4)), dim3(256), 0, st, F[l], items_b, PWC_CH[l], D, L.total,
+                             L.off_upflow, 20.f / (float)(1 << l), Wp, N, h, w);      // :1560-1561: warp the features of frame b
+          check("warp");
+          hipLaunchKernelGGL(pwc_copy_channels_kernel<TE>, dim3(grid_for(npx * PWC_CH[l] / 4)), dim3(256), 0, st, F[l], items, PWC_CH[l], D,
+                             L.total, L.off_c1, px, N);
+          check("copy c1");
+          hipError_t e = launch_costvol<TE>(D, L.total, L.off_c1, ident, Wp, ident, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st);   // :1277
           if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string("cost volume: ") + hipGetErrorString(e));
         }
-        for (int i = 0; i < 5; ++i)                                  // predict_flow :1426-1445 (dense connections)
-          conv("pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i), D, L.total, i == 0 ? L.off_corr : L.off_act[i - 1],
-               D, L.total, L.off_act[i], 1, h, w, 1, 1, 0.1f);
-        float* flow = falloc(px * 4); zero(flow, px * 4);
-        conv("pwcnet/predict_flow/flow" + ls, D, L.total, 0, flow, 4, 0, 1, h, w, 1, 1, 1.f);           // :1447
-        float* T1 = falloc(px * 128); float* T2 = falloc(px * 128);
-        const float* src = D; int src_cs = L.total;                  // refine_flow :1506-1521
-        for (int i = 0; i < 7; ++i) {
-          const std::string cn = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
-          float* dst = (i & 1) ? T2 : T1;
-          if (i < 6) {
-            conv(cn, src, src_cs, 0, dst, PWC_CTXT[i][0], 0, 1, h, w, 1, PWC_CTXT[i][1], 0.1f);
-            src = dst; src_cs = PWC_CTXT[i][0];
-          } else {
-            float* refined = falloc(px * 4); zero(refined, px * 4);
-            conv(cn, src, src_cs, 0, refined, 4, 0, 1, h, w, 1, 1, 1.f, flow, 4, 0);
-            flow_prev = refined;
-          }
-        }
-        if (pyr_out && pyr_out[d * 5 + (PWC_LVLS - l)] && !rc && !ar.dry)
-          hipLaunchKernelGGL(stitch_free_copy2_kernel, dim3(grid_for(px)), dim3(256), 0, st, flow_prev, pyr_out[d * 5 + (PWC_LVLS - l)], px);
-        Dprev = D; prev_total = L.total;
+      } else if (!rc && !ar.dry) {
+        hipError_t e = launch_costvol<TE>(F[l], PWC_CH[l], 0, items, F[l], items_b, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st);
+        if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string("cost volume: ") + hipGetErrorString(e));
       }
-      flow2[d] = flow_prev;
+      for (int i = 0; i < 5; ++i)                                  // predict_flow :1426-1445 (dense connections)
+        conv("pwcnet/predict_flow/conv" + ls + "_" + std::to_string(i), D, L.total, i == 0 ? L.off_corr : L.off_act[i - 1],
+             D, false, L.total, L.off_act[i], N, h, w, 1, 1, 0.1f);
+      float* flow = falloc(npx * 4); zero(flow, npx * 4 * sizeof(float));
+      conv("pwcnet/predict_flow/flow" + ls, D, L.total, 0, flow, true, 4, 0, N, h, w, 1, 1, 1.f);           // :1447
+      TE* T1 = ealloc(npx * 128); TE* T2 = ealloc(npx * 128);
+      const TE* src = D; int src_cs = L.total;                     // refine_flow :1506-1521
+      for (int i = 0; i < 7; ++i) {
+        const std::string cn = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
+        TE* dst = (i & 1) ? T2 : T1;
+        if (i < 6) {
+          conv(cn, src, src_cs, 0, dst, false, PWC_CTXT[i][0], 0, N, h, w, 1, PWC_CTXT[i][1], 0.1f);
+          src = dst; src_cs = PWC_CTXT[i][0];
+        } else {
+          float* refined = falloc(npx * 4); zero(refined, npx * 4 * sizeof(float));
+          conv(cn, src, src_cs, 0, refined, true, 4, 0, N, h, w, 1, 1, 1.f, flow, 4, 0);
+          flow_prev = refined;
+        }
+      }
+      if (pyr_out && !rc && !ar.dry)
+        for (int k = 0; k < N; ++k)
+          if (pyr_out[k * 5 + (PWC_LVLS - l)])
+            hipLaunchKernelGGL(stitch_free_copy2_kernel, dim3(grid_for(px)), dim3(256), 0, st, flow_prev + (size_t)k * px * 4,
+                               pyr_out[k * 5 + (PWC_LVLS - l)], px);
+      Dprev = D; prev_total = L.total;
     }
+    *flow2 = flow_prev;
     return rc;
   }
 };
+
+template <typename F>
+auto with_pwc_elem(const fisr_pwc* c, F&& f) {
+  if (c->precision == FISR_PREC_F16) return f(_Float16());
+  return f(float());
+}
+
+// One call of the flow network on a set of frames: prepared images (im32 float32 [nf, H, W, 4], or NULL and yuv frames [h, w, 3]
+// that the pre-processing kernel turns into them), the feature pyramid of every frame ONCE, then the decoder over the items
+// in groups of PWC_MAX_ITEMS.  each(k, flow2_k): called per item with its refined level-2 flow ([H/4, W/4] x stride 4 floats).
+template <typename TE, typename Each>
+int pwc_run(fisr_pwc* c, const float* im32, const uint8_t* const* yuv, int nf, int h, int w, int H, int W, const std::vector<std::pair<int, int>>& pairs,
+            float* const* pyr, void* ws, size_t ws_bytes, hipStream_t st, bool dry, size_t* peak, Each&& each) {
+  static const ColorConsts cc = make_color_consts();
+  PwcRunner<TE> r; r.ctx = c; r.st = st; r.ar.base = (char*)ws; r.ar.cap = ws_bytes; r.ar.dry = dry;
+  TE* im = nullptr;
+  if (std::is_same<TE, float>::value && im32) im = (TE*)const_cast<float*>(im32);
+  else {
+    im = r.ealloc((size_t)nf * H * W * 4);
+    if (!dry) {
+      if (im32) hipLaunchKernelGGL(pwc_cast_kernel<TE>, dim3(grid_for((size_t)nf * H * W)), dim3(256), 0, st, im32, im, (size_t)nf * H * W);
+      else
+        for (int k = 0; k < nf; ++k)
+          hipLaunchKernelGGL(pwc_prep_kernel<TE>, dim3(grid_for((size_t)H * W)), dim3(256), 0, st, yuv[k], h, w, im + (size_t)k * H * W * 4, H, W, cc);
+      HIP_OK(nullptr, hipGetLastError());
+    }
+  }
+  r.pyramid(im, nf, H, W);
+  const size_t mark = r.ar.off;
+  for (size_t g = 0; g < pairs.size() && !r.rc; g += PWC_MAX_ITEMS) {
+    PwcItems items = identity_items(0);
+    items.n = (int)std::min<size_t>(PWC_MAX_ITEMS, pairs.size() - g);
+    for (int k = 0; k < items.n; ++k) { items.a[k] = pairs[g + k].first; items.b[k] = pairs[g + k].second; }
+    r.ar.off = mark;
+    float* f2 = nullptr;
+    int rc = r.decode(items, &f2, pyr ? pyr + g * 5 : nullptr);
+    if (rc) return rc;
+    if (!dry)
+      for (int k = 0; k < items.n; ++k) {
+        rc = each((int)g + k, f2 + (size_t)k * (H / 4) * (W / 4) * 4);
+        if (rc) return rc;
+      }
+  }
+  if (peak) *peak = r.ar.peak + 256;
+  return r.rc;
+}
+
+size_t pwc_ws(fisr_pwc* c, int nf, int H, int W, int npairs, bool with_prep) {
+  std::vector<std::pair<int, int>> pairs;
+  for (int k = 0; k < npairs; ++k) pairs.push_back({0, nf > 1 ? 1 : 0});
+  size_t peak = 0;
+  with_pwc_elem(c, [&](auto tag) {
+    typedef decltype(tag) TE;
+    const float* fake32 = with_prep ? nullptr : (const float*)16;
+    return pwc_run<TE>(c, fake32, nullptr, nf, H / 2, W / 2, H, W, pairs, nullptr, nullptr, 0, nullptr, true, &peak, [](int, float*) { return 0; });
+  });
+  return peak;
+}
 
 }  // namespace
 
@@ -351,12 +478,20 @@ int fisr_pwc_create(fisr_pwc** out, int device_id) {
   return 0;
 }
 
+static void pwc_release_packed(fisr_pwc* c) {
+  for (auto& kv : c->convs) {
+    PwcConv& pc = kv.second;
+    if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd);
+    if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
+  }
+  for (auto& kv : c->deconvs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
+  c->convs.clear(); c->deconvs.clear();
+}
+
 void fisr_pwc_destroy(fisr_pwc* c) {
   if (!c) return;
   DeviceGuard guard(c->dev);
-  for (auto& kv : c->convs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
-    if (kv.second.dw.d_w) (void)hipFree(kv.second.dw.d_w); if (kv.second.dw.d_b) (void)hipFree(kv.second.dw.d_b); }
-  for (auto& kv : c->deconvs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
+  pwc_release_packed(c);
   delete c;
 }
 
@@ -390,11 +525,17 @@ int fisr_pwc_set_weight(fisr_pwc* c, const char* name, const float* host, const 
   return 0;
 }
 
-int fisr_pwc_finalize(fisr_pwc* c) {
+// precision: FISR_PREC_F32W (fp32 tensors and arithmetic; the dense layers on the Winograd kernel) or FISR_PREC_F16 (fp16 feature
+// tensors, fp32 accumulation, fp32 flows; the dense layers on the LDS-DMA kernel)
+int fisr_pwc_finalize_precision(fisr_pwc* c, int precision) {
   if (!c) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_finalize: ctx is NULL");
+  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F32 && precision != FISR_PREC_F16)
+    return pfail(c, FISR_EINVAL, "fisr_pwc_finalize_precision: FISR_PREC_F32W or FISR_PREC_F16");
   for (auto& kv : c->vars) if (!kv.second.have) return pfail(c, FISR_EMISSING, "missing variable " + kv.first);
   DeviceGuard guard(c->dev);
   HIP_OK(nullptr, guard.err);
+  pwc_release_packed(c);
+  c->precision = precision == FISR_PREC_F16 ? FISR_PREC_F16 : FISR_PREC_F32W;
   int rc = 0;
   const int real[7] = {3, 16, 32, 64, 96, 128, 196};
   for (int l = 1; l <= PWC_LVLS && !rc; ++l) {
@@ -430,21 +571,14 @@ int fisr_pwc_finalize(fisr_pwc* c) {
   c->finalized = true;
   return 0;
 }
+int fisr_pwc_finalize(fisr_pwc* c) { return fisr_pwc_finalize_precision(c, FISR_PREC_F32W); }
 
-static size_t pwc_ws(fisr_pwc* c, int H, int W, bool with_prep) {
-  PwcRunner r; r.ctx = c; r.st = nullptr; r.ar.dry = true;
-  if (with_prep) r.falloc((size_t)2 * H * W * 4);
-  float* f2[2];
-  r.nn(nullptr, H, W, f2, nullptr);
-  return r.ar.peak + 256;
-}
-
-// The network alone on a prepared pair: im [2, H, W, 4] device (RGB/255 + zero channel; H, W multiples of 64).
+// The network alone on a prepared pair: im [2, H, W, 4] device float32 (RGB/255 + zero channel; H, W multiples of 64).
 // flow_pred [2, H, W, 2] (direction 0: a->b, 1: b->a) = x4 bilinear * 4 of the level-2 flow (nullable);
 // pyr[10] (nullable, entries nullable): refined flows of levels 6..2 for direction 0 then direction 1, [h_l, w_l, 2].
 size_t fisr_pwc_nn_workspace_bytes(const fisr_pwc* c, int H, int W) {
   if (!c || !c->finalized || H < 64 || W < 64 || H % 64 || W % 64) return 0;
-  return pwc_ws(const_cast<fisr_pwc*>(c), H, W, false);
+  return pwc_ws(const_cast<fisr_pwc*>(c), 2, H, W, 2, false);
 }
 
 int fisr_pwc_nn(fisr_pwc* c, const float* im, int H, int W, float* flow_pred, float* const* pyr, void* ws, size_t ws_bytes, void* stream) {
@@ -453,25 +587,50 @@ int fisr_pwc_nn(fisr_pwc* c, const float* im, int H, int W, float* flow_pred, fl
   if (ws_bytes < fisr_pwc_nn_workspace_bytes(c, H, W)) return pfail(c, FISR_ENOMEM, "fisr_pwc_nn: workspace too small");
   DeviceGuard guard(c->dev);
   HIP_OK(nullptr, guard.err);
-  PwcRunner r; r.ctx = c; r.st = (hipStream_t)stream; r.ar.base = (char*)ws; r.ar.cap = ws_bytes;
-  float* f2[2] = {nullptr, nullptr};
-  int rc = r.nn(im, H, W, f2, pyr);
-  if (rc) return rc;
-  if (flow_pred)
-    for (int d = 0; d < 2; ++d) {
-      hipLaunchKernelGGL(pwc_upsample4_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, r.st, f2[d], 4, 0, H / 4, W / 4,
-                         flow_pred + (size_t)d * H * W * 2);
-      HIP_OK(nullptr, hipGetLastError());
-    }
-  return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const std::vector<std::pair<int, int>> pairs = {{0, 1}, {1, 0}};
+  return with_pwc_elem(c, [&](auto tag) {
+    typedef decltype(tag) TE;
+    return pwc_run<TE>(c, im, nullptr, 2, H / 2, W / 2, H, W, pairs, pyr, ws, ws_bytes, st, false, nullptr, [&](int k, float* f2) {
+      if (!flow_pred) return 0;
+      hipLaunchKernelGGL(pwc_upsample4_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, st, f2, 4, 0, H / 4, W / 4, flow_pred + (size_t)k * H * W * 2);
+      return hipGetLastError() == hipSuccess ? 0 : pfail(c, FISR_EHIP, "fisr_pwc_nn: flow_pred");
+    });
+  });
+}
+
+// What the reference script's loop (:104-141) computes for a run of nframes YUV uint8 frames [h, w, 3] on the device, in ONE call:
+// flows [nframes - 1, 2, h, w, 2] float32 LR pixels (pair fr: [0] = fr -> fr+1, [1] = fr+1 -> fr).  Every frame is pre-processed and
+// its feature pyramid extracted once (the script's pair-by-pair loop does both twice for the inner frames); the 2 (nframes - 1)
+// directions run through the decoder as batches of up to 8.
+size_t fisr_pwc_flow_stack_workspace_bytes(const fisr_pwc* c, int nframes, int h, int w) {
+  if (!c || !c->finalized || h < 8 || w < 8 || nframes < 2) return 0;
+  return pwc_ws(const_cast<fisr_pwc*>(c), nframes, round_up(2 * h, 64), round_up(2 * w, 64), 2 * (nframes - 1), true);
+}
+
+int fisr_pwc_flow_stack(fisr_pwc* c, const uint8_t* const* yuv, int nframes, int h, int w, float* flows, void* ws, size_t ws_bytes, void* stream) {
+  if (!c || !c->finalized) return pfail(c, FISR_ESTATE, "fisr_pwc_flow_stack: weights not finalized");
+  if (!yuv || !flows || !ws || h < 8 || w < 8 || nframes < 2) return pfail(c, FISR_EINVAL, "fisr_pwc_flow_stack: bad argument");
+  for (int k = 0; k < nframes; ++k) if (!yuv[k]) return pfail(c, FISR_EINVAL, "fisr_pwc_flow_stack: null frame");
+  if (ws_bytes < fisr_pwc_flow_stack_workspace_bytes(c, nframes, h, w)) return pfail(c, FISR_ENOMEM, "fisr_pwc_flow_stack: workspace too small");
+  DeviceGuard guard(c->dev);
+  HIP_OK(nullptr, guard.err);
+  hipStream_t st = (hipStream_t)stream;
+  const int H = round_up(2 * h, 64), W = round_up(2 * w, 64);
+  std::vector<std::pair<int, int>> pairs;
+  for (int fr = 0; fr + 1 < nframes; ++fr) { pairs.push_back({fr, fr + 1}); pairs.push_back({fr + 1, fr}); }
+  return with_pwc_elem(c, [&](auto tag) {
+    typedef decltype(tag) TE;
+    return pwc_run<TE>(c, nullptr, yuv, nframes, h, w, H, W, pairs, nullptr, ws, ws_bytes, st, false, nullptr, [&](int k, float* f2) {
+      hipLaunchKernelGGL(pwc_flow_out_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, st, f2, 4, 0, H / 4, W / 4, flows + (size_t)k * h * w * 2, h, w);
+      return hipGetLastError() == hipSuccess ? 0 : pfail(c, FISR_EHIP, "fisr_pwc_flow_stack: flow_out");
+    });
+  });
 }
 
 // One iteration of the reference script's loop (:118-140): two YUV uint8 frames [h, w, 3] on the device ->
 // flows a->b and b->a in LR pixels, [h, w, 2] float32 each (what the script writes into pred[fr, 0] and pred[fr, 1]).
-size_t fisr_pwc_flow_workspace_bytes(const fisr_pwc* c, int h, int w) {
-  if (!c || !c->finalized || h < 8 || w < 8) return 0;
-  return pwc_ws(const_cast<fisr_pwc*>(c), round_up(2 * h, 64), round_up(2 * w, 64), true);
-}
+size_t fisr_pwc_flow_workspace_bytes(const fisr_pwc* c, int h, int w) { return fisr_pwc_flow_stack_workspace_bytes(c, 2, h, w); }
 
 int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, int h, int w, float* flow_ab, float* flow_ba,
                        void* ws, size_t ws_bytes, void* stream) {
@@ -480,39 +639,38 @@ int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, 
   if (ws_bytes < fisr_pwc_flow_workspace_bytes(c, h, w)) return pfail(c, FISR_ENOMEM, "fisr_pwc_flow_pair: workspace too small");
   DeviceGuard guard(c->dev);
   HIP_OK(nullptr, guard.err);
-  static const ColorConsts cc = make_color_consts();
+  hipStream_t st = (hipStream_t)stream;
   const int H = round_up(2 * h, 64), W = round_up(2 * w, 64);
-  PwcRunner r; r.ctx = c; r.st = (hipStream_t)stream; r.ar.base = (char*)ws; r.ar.cap = ws_bytes;
-  float* im = r.falloc((size_t)2 * H * W * 4);
-  hipLaunchKernelGGL(pwc_prep_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, r.st, yuv_a, h, w, im, H, W, cc);
-  hipLaunchKernelGGL(pwc_prep_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, r.st, yuv_b, h, w, im + (size_t)H * W * 4, H, W, cc);
-  HIP_OK(nullptr, hipGetLastError());
-  float* f2[2] = {nullptr, nullptr};
-  int rc = r.nn(im, H, W, f2, nullptr);
-  if (rc) return rc;
+  const uint8_t* yuv[2] = {yuv_a, yuv_b};
   float* outs[2] = {flow_ab, flow_ba};
-  for (int d = 0; d < 2; ++d) {
-    hipLaunchKernelGGL(pwc_flow_out_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, r.st, f2[d], 4, 0, H / 4, W / 4, outs[d], h, w);
-    HIP_OK(nullptr, hipGetLastError());
-  }
-  return 0;
+  const std::vector<std::pair<int, int>> pairs = {{0, 1}, {1, 0}};
+  return with_pwc_elem(c, [&](auto tag) {
+    typedef decltype(tag) TE;
+    return pwc_run<TE>(c, nullptr, yuv, 2, h, w, H, W, pairs, nullptr, ws, ws_bytes, st, false, nullptr, [&](int k, float* f2) {
+      hipLaunchKernelGGL(pwc_flow_out_kernel, dim3(grid_for((size_t)h * w)), dim3(256), 0, st, f2, 4, 0, H / 4, W / 4, outs[k], h, w);
+      return hipGetLastError() == hipSuccess ? 0 : pfail(c, FISR_EHIP, "fisr_pwc_flow_pair: flow_out");
+    });
+  });
 }
 
 // ---- op-level entries (parity tests of the flow network's kernels at the sizes the bench runs them at) ----
+// precision FISR_PREC_F32W: float32 tensors; FISR_PREC_F16: fp16 feature tensors (in, and out unless out_f32), float32 `add`.
 // One tf.layers.conv2d 3x3 'same' (+ bias, leaky relu, optional add) exactly as the network launches it: the input is the
 // channel range [in_co, in_co + cin_buf) of a buffer with pixel stride in_cs, the output the range [out_co, out_co + cout)
 // of a buffer with pixel stride out_cs.  w_host: TF HWIO [3,3,ci,cout]; chmap (nullable = identity, then ci == cin_buf):
 // buffer channel, relative to in_co, of TF input channel j (the dense blocks' padded channel groups).  route 0: the
-// network's own choice (persistent Winograd kernel / FISRnet's direct kernel / generic implicit GEMM), 1: generic, 2:
-// Winograd or error, 3: direct or error.  Returns the route taken (1, 2, 3) or a negative error.
-int fisr_pwc_op_conv(const float* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
-                     const int* chmap, float* out, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
-                     int stride, int dil, float slope, int route, void* stream) {
+// network's own choice, 1: generic implicit GEMM, 2: fp32 Winograd, 3: FISRnet's direct kernel, 4: fp16 LDS-DMA kernel (2 - 4: error
+// if the layer is not eligible).  Returns the route taken (1 .. 4) or a negative error.
+int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
+                     const int* chmap, void* out, int out_f32, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
+                     int stride, int dil, float slope, int route, int precision, void* stream) {
   if (!in || !w_host || !b_host || !out || ci < 1 || cout < 1 || cin_buf < ci || n < 1 || h < 1 || w < 1 || stride < 1 || stride > 2 || dil < 1)
     return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: bad argument");
+  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F16) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: FISR_PREC_F32W or FISR_PREC_F16");
   if ((in_cs | in_co | out_cs | out_co | cin_buf) & 3) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: channel strides / offsets / cin_buf must be multiples of 4");
   fisr_pwc tmp;
   tmp.dev = device_of(out);
+  tmp.precision = precision;
   DeviceGuard guard(tmp.dev);
   HIP_OK(nullptr, guard.err);
   PwcVar& kw = tmp.vars["op/kernel"]; PwcVar& kb = tmp.vars["op/bias"];
@@ -520,32 +678,34 @@ int fisr_pwc_op_conv(const float* in, int in_cs, int in_co, int cin_buf, const f
   kb.shape = {cout}; kb.v.assign(b_host, b_host + cout);
   std::vector<int> m = chmap ? std::vector<int>(chmap, chmap + ci) : iota_map(ci);
   for (int c : m) if (c < 0 || c >= cin_buf) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: chmap entry out of range");
-  PwcConv& pc = tmp.convs["op"];
-  int rc = pwc_pack_conv(&tmp, "op", m, cin_buf, pc, route != 1);
-  auto release = [&]() {
-    if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu);
-    if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
-  };
-  if (rc) { release(); return rc; }
-  PwcRunner r; r.ctx = &tmp; r.st = (hipStream_t)stream;
-  const int took = r.conv_route("op", n, h, w, in_cs, out_cs, stride, dil, slope, add != nullptr);
-  if ((route == 2 || route == 3) && took != route) { release(); return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: the requested kernel does not take this layer"); }
-  r.conv("op", in, in_cs, in_co, out, out_cs, out_co, n, h, w, stride, dil, slope, add, add_cs, add_co);
-  hipError_t e = hipStreamSynchronize(r.st);
-  release();
-  if (r.rc) return r.rc;
-  if (e != hipSuccess) return pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_conv: ") + hipGetErrorString(e));
-  return took;
+  int rc = pwc_pack_conv(&tmp, "op", m, cin_buf, tmp.convs["op"], route != 1);
+  if (rc) { pwc_release_packed(&tmp); return rc; }
+  int took = 0;
+  rc = with_pwc_elem(&tmp, [&](auto tag) {
+    typedef decltype(tag) TE;
+    PwcRunner<TE> r; r.ctx = &tmp; r.st = (hipStream_t)stream;
+    took = r.conv_route("op", n, h, w, in_cs, out_cs, out_f32 != 0 && std::is_same<TE, _Float16>::value, stride, dil, slope, add != nullptr);
+    if (route >= 2 && took != route) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: the requested kernel does not take this layer");
+    r.conv("op", (const TE*)in, in_cs, in_co, out, out_f32 != 0, out_cs, out_co, n, h, w, stride, dil, slope, add, add_cs, add_co);
+    hipError_t e = hipStreamSynchronize(r.st);
+    if (r.rc) return r.rc;
+    return e != hipSuccess ? pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_conv: ") + hipGetErrorString(e)) : 0;
+  });
+  pwc_release_packed(&tmp);
+  return rc ? rc : took;
 }
 
 // tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (model_pwcnet.py:1196): in = range [in_co, in_co + cin4) of a buffer with pixel
-// stride in_cs, [n,h,w]; w_host TF layout [4,4,2,ci]; chmap as above; out channels [out_co, out_co + 2) of [n,2h,2w] x out_cs.
-int fisr_pwc_op_deconv(const float* in, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci, const int* chmap,
-                       float* out, int out_cs, int out_co, int n, int h, int w, void* stream) {
+// stride in_cs, [n,h,w] (in_f32: float32 -- the flow -- else the engine's element type); w_host TF layout [4,4,2,ci]; chmap as
+// above; out channels [out_co, out_co + 2) of [n,2h,2w] x out_cs (element type).
+int fisr_pwc_op_deconv(const void* in, int in_f32, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci, const int* chmap,
+                       void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream) {
   if (!in || !w_host || !b_host || !out || ci < 1 || cin4 < ci || (cin4 & 3) || (in_cs & 3) || (in_co & 3) || n < 1 || h < 1 || w < 1)
     return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_deconv: bad argument");
+  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F16) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_deconv: FISR_PREC_F32W or FISR_PREC_F16");
   fisr_pwc tmp;
   tmp.dev = device_of(out);
+  tmp.precision = precision;
   DeviceGuard guard(tmp.dev);
   HIP_OK(nullptr, guard.err);
   PwcVar& kw = tmp.vars["op/kernel"]; PwcVar& kb = tmp.vars["op/bias"];
@@ -553,37 +713,47 @@ int fisr_pwc_op_deconv(const float* in, int in_cs, int in_co, int cin4, const fl
   kb.shape = {2}; kb.v.assign(b_host, b_host + 2);
   std::vector<int> m = chmap ? std::vector<int>(chmap, chmap + ci) : iota_map(ci);
   for (int c : m) if (c < 0 || c >= cin4) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_deconv: chmap entry out of range");
-  PwcDeconv& pd = tmp.deconvs["op"];
-  int rc = pwc_pack_deconv(&tmp, "op", m, cin4, pd);
-  if (!rc) {
-    PwcRunner r; r.ctx = &tmp; r.st = (hipStream_t)stream;
-    r.deconv("op", in, in_cs, in_co, out, out_cs, out_co, n, h, w);
-    hipError_t e = hipStreamSynchronize(r.st);
-    rc = r.rc ? r.rc : (e != hipSuccess ? pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_deconv: ") + hipGetErrorString(e)) : 0);
-  }
-  if (pd.d_w) (void)hipFree(pd.d_w); if (pd.d_b) (void)hipFree(pd.d_b);
+  int rc = pwc_pack_deconv(&tmp, "op", m, cin4, tmp.deconvs["op"]);
+  if (!rc)
+    rc = with_pwc_elem(&tmp, [&](auto tag) {
+      typedef decltype(tag) TE;
+      PwcRunner<TE> r; r.ctx = &tmp; r.st = (hipStream_t)stream;
+      if (in_f32) r.template deconv<float>("op", (const float*)in, in_cs, in_co, (TE*)out, out_cs, out_co, n, h, w);
+      else r.template deconv<TE>("op", (const TE*)in, in_cs, in_co, (TE*)out, out_cs, out_co, n, h, w);
+      hipError_t e = hipStreamSynchronize(r.st);
+      return r.rc ? r.rc : (e != hipSuccess ? pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_deconv: ") + hipGetErrorString(e)) : 0);
+    });
+  pwc_release_packed(&tmp);
   return rc;
 }
 
 // core_costvol.cost_volume + leaky relu (model_pwcnet.py:1277): c1, c2 dense [n,h,w,c] (c % 4 == 0) -> 81 channels at out_co of a
 // buffer with pixel stride out_cs
-int fisr_pwc_op_costvol(const float* c1, const float* c2, int c, float* out, int out_cs, int out_co, int n, int h, int w, void* stream) {
-  if (!c1 || !c2 || !out || c < 4 || (c & 3) || (out_cs & 3) || (out_co & 3) || n < 1 || h < 1 || w < 1)
+int fisr_pwc_op_costvol(const void* c1, const void* c2, int c, void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream) {
+  if (!c1 || !c2 || !out || c < 4 || (c & 3) || (out_cs & 3) || (out_co & 3) || n < 1 || n > PWC_MAX_ITEMS || h < 1 || w < 1)
     return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_costvol: bad argument");
   DeviceGuard guard(device_of(out));
   HIP_OK(nullptr, guard.err);
-  hipError_t e = launch_costvol(c1, c2, c, out, out_cs, out_co, n, h, w, (hipStream_t)stream);
+  const PwcItems id = identity_items(n);
+  hipError_t e = precision == FISR_PREC_F16
+      ? launch_costvol<_Float16>((const _Float16*)c1, c, 0, id, (const _Float16*)c2, id, c, (_Float16*)out, out_cs, out_co, n, h, w, (hipStream_t)stream)
+      : launch_costvol<float>((const float*)c1, c, 0, id, (const float*)c2, id, c, (float*)out, out_cs, out_co, n, h, w, (hipStream_t)stream);
   if (e != hipSuccess) return pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_costvol: ") + hipGetErrorString(e));
   return 0;
 }
 
 // core_warp.dense_image_warp (model_pwcnet.py:1178): img dense [n,h,w,c] sampled at (x + scale*u, y + scale*v), (u, v) = channels
 // f_co, f_co + 1 of a buffer with pixel stride f_cs -> out dense [n,h,w,c]
-int fisr_pwc_op_warp(const float* img, int c, const float* flow, int f_cs, int f_co, float scale, float* out, int n, int h, int w, void* stream) {
-  if (!img || !flow || !out || c < 4 || (c & 3) || n < 1 || h < 2 || w < 2) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_warp: bad argument");
+int fisr_pwc_op_warp(const void* img, int c, const void* flow, int f_cs, int f_co, float scale, void* out, int n, int h, int w, int precision, void* stream) {
+  if (!img || !flow || !out || c < 4 || (c & 3) || n < 1 || n > PWC_MAX_ITEMS || h < 2 || w < 2) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_warp: bad argument");
   DeviceGuard guard(device_of(out));
   HIP_OK(nullptr, guard.err);
-  hipLaunchKernelGGL(pwc_warp_kernel, dim3(grid_for((size_t)n * h * w * c / 4)), dim3(256), 0, (hipStream_t)stream, img, c, flow, f_cs, f_co, scale, out, n, h, w);
+  const PwcItems id = identity_items(n);
+  const dim3 grid(grid_for((size_t)n * h * w * c / 4));
+  if (precision == FISR_PREC_F16)
+    hipLaunchKernelGGL(pwc_warp_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)img, id, c, (const _Float16*)flow, f_cs, f_co, scale, (_Float16*)out, n, h, w);
+  else
+    hipLaunchKernelGGL(pwc_warp_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)img, id, c, (const float*)flow, f_cs, f_co, scale, (float*)out, n, h, w);
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }
@@ -593,7 +763,7 @@ int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, 
   if (!yuv || !out || PH < 2 * h || PW < 2 * w) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_prep: bad argument");
   static const ColorConsts cc = make_color_consts();
   DeviceGuard guard(device_of(out));
-  hipLaunchKernelGGL(pwc_prep_kernel, dim3(grid_for((size_t)PH * PW)), dim3(256), 0, (hipStream_t)stream, yuv, h, w, out, PH, PW, cc);
+  hipLaunchKernelGGL(pwc_prep_kernel<float>, dim3(grid_for((size_t)PH * PW)), dim3(256), 0, (hipStream_t)stream, yuv, h, w, out, PH, PW, cc);
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }

@@ -23,6 +23,29 @@
 
 namespace fisr {
 
+// Element type of the flow network's feature tensors: float (the exact engine) or _Float16 (FISR_PREC_F16: 16-bit features,
+// fp32 arithmetic inside these kernels, fp32 flows).  Four consecutive channels <-> one f32x4.
+template <typename T> struct PwcElem;
+template <> struct PwcElem<float> {
+  static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct PwcElem<_Float16> {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x4 ld4(const _Float16* p) {
+    const h4 h = *reinterpret_cast<const h4*>(p);
+    return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+  }
+  static __device__ __forceinline__ void st4(_Float16* p, f32x4 v) {
+    h4 h; h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+    *reinterpret_cast<h4*>(p) = h;
+  }
+};
+
+// (pair, direction) items of a batched decoder pass: item i correlates the features of frame a[i] with those of frame b[i]
+constexpr int PWC_MAX_ITEMS = 8;
+struct PwcItems { int n; int a[PWC_MAX_ITEMS]; int b[PWC_MAX_ITEMS]; };
+
 constexpr int G_CH = 8;                 // input channels per K chunk
 constexpr int G_REC = 32;               // bytes per LDS record
 constexpr int G_PX = 256;               // output pixels per workgroup (8 x 32)
@@ -30,15 +53,16 @@ constexpr int G_BN = 64;                // output channels per workgroup
 constexpr size_t convg_lds_bytes() { return (size_t)9 * G_PX * G_REC + (size_t)9 * G_BN * G_REC; }
 
 struct ConvGArgs {
-  const float* in;  int in_cs, in_co, Cin;      // input buffer: pixel stride (floats), first channel, channels read
+  const void* in;   int in_cs, in_co, Cin;      // input buffer (TI): pixel stride (elements), first channel, channels read
   const float* w;                                // packed [Cin8/8][9][CoutPad][8], LDS image (halves swizzled by row bit 3)
   const float* bias;                             // [CoutPad]
-  float* out;       int out_cs, out_co, Cout, CoutPad;
+  void* out;        int out_cs, out_co, Cout, CoutPad;     // (TO)
   const float* add; int add_cs, add_co;          // optional: out = act(conv + bias) + add   (refine_flow, :1521)
   int N, H, W, OH, OW, stride, dil, pad_t, pad_l;
   float slope;                                   // leaky relu slope (1 = linear)
 };
 
+template <typename TI, typename TO>
 __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sIn = smem;                               // [tap 9][px 256][32 B]
@@ -79,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
       const int iy = oy * p.stride - p.pad_t + (tap / 3) * p.dil, ix = ox * p.stride - p.pad_l + (tap % 3) * p.dil;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (c_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-        v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(nb * p.H + iy) * p.W + ix) * p.in_cs + p.in_co + c0);
+        v = PwcElem<TI>::ld4((const TI*)p.in + ((size_t)(nb * p.H + iy) * p.W + ix) * p.in_cs + p.in_co + c0);
       *reinterpret_cast<f32x4*>(sIn + (tap * G_PX + px) * G_REC + ((l_half ^ ((px >> 3) & 1)) * 16)) = v;
     }
     {
@@ -115,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
     const int oy = y0 + 4 * pxh + j;
     if (oy >= p.OH || ox >= p.OW || cb >= p.Cout) continue;
     const size_t pix = (size_t)(nb * p.OH + oy) * p.OW + ox;
-    float* ob = p.out + pix * p.out_cs + p.out_co + cb;
+    TO* ob = (TO*)p.out + pix * p.out_cs + p.out_co + cb;
     const float* ab = p.add ? p.add + pix * p.add_cs + p.add_co + cb : nullptr;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -128,11 +152,11 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
       if (cb + 4 * q + 3 < p.Cout) {
         f32x4 o = {v[0], v[1], v[2], v[3]};
         if (ab) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + 4 * q); o += a4; }
-        *reinterpret_cast<f32x4*>(ob + 4 * q) = o;
+        PwcElem<TO>::st4(ob + 4 * q, o);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (cb + 4 * q + e < p.Cout) ob[4 * q + e] = v[e] + (ab ? ab[4 * q + e] : 0.f);
+          if (cb + 4 * q + e < p.Cout) ob[4 * q + e] = (TO)(v[e] + (ab ? ab[4 * q + e] : 0.f));
       }
     }
   }
@@ -140,8 +164,9 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
 
 // tf.layers.conv2d_transpose(x, 2, 4, 2, 'same'): out[2*i + k - 1] += in[i] * kernel[k]  (two output channels).
 // One thread per output pixel; weights [ky][kx][o][Cin4] in global (L1/L2 resident), 16-byte loads.
-__global__ void pwc_deconv_kernel(const float* __restrict__ in, int in_cs, int in_co, int Cin4, const float* __restrict__ w,
-                                  const float* __restrict__ bias, float* __restrict__ out, int out_cs, int out_co,
+template <typename TI, typename TO>
+__global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_co, int Cin4, const float* __restrict__ w,
+                                  const float* __restrict__ bias, TO* __restrict__ out, int out_cs, int out_co,
                                   int N, int H, int W) {
   const int OH = 2 * H, OW = 2 * W;
   const size_t total = (size_t)N * OH * OW;
@@ -156,18 +181,18 @@ __global__ void pwc_deconv_kernel(const float* __restrict__ in, int in_cs, int i
       for (int tx = 0; tx < 2; ++tx) {
         const int kx = ((ox + 1) & 1) + 2 * tx, ix = (ox + 1 - kx) / 2;
         if ((ox + 1 - kx) < 0 || ix >= W) continue;
-        const f32x4* src = reinterpret_cast<const f32x4*>(in + ((size_t)(n * H + iy) * W + ix) * in_cs + in_co);
+        const TI* src = in + ((size_t)(n * H + iy) * W + ix) * in_cs + in_co;
         const f32x4* w0 = reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 0) * Cin4);
         const f32x4* w1 = reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 1) * Cin4);
         for (int c = 0; c < Cin4 / 4; ++c) {
-          const f32x4 v = src[c], k0 = w0[c], k1 = w1[c];
+          const f32x4 v = PwcElem<TI>::ld4(src + 4 * c), k0 = w0[c], k1 = w1[c];
           a0 += v.x * k0.x + v.y * k0.y + v.z * k0.z + v.w * k0.w;
           a1 += v.x * k1.x + v.y * k1.y + v.z * k1.z + v.w * k1.w;
         }
       }
     }
-    float* o = out + i * out_cs + out_co;
-    o[0] = a0; o[1] = a1;
+    TO* o = out + i * out_cs + out_co;
+    o[0] = (TO)a0; o[1] = (TO)a1;
   }
 }
 
@@ -180,8 +205,12 @@ constexpr int CV_REC = CV_CH * 4 + 16;
 constexpr int CV_HW = TILE_W + 8, CV_HH = TILE_H + 8;
 constexpr size_t costvol_lds_bytes() { return (size_t)CV_HH * CV_HW * CV_REC; }
 
-__global__ __launch_bounds__(256) void pwc_costvol_kernel(const float* __restrict__ c1, const float* __restrict__ w2, int C,
-                                                          float* __restrict__ out, int out_cs, int out_co, int N, int H, int W) {
+// Batched form: image n of c1 is c1 + (size_t)c1_img[n] * H * W * c1_cs (the features of the item's first frame, or its slot of the
+// decoder buffer), likewise w2.
+template <typename TE>
+__global__ __launch_bounds__(256) void pwc_costvol_kernel(const TE* __restrict__ c1, int c1_cs, int c1_co, const PwcItems c1_img,
+                                                          const TE* __restrict__ w2, const PwcItems w2_img, int C,
+                                                          TE* __restrict__ out, int out_cs, int out_co, int N, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) char cv_smem[];
   const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
@@ -192,7 +221,10 @@ __global__ __launch_bounds__(256) void pwc_costvol_kernel(const float* __restric
   const int x0 = tx_ * TILE_W, y0 = ty_ * TILE_H;
   const int x = x0 + tx, y = y0 + ty;
   const bool inside = x < W && y < H;
-  const size_t pix = ((size_t)n * H + min(y, H - 1)) * W + min(x, W - 1);
+  const size_t pix_in = (size_t)min(y, H - 1) * W + min(x, W - 1);
+  const size_t pix = (size_t)n * H * W + pix_in;
+  const TE* c1n = c1 + (size_t)c1_img.a[n] * H * W * c1_cs + c1_co;
+  const TE* w2n = w2 + (size_t)w2_img.a[n] * H * W * C;
   float s[81];
 #pragma unroll
   for (int k = 0; k < 81; ++k) s[k] = 0.f;
@@ -204,14 +236,14 @@ __global__ __launch_bounds__(256) void pwc_costvol_kernel(const float* __restric
       const int gy = y0 - 4 + hy, gx = x0 - 4 + hx;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (q < nq && gy >= 0 && gy < H && gx >= 0 && gx < W)
-        v = *reinterpret_cast<const f32x4*>(w2 + (((size_t)n * H + gy) * W + gx) * C + c0 + 4 * q);
+        v = PwcElem<TE>::ld4(w2n + ((size_t)gy * W + gx) * C + c0 + 4 * q);
       *reinterpret_cast<f32x4*>(cv_smem + hp * CV_REC + q * 16) = v;
     }
     f32x4 a[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (q < nq) a[q] = *reinterpret_cast<const f32x4*>(c1 + pix * C + c0 + 4 * q);
+      if (q < nq) a[q] = PwcElem<TE>::ld4(c1n + pix_in * c1_cs + c0 + 4 * q);
     }
     __syncthreads();
 #pragma unroll
@@ -231,53 +263,61 @@ __global__ __launch_bounds__(256) void pwc_costvol_kernel(const float* __restric
   }
   if (!inside) return;
   const float inv = 1.f / (float)C;
-  float* o = out + pix * out_cs + out_co;
+  TE* o = out + pix * out_cs + out_co;
 #pragma unroll
   for (int k = 0; k < 80; k += 4) {
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const float m = s[k + e] * inv; v[e] = m >= 0.f ? m : 0.1f * m; }
-    *reinterpret_cast<f32x4*>(o + k) = v;
+    PwcElem<TE>::st4(o + k, v);
   }
-  { const float m = s[80] * inv; o[80] = m >= 0.f ? m : 0.1f * m; }
+  { const float m = s[80] * inv; o[80] = (TE)(m >= 0.f ? m : 0.1f * m); }
 }
 
 // dense_image_warp: out[px][c] = bilinear(img, x + scale*u, y + scale*v); floor index clamped to [0, size-2], weight
 // clamped to [0, 1] (tf.contrib.image); evaluation order top = ax*(tr - tl) + tl, ... as tf.contrib's.
-__global__ void pwc_warp_kernel(const float* __restrict__ img, int C, const float* __restrict__ flow, int f_cs, int f_co,
-                                float scale, float* __restrict__ out, int N, int H, int W) {
+// Batched form: image n samples img + (size_t)img_idx.a[n] * H * W * C.
+template <typename TE>
+__global__ void pwc_warp_kernel(const TE* __restrict__ img, const PwcItems img_idx, int C, const TE* __restrict__ flow, int f_cs, int f_co,
+                                float scale, TE* __restrict__ out, int N, int H, int W) {
   const int C4 = C / 4;
   const size_t total = (size_t)N * H * W * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4);
     const size_t pix = i / C4;
     const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
-    const float qx = (float)x + flow[pix * f_cs + f_co] * scale, qy = (float)y + flow[pix * f_cs + f_co + 1] * scale;
+    const float qx = (float)x + (float)flow[pix * f_cs + f_co] * scale, qy = (float)y + (float)flow[pix * f_cs + f_co + 1] * scale;
     const float fx = fminf(fmaxf(floorf(qx), 0.f), (float)(W - 2)), fy = fminf(fmaxf(floorf(qy), 0.f), (float)(H - 2));
     const float ax = fminf(fmaxf(qx - fx, 0.f), 1.f), ay = fminf(fmaxf(qy - fy, 0.f), 1.f);
     const int x0 = (int)fx, y0 = (int)fy;
-    const f32x4* b = reinterpret_cast<const f32x4*>(img + (size_t)n * H * W * C) + c;
-    const f32x4 tl = b[((size_t)y0 * W + x0) * C4], tr = b[((size_t)y0 * W + x0 + 1) * C4];
-    const f32x4 bl = b[((size_t)(y0 + 1) * W + x0) * C4], br = b[((size_t)(y0 + 1) * W + x0 + 1) * C4];
+    const TE* b = img + (size_t)img_idx.a[n] * H * W * C + 4 * c;
+    const f32x4 tl = PwcElem<TE>::ld4(b + ((size_t)y0 * W + x0) * C), tr = PwcElem<TE>::ld4(b + ((size_t)y0 * W + x0 + 1) * C);
+    const f32x4 bl = PwcElem<TE>::ld4(b + ((size_t)(y0 + 1) * W + x0) * C), br = PwcElem<TE>::ld4(b + ((size_t)(y0 + 1) * W + x0 + 1) * C);
     const f32x4 top = ax * (tr - tl) + tl, bot = ax * (br - bl) + bl;
-    reinterpret_cast<f32x4*>(out)[i] = ay * (bot - top) + top;
+    PwcElem<TE>::st4(out + 4 * i, ay * (bot - top) + top);
   }
 }
 
 // copy a channel range (feature level c1 into the decoder's concatenated buffer)
-__global__ void pwc_copy_channels_kernel(const float* __restrict__ src, int C, float* __restrict__ dst, int d_cs, int d_co, size_t npix) {
+// (batched: item n of dst takes image src_idx.a[n] of src; npix = pixels per image)
+template <typename TE>
+__global__ void pwc_copy_channels_kernel(const TE* __restrict__ src, const PwcItems src_idx, int C, TE* __restrict__ dst, int d_cs, int d_co,
+                                         size_t npix, int N) {
   const int C4 = C / 4;
-  const size_t total = npix * C4;
+  const size_t per = npix * C4, total = per * N;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t pix = i / C4;
-    const int c = (int)(i % C4);
-    *reinterpret_cast<f32x4*>(dst + pix * d_cs + d_co + 4 * c) = reinterpret_cast<const f32x4*>(src)[i];
+    const int n = (int)(i / per);
+    const size_t r = i - (size_t)n * per;
+    const size_t pix = r / C4;
+    const int c = (int)(r % C4);
+    PwcElem<TE>::st4(dst + ((size_t)n * npix + pix) * d_cs + d_co + 4 * c, PwcElem<TE>::ld4(src + ((size_t)src_idx.a[n] * npix + pix) * C + 4 * c));
   }
 }
 
 // Pre-processing of one frame: YUV uint8 [h, w, 3] -> network input [PH, PW, 4] (RGB / 255, channel 3 = 0, zero padding
 // below / right of the 2h x 2w image).  Double maths up to the uint8 truncation, as the reference's numpy / skimage do.
-__global__ void pwc_prep_kernel(const uint8_t* __restrict__ yuv, int h, int w, float* __restrict__ out, int PH, int PW,
+template <typename TE>
+__global__ void pwc_prep_kernel(const uint8_t* __restrict__ yuv, int h, int w, TE* __restrict__ out, int PH, int PW,
                                 const ColorConsts cc) {
 #pragma clang fp contract(off)
   const size_t total = (size_t)PH * PW;
@@ -313,7 +353,7 @@ __global__ void pwc_prep_kernel(const uint8_t* __restrict__ yuv, int h, int w, f
       }
       o.x = rgb[0]; o.y = rgb[1]; o.z = rgb[2];
     }
-    reinterpret_cast<f32x4*>(out)[i] = o;
+    PwcElem<TE>::st4(out + 4 * i, o);        // (k / 255, k = 0 .. 255: fp16 holds it to 2^-12 relative)
   }
 }
 

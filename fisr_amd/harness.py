@@ -99,7 +99,7 @@ def compute_flow(net, args):
     num_fr = args.frame_num
     if len(paths) < num_fr:
         raise FileNotFoundError(f"{args.frame_folder_path}: {len(paths)} frames, need {num_fr}")
-    pwc = pwcnet.PWCNet(str(net.device))
+    pwc = pwcnet.PWCNet(str(net.device), precision=getattr(args, "flow_precision", "fp32") or "fp32")
     try:
         if getattr(args, "synthetic_weights", None) is not None:
             pwc.set_weights(pwcnet.synthetic_weights(595000 + int(args.synthetic_weights)))

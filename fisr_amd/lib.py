@@ -28,7 +28,8 @@ EXPORTS = [
     "fisr_comm_unique_id", "fisr_comm_init", "fisr_comm_rank", "fisr_comm_size", "fisr_comm_allgather",
     "fisr_comm_sendrecv", "fisr_comm_destroy",
     "fisr_pwc_create", "fisr_pwc_destroy", "fisr_pwc_last_error", "fisr_pwc_num_variables", "fisr_pwc_variable",
-    "fisr_pwc_set_weight", "fisr_pwc_finalize", "fisr_pwc_flow_workspace_bytes", "fisr_pwc_flow_pair",
+    "fisr_pwc_set_weight", "fisr_pwc_finalize", "fisr_pwc_finalize_precision", "fisr_pwc_flow_stack_workspace_bytes", "fisr_pwc_flow_stack",
+    "fisr_pwc_flow_workspace_bytes", "fisr_pwc_flow_pair",
     "fisr_pwc_nn_workspace_bytes", "fisr_pwc_nn", "fisr_pwc_prep", "fisr_pwc_flow_out",
     "fisr_pwc_op_conv", "fisr_pwc_op_deconv", "fisr_pwc_op_costvol", "fisr_pwc_op_warp",
     "fisr_train_packed_bytes", "fisr_train_pack", "fisr_train_wino_bytes", "fisr_train_pack_wino", "fisr_train_conv3x3", "fisr_train_wgrad", "fisr_train_bgrad",
@@ -156,11 +157,15 @@ def lib():
     L.fisr_pwc_prep.argtypes = [vp, c_int, c_int, vp, c_int, c_int, vp]
     L.fisr_pwc_flow_out.argtypes = [vp, c_int, c_int, vp, c_int, c_int, vp]
     L.fisr_pwc_op_conv.argtypes = [vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, POINTER(c_int), vp, c_int,
-                                   c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, vp]
-    L.fisr_pwc_op_deconv.argtypes = [vp, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, POINTER(c_int), vp, c_int, c_int,
-                                     c_int, c_int, c_int, vp]
-    L.fisr_pwc_op_costvol.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp]
-    L.fisr_pwc_op_warp.argtypes = [vp, c_int, vp, c_int, c_int, c_float, vp, c_int, c_int, c_int, vp]
+                                   c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, vp]
+    L.fisr_pwc_op_deconv.argtypes = [vp, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), c_int, POINTER(c_int), vp, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_pwc_op_costvol.argtypes = [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_pwc_op_warp.argtypes = [vp, c_int, vp, c_int, c_int, c_float, vp, c_int, c_int, c_int, c_int, vp]
+    L.fisr_pwc_finalize_precision.argtypes = [vp, c_int]
+    L.fisr_pwc_flow_stack_workspace_bytes.argtypes = [vp, c_int, c_int, c_int]
+    L.fisr_pwc_flow_stack_workspace_bytes.restype = c_size_t
+    L.fisr_pwc_flow_stack.argtypes = [vp, POINTER(vp), c_int, c_int, c_int, vp, vp, c_size_t, vp]
     L.fisr_train_packed_bytes.argtypes = [c_int, c_int, c_int]
     L.fisr_train_packed_bytes.restype = c_size_t
     L.fisr_train_pack.argtypes = [vp, c_int, c_int, c_int, vp, vp]

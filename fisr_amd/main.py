@@ -107,6 +107,8 @@ def parse_args(argv=None):
     p.add_argument("--flow_file", type=str, default=None, help="pre-computed 5-D .flo for FISR_for_video (default: PWC-Net on the GPU)")
     p.add_argument("--pwc_ckpt", type=str, default="./models/pwcnet-lg-6-2-multisteps-chairsthingsmix/pwcnet.ckpt-595000",
                    help="PWC-Net weights: TF checkpoint-V2 bundle prefix or .npz keyed by the TF variable names")
+    p.add_argument("--flow_precision", type=str, default="fp32", choices=["fp32", "fp16"],
+                   help="arithmetic of the on-GPU PWC-Net: fp32, or fp16 feature tensors with fp32 accumulation and fp32 flows (cfg5)")
     p.add_argument("--warp_file", type=str, default=None, help="pre-computed warp (.mat/.npy); default: warp on the GPU")
     p.add_argument("--synthetic_weights", type=int, default=None, metavar="SEED",
                    help="use seeded stand-in weights instead of a checkpoint (no checkpoint ships with the reference)")

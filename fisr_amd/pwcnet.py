@@ -52,8 +52,14 @@ def synthetic_weights(seed: int = 595000, flow_gain: float = 1.0) -> "OrderedDic
 
 
 class PWCNet:
-    def __init__(self, device: str = "cuda:0"):
+    """precision "fp32" (float32 tensors and arithmetic) or "fp16" (fp16 feature tensors, fp32 accumulation, float32 flows: the
+    16-bit flow of cfg5)."""
+
+    def __init__(self, device: str = "cuda:0", precision: str = "fp32"):
         import torch
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("PWCNet precision must be 'fp32' or 'fp16'")
+        self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise FisrError("PWCNet needs a ROCm GPU (cuda device); there is no CPU fallback")
@@ -79,7 +85,7 @@ class PWCNet:
             a = np.ascontiguousarray(weights[name], np.float32)
             shp = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
             self._check(self._L.fisr_pwc_set_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shp, a.ndim))
-        self._check(self._L.fisr_pwc_finalize(self._ctx))
+        self._check(self._L.fisr_pwc_finalize_precision(self._ctx, _lib.PREC_F16 if self.precision == "fp16" else _lib.PREC_F32W))
         self._finalized = True
 
     def load(self, path_or_prefix: str) -> None:
@@ -139,17 +145,38 @@ class PWCNet:
                                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
         return fab, fba
 
-    def compute_flow(self, frames_u8):
+    def flow_stack(self, frames_u8, out=None):
+        """One call for a run of frames (list of [h,w,3] uint8 YUV device tensors, 2 .. 9 of them): every frame is pre-processed
+        and its feature pyramid extracted once, all 2 (n-1) directions go through the decoder as batches of up to 8 ->
+        [n-1, 2, h, w, 2] float32 on the device (pair fr: [0] = fr -> fr+1, [1] = fr+1 -> fr)."""
+        import torch
+        fr = [f.to(device=self.device, dtype=torch.uint8).contiguous() for f in frames_u8]
+        n = len(fr)
+        if n < 2 or any(f.shape != fr[0].shape or f.dim() != 3 or f.shape[2] != 3 for f in fr):
+            raise ValueError("frames must be two or more [h,w,3] uint8 tensors of equal size")
+        h, w = fr[0].shape[:2]
+        ws = self._workspace(self._L.fisr_pwc_flow_stack_workspace_bytes(self._ctx, n, h, w))
+        if out is None:
+            out = torch.empty((n - 1, 2, h, w, 2), dtype=torch.float32, device=self.device)
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fr])
+        self._check(self._L.fisr_pwc_flow_stack(self._ctx, ptrs, n, h, w, ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(ws.data_ptr()), ws.numel(), self._stream()))
+        return out
+
+    def compute_flow(self, frames_u8, chunk: int = 5):
         """script :104-141: frames (list of [h,w,3] uint8 YUV, device or host tensors / arrays) ->
-        pred [num_fr-1, 2, h, w, 2] float32 on the device (pair fr: [0] = fr -> fr+1, [1] = fr+1 -> fr)."""
+        pred [num_fr-1, 2, h, w, 2] float32 on the device (pair fr: [0] = fr -> fr+1, [1] = fr+1 -> fr).  Runs of `chunk`
+        frames per call (neighbouring runs share one frame)."""
         import torch
         fr = [torch.as_tensor(f).to(self.device) for f in frames_u8]
         out = []
-        for k in range(len(fr) - 1):
-            ab, ba = self.flow_pair(fr[k], fr[k + 1])
-            out.append(torch.stack([ab, ba]))
-            print("Processing for computing flows [%5d/%5d]" % (k + 1, len(fr)))
-        return torch.stack(out)
+        k = 0
+        while k < len(fr) - 1:
+            run = fr[k:k + chunk]
+            out.append(self.flow_stack(run))
+            k += len(run) - 1
+            print("Processing for computing flows [%5d/%5d]" % (k, len(fr)))
+        return torch.cat(out, dim=0)
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -217,7 +217,18 @@ int fisr_pwc_num_variables(void);
 int fisr_pwc_variable(int i, const char** name, int64_t* shape4);
 /* host float32 tensor in TF layout; unknown names (optimizer slots, ...) are ignored with return 1 */
 int fisr_pwc_set_weight(fisr_pwc* ctx, const char* tf_var_name, const float* host, const int64_t* shape, int rank);
-int fisr_pwc_finalize(fisr_pwc* ctx);   /* FISR_EMISSING names the first absent variable */
+int fisr_pwc_finalize(fisr_pwc* ctx);   /* FISR_EMISSING names the first absent variable; = ..._precision(ctx, FISR_PREC_F32W) */
+/* precision FISR_PREC_F32W: float32 tensors and arithmetic (dense layers on the Winograd kernel).  FISR_PREC_F16 (cfg5 of
+ * BASELINE.json, "bf16"-class 16-bit arithmetic): fp16 feature tensors, fp32 accumulation, float32 flows (flow heads, refinement
+ * sums, what is handed to the next level and to the caller); dense layers on the LDS-DMA kernel. */
+int fisr_pwc_finalize_precision(fisr_pwc* ctx, int precision);
+/* The script's whole loop (:104-141) in one call: nframes YUV uint8 frames [h,w,3] (device pointers) -> flows
+ * [nframes-1, 2, h, w, 2] float32 LR pixels (pair fr: [0] = fr -> fr+1, [1] = fr+1 -> fr; the layout of the script's 5-D .flo).
+ * Every frame is pre-processed and its feature pyramid extracted once, the 2 (nframes-1) directions go through the decoder as
+ * batches of up to 8. */
+size_t fisr_pwc_flow_stack_workspace_bytes(const fisr_pwc* ctx, int nframes, int h, int w);
+int fisr_pwc_flow_stack(fisr_pwc* ctx, const uint8_t* const* yuv_frames, int nframes, int h, int w, float* flows, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* One iteration of the script's loop (:118-140): two YUV uint8 frames [h,w,3] (device) -> YUV->RGB, x2 scikit-image
  * up-resize, uint8 truncation, /255, pad to 64 (adapt_x, model_pwcnet.py:371-411), the network in both directions,
  * x4 bilinear * 4 (:1587-1590), crop, anti-aliased scikit-image down-resize, / 2 -> flow_ab, flow_ba [h,w,2] float32
@@ -235,22 +246,26 @@ int fisr_pwc_nn(fisr_pwc* ctx, const float* im, int H, int W, float* flow_pred, 
 int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream);
 int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream);
 /* Op-level entries: one layer of the flow network exactly as the network launches it (parity tests at the sizes the
- * bench runs).  fisr_pwc_op_conv = tf.layers.conv2d(x, cout, 3, stride, 'same', dilation_rate=dil) + leaky relu (slope; 1 =
+ * bench runs).  precision: FISR_PREC_F32W (float32 tensors) or FISR_PREC_F16 (fp16 feature tensors; `add` and any out_f32 /
+ * in_f32 tensor stay float32 -- the flows).
+ * fisr_pwc_op_conv = tf.layers.conv2d(x, cout, 3, stride, 'same', dilation_rate=dil) + leaky relu (slope; 1 =
  * linear) (+ add) of model_pwcnet.py:1092-1097, 1426-1449, 1506-1521 on the channel range [in_co, in_co + cin_buf) of a buffer
  * with pixel stride in_cs, written to the range [out_co, out_co + cout) of a buffer with pixel stride out_cs; w_host TF HWIO
  * [3,3,ci,cout]; chmap (nullable = identity): buffer channel, relative to in_co, of TF input channel j.  route 0 = the
- * network's own choice, 1 = generic implicit GEMM, 2 = persistent Winograd kernel, 3 = FISRnet's direct kernel (2, 3: error if
- * the layer is not eligible).  Returns the route taken (1..3) or a negative error.  Synchronises the stream.
+ * network's own choice, 1 = generic implicit GEMM, 2 = persistent fp32 Winograd kernel, 3 = FISRnet's direct kernel, 4 = its
+ * fp16 LDS-DMA kernel (2 - 4: error if the layer is not eligible).  Returns the route taken (1..4) or a negative error.
+ * Synchronises the stream.
  * fisr_pwc_op_deconv = tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196), w_host [4,4,2,ci];
  * fisr_pwc_op_costvol = core_costvol.cost_volume + leaky relu (:1277), 81 channels; fisr_pwc_op_warp = core_warp.dense_image_warp
  * (:1178) at (x + scale*u, y + scale*v). */
-int fisr_pwc_op_conv(const float* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
-                     const int* chmap, float* out, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
-                     int stride, int dil, float slope, int route, void* stream);
-int fisr_pwc_op_deconv(const float* in, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci, const int* chmap,
-                       float* out, int out_cs, int out_co, int n, int h, int w, void* stream);
-int fisr_pwc_op_costvol(const float* c1, const float* c2, int c, float* out, int out_cs, int out_co, int n, int h, int w, void* stream);
-int fisr_pwc_op_warp(const float* img, int c, const float* flow, int f_cs, int f_co, float scale, float* out, int n, int h, int w, void* stream);
+int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
+                     const int* chmap, void* out, int out_f32, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h,
+                     int w, int stride, int dil, float slope, int route, int precision, void* stream);
+int fisr_pwc_op_deconv(const void* in, int in_f32, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci,
+                       const int* chmap, void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream);
+int fisr_pwc_op_costvol(const void* c1, const void* c2, int c, void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream);
+int fisr_pwc_op_warp(const void* img, int c, const void* flow, int f_cs, int f_co, float scale, void* out, int n, int h, int w, int precision,
+                     void* stream);
 
 /* ---- training graph: the ops the reference gets from TensorFlow's autodiff and optimizer ----
  * FISRnet.build_model (FISRnet.py:175-497) builds forward passes, seven loss terms and tf.train.AdamOptimizer in Python;

@@ -178,3 +178,75 @@ def test_flow_pair_full_size_vs_oracle_golden(pwc, gold_dir):
         err = np.abs(got - exp).max()
         print(f"1080p flow{lvl} ({pyr[0][k].shape[0]}x{pyr[0][k].shape[1]}): max|err| {err:.2e}, |flow| max {np.abs(exp).max():.3f}")
         assert err < 2e-3, (lvl, err)
+
+
+# ----------------------------------------------------------------------------- the 16-bit flow engine (cfg5: FISR_PREC_F16)
+@pytest.fixture(scope="module")
+def pwc16():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    W = pwcnet.synthetic_weights(595000, flow_gain=3.0)
+    net = pwcnet.PWCNet("cuda:0", precision="fp16")
+    net.set_weights(W)
+    yield net, W
+    net.close()
+
+
+def test_flow_stack_equals_the_pairwise_loop(pwc, pwc16, gold_dir):
+    """fisr_pwc_flow_stack (one pyramid per frame, the directions batched through the decoder) against the reference script's
+    pair-by-pair loop (flow_pair): the same kernels on the same data in another batch arrangement -> identical flows, in both
+    engines; 6 frames = 10 directions = two decoder batches."""
+    g = np.load(os.path.join(gold_dir, "scene1_crop96.npz"))
+    key = [k for k in g.files if g[k].ndim == 4 and g[k].dtype == np.uint8][0]
+    frames = [torch.from_numpy(g[key][k]).cuda() for k in range(5)]
+    frames.append(torch.from_numpy(np.ascontiguousarray(g[key][2][::-1])).cuda())
+    for net, _ in (pwc, pwc16):
+        st = net.flow_stack(frames)
+        torch.cuda.synchronize()
+        assert tuple(st.shape) == (5, 2, 96, 96, 2)
+        for fr in range(5):
+            ab, ba = net.flow_pair(frames[fr], frames[fr + 1])
+            assert torch.equal(st[fr, 0], ab) and torch.equal(st[fr, 1], ba), (net.precision, fr)
+        assert torch.equal(net.compute_flow(frames, chunk=3), st)
+
+
+@pytest.mark.parametrize("shape", [(128, 192)])
+def test_pwcnet_nn_fp16_vs_oracle(pwc16, shape):
+    """The fp16 flow engine against the float64 oracle: fp16 feature tensors (11 significant bits) through a 6-level coarse-to-fine
+    cascade -- the flow error is what cfg5 trades for speed; it must stay far below what moves the network's input (flows enter
+    FISRnet as flow / 192, FISRnet.py:835: 0.02 px = 1e-4 of the input range)."""
+    net, W = pwc16
+    H, Wd = shape
+    rng = np.random.default_rng(H)
+    base = rng.random((H // 8 + 2, Wd // 8 + 2, 3))
+    img = np.kron(base, np.ones((8, 8, 1)))
+    a = img[4:4 + H, 4:4 + Wd] * 0.8 + rng.random((H, Wd, 3)) * 0.2
+    b = img[2:2 + H, 7:7 + Wd] * 0.8 + rng.random((H, Wd, 3)) * 0.2
+    im = np.zeros((2, H, Wd, 4), np.float32)
+    im[0, ..., :3], im[1, ..., :3] = a, b
+    pairs = np.stack([np.stack([im[0, ..., :3], im[1, ..., :3]]), np.stack([im[1, ..., :3], im[0, ..., :3]])])
+    ref_pred, ref_pyr = P.nn(torch.from_numpy(pairs).double(), W)
+    got_pred, got_pyr = net.nn(torch.from_numpy(im).cuda(), want_pyramid=True)
+    torch.cuda.synchronize()
+    for d in range(2):
+        for k, lvl in enumerate(range(6, 1, -1)):
+            err = np.abs(got_pyr[d][k].cpu().numpy() - ref_pyr[k][d].permute(1, 2, 0).numpy())
+            print(f"fp16 dir {d} flow{lvl}: max|err| {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e}")
+        err = np.abs(got_pred[d].cpu().numpy() - ref_pred[d].numpy())
+        print(f"fp16 dir {d} flow_pred (x2-frame pixels): max|err| {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (|flow| max {np.abs(ref_pred[d].numpy()).max():.3f})")
+        assert err.max() < 0.08 and np.sqrt((err ** 2).mean()) < 0.01
+
+
+def test_flow_pair_full_size_fp16_vs_oracle_golden(pwc16, gold_dir):
+    """cfg5's flow at benchmark size in the 16-bit engine against the float64 oracle's golden (every 8th LR pixel of a 1080p pair)."""
+    from tests_support import make_flow_frames
+    g = np.load(os.path.join(gold_dir, "pwc_flow_1080p_sparse.npz"))
+    fa, fb = make_flow_frames(int(g["seed"]), 1080, 1920)
+    net, W = pwc16
+    fl = net.flow_stack([torch.from_numpy(fa), torch.from_numpy(fb)])
+    torch.cuda.synchronize()
+    st = int(g["stride"])
+    for k, name in enumerate(("a->b", "b->a")):
+        d = np.abs(fl[0, k, ::st, ::st].cpu().numpy().astype(np.float64) - g["flow_sparse"][k])
+        print(f"1080p fp16 {name}: max|err| {d.max():.2e} rms {np.sqrt((d ** 2).mean()):.2e} LR px, |flow| max {np.abs(g['flow_sparse'][k]).max():.2f} px")
+        assert d.max() < 0.05 and np.sqrt((d ** 2).mean()) < 0.005

@@ -47,14 +47,27 @@ def _oracle_conv(x_nhwc, w, b, stride, dil, slope, add=None):
     return y + add if add is not None else y
 
 
-def _run_conv(x_buf, in_co, cin_buf, w, b, chmap, out_buf, out_co, n, h, wd, stride, dil, slope, route, add_buf=None, add_co=0):
+def _dev(a, prec):
+    t = torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    return t.half().contiguous() if prec == "fp16" else t
+
+
+def _host(t):
+    return t.float().cpu().numpy()
+
+
+PID = {"fp32": flib.PREC_F32W, "fp16": flib.PREC_F16}
+
+
+def _run_conv(x_buf, in_co, cin_buf, w, b, chmap, out_buf, out_co, n, h, wd, stride, dil, slope, route, add_buf=None, add_co=0, prec="fp32"):
     ci, cout = w.shape[2], w.shape[3]
     wc = np.ascontiguousarray(w, np.float32)
     bc = np.ascontiguousarray(b, np.float32)
     cm = None if chmap is None else (ctypes.c_int * ci)(*[int(v) for v in chmap])
+    out_f32 = int(out_buf.dtype == torch.float32)
     rc = flib.lib().fisr_pwc_op_conv(_ptr(x_buf), x_buf.shape[-1], in_co, cin_buf, wc.ctypes.data_as(F32P), bc.ctypes.data_as(F32P),
-                                     ci, cout, cm, _ptr(out_buf), out_buf.shape[-1], out_co, _ptr(add_buf),
-                                     0 if add_buf is None else add_buf.shape[-1], add_co, n, h, wd, stride, dil, slope, route, _stream())
+                                     ci, cout, cm, _ptr(out_buf), out_f32, out_buf.shape[-1], out_co, _ptr(add_buf),
+                                     0 if add_buf is None else add_buf.shape[-1], add_co, n, h, wd, stride, dil, slope, route, PID[prec], _stream())
     flib.check(rc)
     torch.cuda.synchronize()
     return rc
@@ -194,8 +207,8 @@ def test_deconv_vs_oracle(shape):
     ob = torch.full((1, 2 * h, 2 * wd, 12), -3.0, dtype=torch.float32, device="cuda")
     cm = (ctypes.c_int * ci)(*chmap)
     xb = torch.from_numpy(x).cuda()          # (named: a temporary would be freed, and its block re-used, before the launch)
-    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(xb), cin4 + 8, 4, cin4, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P),
-                                             ci, cm, _ptr(ob), 12, 8, 1, h, wd, _stream()))
+    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(xb), 1, cin4 + 8, 4, cin4, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P),
+                                             ci, cm, _ptr(ob), 12, 8, 1, h, wd, flib.PREC_F32W, _stream()))
     torch.cuda.synchronize()
     xs = x[..., 4:4 + cin4][..., chmap]
     exp = P.deconv(torch.from_numpy(xs).double().permute(0, 3, 1, 2), {"op/kernel": w, "op/bias": b}, "op").permute(0, 2, 3, 1).numpy()
@@ -216,7 +229,7 @@ def test_costvol_vs_oracle(shape, c):
     ob = torch.full((2, h, wd, 96), 9.5, dtype=torch.float32, device="cuda")
     c1b, c2b = torch.from_numpy(c1).cuda(), torch.from_numpy(c2).cuda()
     flib.check(flib.lib().fisr_pwc_op_costvol(_ptr(c1b), _ptr(c2b), c, _ptr(ob), 96, 8,
-                                              2, h, wd, _stream()))
+                                              2, h, wd, flib.PREC_F32W, _stream()))
     torch.cuda.synchronize()
     t = lambda a: torch.from_numpy(a).double().permute(0, 3, 1, 2)
     exp = P.lrelu(P.cost_volume(t(c1), t(c2))).permute(0, 2, 3, 1).numpy()
@@ -242,7 +255,7 @@ def test_warp_with_flows_leaving_the_image_vs_oracle(shape):
     ob = torch.zeros((2, h, wd, c), dtype=torch.float32, device="cuda")
     imb, flb = torch.from_numpy(img).cuda(), torch.from_numpy(flow).cuda()
     flib.check(flib.lib().fisr_pwc_op_warp(_ptr(imb), c, _ptr(flb), 8, 4, 2.5,
-                                           _ptr(ob), 2, h, wd, _stream()))
+                                           _ptr(ob), 2, h, wd, flib.PREC_F32W, _stream()))
     torch.cuda.synchronize()
     f = torch.from_numpy(flow[..., 4:6].astype(np.float32) * np.float32(2.5)).double().permute(0, 3, 1, 2)
     exp = P.dense_image_warp(torch.from_numpy(img).double().permute(0, 3, 1, 2), f).permute(0, 2, 3, 1).numpy()
@@ -258,9 +271,115 @@ def test_op_entry_errors():
     w = np.zeros((3, 3, 32, 64), np.float32)
     b = np.zeros(64, np.float32)
     L = flib.lib()
-    assert L.fisr_pwc_op_conv(_ptr(x), 32, 0, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None, _ptr(o), 64, 0, None, 0, 0,
-                              1, 16, 32, 3, 1, 0.1, 0, _stream()) < 0                      # stride 3
-    assert L.fisr_pwc_op_conv(_ptr(x), 32, 0, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None, _ptr(o), 64, 0, None, 0, 0,
-                              1, 16, 32, 2, 1, 0.1, 2, _stream()) < 0                      # Winograd forced on a stride-2 layer
-    assert L.fisr_pwc_op_conv(_ptr(x), 32, 2, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None, _ptr(o), 64, 0, None, 0, 0,
-                              1, 16, 32, 1, 1, 0.1, 0, _stream()) < 0                      # unaligned channel offset
+    call = lambda in_co, stride, route, prec: L.fisr_pwc_op_conv(_ptr(x), 32, in_co, 32, w.ctypes.data_as(F32P), b.ctypes.data_as(F32P), 32, 64, None,
+                                                                  _ptr(o), 1, 64, 0, None, 0, 0, 1, 16, 32, stride, 1, 0.1, route, prec, _stream())
+    assert call(0, 3, 0, flib.PREC_F32W) < 0                      # stride 3
+    assert call(0, 2, 2, flib.PREC_F32W) < 0                      # Winograd forced on a stride-2 layer
+    assert call(2, 1, 0, flib.PREC_F32W) < 0                      # unaligned channel offset
+    assert call(0, 1, 4, flib.PREC_F32W) < 0                      # the fp16 kernel asked of the fp32 engine
+    assert call(0, 1, 0, flib.PREC_BF16X3) < 0                    # not a precision of the flow network
+
+
+# ----------------------------------------------------------------------------- the fp16 flow engine (FISR_PREC_F16, cfg5)
+def _h16(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("dil,shape", [(1, (272, 480)), (2, (272, 480)), (4, (136, 240)), (8, (136, 240)), (16, (136, 240)), (16, (272, 480)),
+                                       (4, (75, 133)), (8, (139, 251))])
+def test_lds_dma_general_dilated_fp16_vs_oracle(dil, shape):
+    """The GENERAL instantiation of the fp16 LDS-DMA kernel (conv3x3_dma.h), which carries the dense and context layers of the fp16
+    flow engine: dilation as d x d interleaved sub-images, channel-range input and output of wider buffers, leaky relu, Cout = 1.5
+    N blocks, batch 2.  Inputs and weights are fp16 values, so the float64 oracle sees the same operands: what is left is the fp32
+    accumulation and ONE rounding of the result to fp16."""
+    h, wd = shape
+    rng = np.random.default_rng(1000 * dil + h)
+    in_cs, in_co, cin = 160, 32, 96
+    out_cs, out_co, cout = 192, 64, 96
+    x = _h16(rng.standard_normal((2, h, wd, in_cs)) * 0.5)
+    w = _h16(rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin)))
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    xb = _dev(x, "fp16")
+    ob = torch.full((2, h, wd, out_cs), 7.25, dtype=torch.float16, device="cuda")
+    took = _run_conv(xb, in_co, cin, w, b, None, ob, out_co, 2, h, wd, 1, dil, 0.1, 4, prec="fp16")
+    assert took == 4
+    got = _host(ob)
+    exp = _oracle_conv(x[..., in_co:in_co + cin], w, b, 1, dil, 0.1)
+    err = np.abs(got[..., out_co:out_co + cout] - exp)
+    ulp = np.maximum(np.abs(exp), 2.0 ** -14) * 2.0 ** -10
+    print(f"lds-dma GENERAL fp16 dil {dil} {h}x{wd}: max|err| {err.max():.2e} (|y| max {np.abs(exp).max():.2f})")
+    assert (err <= 0.51 * ulp + 3e-6 * np.abs(exp).max()).all()
+    assert (got[..., :out_co] == 7.25).all() and (got[..., out_co + cout:] == 7.25).all()
+
+
+def test_fp16_engine_routes_and_small_kernels_vs_oracle():
+    """The other layer types of the fp16 flow engine on level-sized maps: stride-2 pyramid conv (generic kernel, fp16 in / out),
+    the 2-channel flow head (FISRnet's 16-row fp16 kernel, float32 out), dc_conv7 (generic kernel, float32 out + the float32 flow),
+    transpose conv from the float32 flow and from fp16 features, cost volume, warp."""
+    rng = np.random.default_rng(77)
+    h, wd = 136, 240
+    # stride 2
+    x = _h16(rng.standard_normal((2, h, wd, 32)) * 0.5)
+    w = _h16(rng.standard_normal((3, 3, 32, 64)) * 0.06)
+    b = (rng.standard_normal(64) * 0.05).astype(np.float32)
+    xb = _dev(x, "fp16")
+    ob = torch.zeros((2, h // 2, wd // 2, 64), dtype=torch.float16, device="cuda")
+    assert _run_conv(xb, 0, 32, w, b, None, ob, 0, 2, h, wd, 2, 1, 0.1, 0, prec="fp16") == 1
+    exp = _oracle_conv(x, w, b, 2, 1, 0.1)
+    assert np.abs(_host(ob) - exp).max() < 2e-3 * max(1.0, np.abs(exp).max())
+    # flow head: 608-channel buffer -> 2 channels, float32
+    cin_buf = 608
+    chmap = list(range(0, 448)) + list(range(448, 448 + 81)) + list(range(536, 600)) + [600, 601, 604, 605]
+    xd = _h16(rng.standard_normal((2, h, wd, cin_buf)) * 0.3)
+    wh = _h16(rng.standard_normal((3, 3, len(chmap), 2)) * 0.01)
+    bh = (rng.standard_normal(2) * 0.05).astype(np.float32)
+    xdb = _dev(xd, "fp16")
+    fl = torch.zeros((2, h, wd, 4), dtype=torch.float32, device="cuda")
+    assert _run_conv(xdb, 0, cin_buf, wh, bh, chmap, fl, 0, 2, h, wd, 1, 1, 1.0, 0, prec="fp16") == 3
+    exph = _oracle_conv(xd[..., chmap], wh, bh, 1, 1, 1.0)
+    got = _host(fl)
+    print(f"fp16 flow head: max|err| {np.abs(got[..., :2] - exph).max():.2e}")
+    assert np.abs(got[..., :2] - exph).max() < 2e-5 and not got[..., 2:].any()     # fp32 accumulation of exact fp16 products
+    # dc_conv7 + flow
+    x7 = _h16(rng.standard_normal((2, h, wd, 32)) * 0.5)
+    w7 = _h16(rng.standard_normal((3, 3, 32, 2)) * 0.05)
+    x7b = _dev(x7, "fp16")
+    ref = torch.zeros((2, h, wd, 4), dtype=torch.float32, device="cuda")
+    assert _run_conv(x7b, 0, 32, w7, bh, None, ref, 0, 2, h, wd, 1, 1, 1.0, 0, add_buf=fl, prec="fp16") == 1
+    exp7 = _oracle_conv(x7, w7, bh, 1, 1, 1.0, add=got[..., :2])
+    assert np.abs(_host(ref)[..., :2] - exp7).max() < 2e-5
+    # transpose convs
+    wdv = (rng.standard_normal((4, 4, 2, 2)) * 0.1).astype(np.float32)
+    up = torch.full((2, 2 * h, 2 * wd, 8), -3.0, dtype=torch.float16, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(fl), 1, 4, 0, 4, wdv.ctypes.data_as(F32P), bh.ctypes.data_as(F32P), 2, None, _ptr(up), 8, 4,
+                                             2, h, wd, flib.PREC_F16, _stream()))
+    torch.cuda.synchronize()
+    expd = P.deconv(torch.from_numpy(got[..., :2]).double().permute(0, 3, 1, 2), {"op/kernel": wdv, "op/bias": bh}, "op").permute(0, 2, 3, 1).numpy()
+    gu = _host(up)
+    assert np.abs(gu[..., 4:6] - expd).max() < 1e-3 * max(1.0, np.abs(expd).max()) and (gu[..., :4] == -3.0).all() and (gu[..., 6:] == -3.0).all()
+    wdf = (rng.standard_normal((4, 4, 2, 64)) * 0.05).astype(np.float32)
+    upf = torch.zeros((2, 2 * h, 2 * wd, 4), dtype=torch.float16, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_deconv(_ptr(xb), 0, 32, 0, 32, wdf[..., :32].copy().ctypes.data_as(F32P),
+                                             bh.ctypes.data_as(F32P), 32, None, _ptr(upf), 4, 0, 2, h, wd, flib.PREC_F16, _stream()))
+    torch.cuda.synchronize()
+    expf = P.deconv(torch.from_numpy(x).double().permute(0, 3, 1, 2), {"op/kernel": wdf[..., :32].copy(), "op/bias": bh}, "op").permute(0, 2, 3, 1).numpy()
+    assert np.abs(_host(upf)[..., :2] - expf).max() < 1e-3 * max(1.0, np.abs(expf).max())
+    # cost volume and warp
+    c1 = _h16(rng.standard_normal((2, h, wd, 96)) * 0.7)
+    c2 = _h16(rng.standard_normal((2, h, wd, 96)) * 0.7)
+    c1b, c2b = _dev(c1, "fp16"), _dev(c2, "fp16")
+    cv = torch.full((2, h, wd, 96), 9.5, dtype=torch.float16, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_costvol(_ptr(c1b), _ptr(c2b), 96, _ptr(cv), 96, 8, 2, h, wd, flib.PREC_F16, _stream()))
+    torch.cuda.synchronize()
+    t = lambda a: torch.from_numpy(a).double().permute(0, 3, 1, 2)
+    expc = P.lrelu(P.cost_volume(t(c1), t(c2))).permute(0, 2, 3, 1).numpy()
+    gc = _host(cv)
+    assert np.abs(gc[..., 8:89] - expc).max() < 1e-3 * max(1.0, np.abs(expc).max()) and (gc[..., :8] == 9.5).all() and (gc[..., 89:] == 9.5).all()
+    fw = _h16(rng.standard_normal((2, h, wd, 8)) * 3)
+    fwb = _dev(fw, "fp16")
+    wo = torch.zeros((2, h, wd, 96), dtype=torch.float16, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_warp(_ptr(c2b), 96, _ptr(fwb), 8, 4, 2.5, _ptr(wo), 2, h, wd, flib.PREC_F16, _stream()))
+    torch.cuda.synchronize()
+    f = torch.from_numpy(fw[..., 4:6] * np.float32(2.5)).double().permute(0, 3, 1, 2)
+    expw = P.dense_image_warp(t(c2), f).permute(0, 2, 3, 1).numpy()
+    assert np.abs(_host(wo) - expw).max() < 4e-3
