@@ -900,7 +900,14 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = n0 + 4 * kg + r;
-          if (n < p.Cout) ob[n + p.out_coff + (n >= p.out_split ? p.out_gap : 0)] = act(acc4[m][ct][r]);
+          // (p.res with this fp32 store: a float32 tensor in the OUTPUT's layout, added after the activation -- the flow that
+          //  PWC-Net's dc_conv7 refines, model_pwcnet.py:1521)
+          if (n < p.Cout) {
+            const int oc = n + p.out_coff + (n >= p.out_split ? p.out_gap : 0);
+            float v_ = act(acc4[m][ct][r]);
+            if (p.res) v_ += ((const float*)p.res)[((size_t)(nb * p.H + y) * p.W + xc) * (size_t)p.out_cstride + oc];
+            ob[oc] = v_;
+          }
         }
       }
     }

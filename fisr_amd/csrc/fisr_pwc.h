@@ -236,7 +236,7 @@ struct PwcRunner {
     const bool act_ok = slope == 1.f || (slope > 0.f && slope < 1.f);
     if (HALF) {
       if (pc.d_wd && stride == 1 && !has_add && !out_f32 && act_ok && dma_fits(h, w, pc.cin_buf, 0, in_cs, 0)) return 4;
-      if (pc.have_dw && stride == 1 && dil == 1 && !has_add && out_f32 && act_ok) return 3;
+      if (pc.have_dw && stride == 1 && dil == 1 && out_f32 && act_ok && pc.dw.nt == 0) return 3;     // (with or without the float32 add)
       return 1;
     }
     (void)n;
@@ -278,6 +278,8 @@ struct PwcRunner {
       return;
     }
     if (route == 3) {
+      if (add && (add_cs != out_cs || add_co != out_co)) { if (rc == 0) rc = pfail(ctx, FISR_EINVAL, name + ": the added tensor must have the output's layout"); return; }
+      a.res = add;                                                   // (16-row kernel, fp32 store: added after the activation)
       a.wpk = pc.dw.d_w; a.bias = pc.dw.d_b;
       a.C0 = pc.dw.cin_pad; a.C1 = 0; a.CoutPad = pc.dw.cout_pad;
       a.rec_cs = pc.cout; a.rec_co = 0; a.dil = 1;
@@ -310,7 +312,7 @@ struct PwcRunner {
   void deconv(const std::string& name, const TI* in, int in_cs, int in_co, TE* out, int out_cs, int out_co, int n, int h, int w) {
     if (rc || ar.dry) return;
     const PwcDeconv& pd = ctx->deconvs[name];
-    hipLaunchKernelGGL((pwc_deconv_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
+    hipLaunchKernelGGL((pwc_deconv_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w * 8)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
                        pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w);
     check(name.c_str());
   }
@@ -559,7 +561,7 @@ int fisr_pwc_finalize_precision(fisr_pwc* c, int precision) {
     for (int i = 0; i < 7 && !rc; ++i) {
       const std::string n = "pwcnet/ctxt/dc_conv" + ls + std::to_string(i + 1);
       rc = i == 0 ? pwc_pack_conv(c, n, L.map_from(4), L.total, c->convs[n], true)
-                  : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n], i < 6);
+                  : pwc_pack_conv(c, n, iota_map(ci), ci, c->convs[n], true);
       ci = PWC_CTXT[i][0];
     }
     if (l != PWC_PRED && !rc) {

@@ -163,16 +163,25 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
 }
 
 // tf.layers.conv2d_transpose(x, 2, 4, 2, 'same'): out[2*i + k - 1] += in[i] * kernel[k]  (two output channels).
-// One thread per output pixel; weights [ky][kx][o][Cin4] in global (L1/L2 resident), 16-byte loads.
+// EIGHT lanes per output pixel, each taking every eighth group of 4 input channels (the eight lanes of a pixel read 32
+// consecutive channels per step: whole 64- / 128-byte pieces of a pixel record instead of one lane striding through a 1.2-KB
+// record alone), then a 3-step butterfly; weights [ky][kx][o][Cin4] in global (L1/L2 resident), 16-byte loads.
+// (r03: one thread per pixel took 7.7 ms per launch on the 608-channel level-2 buffer of a 5-frame 1080p stack.)
 template <typename TI, typename TO>
 __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_co, int Cin4, const float* __restrict__ w,
                                   const float* __restrict__ bias, TO* __restrict__ out, int out_cs, int out_co,
                                   int N, int H, int W) {
   const int OH = 2 * H, OW = 2 * W;
   const size_t total = (size_t)N * OH * OW;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((size_t)OW * OH));
-    float a0 = bias[0], a1 = bias[1];
+  const int sub = threadIdx.x & 7;
+  const size_t gstride = ((size_t)gridDim.x * blockDim.x) >> 3;
+  const size_t rounds = (total + gstride - 1) / gstride;          // every lane runs every round: the butterfly needs all eight
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  for (size_t r_ = 0; r_ < rounds; ++r_, i += gstride) {
+    const bool live = i < total;
+    const size_t ii = live ? i : total - 1;
+    const int ox = (int)(ii % OW), oy = (int)((ii / OW) % OH), n = (int)(ii / ((size_t)OW * OH));
+    float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int ty = 0; ty < 2; ++ty) {
       const int ky = ((oy + 1) & 1) + 2 * ty, iy = (oy + 1 - ky) / 2;
@@ -182,17 +191,22 @@ __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_c
         const int kx = ((ox + 1) & 1) + 2 * tx, ix = (ox + 1 - kx) / 2;
         if ((ox + 1 - kx) < 0 || ix >= W) continue;
         const TI* src = in + ((size_t)(n * H + iy) * W + ix) * in_cs + in_co;
-        const f32x4* w0 = reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 0) * Cin4);
-        const f32x4* w1 = reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 1) * Cin4);
-        for (int c = 0; c < Cin4 / 4; ++c) {
-          const f32x4 v = PwcElem<TI>::ld4(src + 4 * c), k0 = w0[c], k1 = w1[c];
+        const float* w0 = w + ((size_t)(ky * 4 + kx) * 2 + 0) * Cin4;
+        const float* w1 = w + ((size_t)(ky * 4 + kx) * 2 + 1) * Cin4;
+        for (int c = 4 * sub; c < Cin4; c += 32) {
+          const f32x4 v = PwcElem<TI>::ld4(src + c);
+          const f32x4 k0 = *reinterpret_cast<const f32x4*>(w0 + c), k1 = *reinterpret_cast<const f32x4*>(w1 + c);
           a0 += v.x * k0.x + v.y * k0.y + v.z * k0.z + v.w * k0.w;
           a1 += v.x * k1.x + v.y * k1.y + v.z * k1.z + v.w * k1.w;
         }
       }
     }
-    TO* o = out + i * out_cs + out_co;
-    o[0] = (TO)a0; o[1] = (TO)a1;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); }
+    if (live && sub == 0) {
+      TO* o = out + i * out_cs + out_co;
+      o[0] = (TO)(a0 + bias[0]); o[1] = (TO)(a1 + bias[1]);
+    }
   }
 }
 
@@ -372,35 +386,50 @@ __global__ void pwc_flow_out_kernel(const float* __restrict__ f2, int f_cs, int 
   const size_t total = (size_t)h * w;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(i % w), y = (int)(i / w);
-    float a0 = 0.f, a1 = 0.f;
+    // Both filters are separable and the six x2-frame rows 2y-2 .. 2y+3 (mirrored) fall into at most three level-2 rows (+ one
+    // for the bilinear partner): filter those four rows horizontally once (96 loads instead of 288), then combine vertically.
+    int Yt[6], rmin = 1 << 30;
 #pragma unroll
     for (int ty = 0; ty < 6; ++ty) {
       int Y = 2 * y + ty - 2;
       Y = Y < 0 ? -Y : (Y >= H2 ? 2 * H2 - 2 - Y : Y);
-      const float sy = (float)Y * 0.25f;
-      const int y0 = (int)sy, y1 = min(y0 + 1, FH - 1);
-      const float fy = sy - (float)y0;
+      Yt[ty] = Y;
+      rmin = min(rmin, Y >> 2);
+    }
+    int x0t[6], x1t[6];
+    float fxt[6];
+#pragma unroll
+    for (int tx = 0; tx < 6; ++tx) {
+      int X = 2 * x + tx - 2;
+      X = X < 0 ? -X : (X >= W2 ? 2 * W2 - 2 - X : X);
+      x0t[tx] = X >> 2; x1t[tx] = min(x0t[tx] + 1, FW - 1);
+      fxt[tx] = (float)(X & 3) * 0.25f;
+    }
+    float hr[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = f2 + (size_t)min(rmin + r, FH - 1) * FW * f_cs + f_co;
       float r0 = 0.f, r1 = 0.f;
 #pragma unroll
       for (int tx = 0; tx < 6; ++tx) {
-        int X = 2 * x + tx - 2;
-        X = X < 0 ? -X : (X >= W2 ? 2 * W2 - 2 - X : X);
-        const float sx = (float)X * 0.25f;
-        const int x0 = (int)sx, x1 = min(x0 + 1, FW - 1);
-        const float fx = sx - (float)x0;
-        const float* tl = f2 + ((size_t)y0 * FW + x0) * f_cs + f_co; const float* tr = f2 + ((size_t)y0 * FW + x1) * f_cs + f_co;
-        const float* bl = f2 + ((size_t)y1 * FW + x0) * f_cs + f_co; const float* br = f2 + ((size_t)y1 * FW + x1) * f_cs + f_co;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const float top = tl[k] + (tr[k] - tl[k]) * fx, bot = bl[k] + (br[k] - bl[k]) * fx;
-          const float v = (top + (bot - top) * fy) * 4.f;
-          if (k == 0) r0 += e[tx] * v; else r1 += e[tx] * v;
-        }
+        const float* l = row + (size_t)x0t[tx] * f_cs; const float* rr = row + (size_t)x1t[tx] * f_cs;
+        r0 += e[tx] * (l[0] + (rr[0] - l[0]) * fxt[tx]);
+        r1 += e[tx] * (l[1] + (rr[1] - l[1]) * fxt[tx]);
       }
-      a0 += e[ty] * r0; a1 += e[ty] * r1;
+      hr[r][0] = r0; hr[r][1] = r1;
     }
-    out[i * 2] = a0 * 0.5f;
-    out[i * 2 + 1] = a1 * 0.5f;
+    auto pick = [&](int idx, int k) { return idx == 0 ? hr[0][k] : (idx == 1 ? hr[1][k] : (idx == 2 ? hr[2][k] : hr[3][k])); };
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 6; ++ty) {
+      const int y0 = Yt[ty] >> 2, y1 = min(y0 + 1, FH - 1);
+      const float fy = (float)(Yt[ty] & 3) * 0.25f;
+      const float t0 = pick(y0 - rmin, 0), b0 = pick(y1 - rmin, 0), t1 = pick(y0 - rmin, 1), b1 = pick(y1 - rmin, 1);
+      a0 += e[ty] * (t0 + (b0 - t0) * fy);
+      a1 += e[ty] * (t1 + (b1 - t1) * fy);
+    }
+    out[i * 2] = a0 * 2.f;                 // x 4 (model_pwcnet.py:1590) / 2 (script :139)
+    out[i * 2 + 1] = a1 * 2.f;
   }
 }
 
