@@ -96,7 +96,13 @@ class Workload:
         self.tiles = tiling.plan_tiles(self.h, self.w, patch)
         self.full = torch.zeros((3, self.h * 2, self.w * 2, 9), dtype=torch.float32, device=dev)
         self.yuv = torch.zeros((3, self.h * 2, self.w * 2, 9), dtype=torch.uint8, device=dev)
-        self.gathered = None
+        # cfg4: the uint8 output frames of every rank travel to rank 0 -- asynchronously (side stream, two send buffers, a
+        # receive buffer allocated once; fisr_amd/dist.py AsyncGather), so the gather of step k runs under the compute of step k+1
+        self.gather = None
+        if gather_group_world > 1:
+            from fisr_amd import dist as fdist
+            self.gather = fdist.AsyncGather(tuple(self.yuv.shape), torch.uint8, dev, dst=0)
+        self.step_index = 0
         self.glue_events = None       # instrumented pass: {kernel: [(ev0, ev1, launches)]}
 
     def premake_warps(self, net):
@@ -137,14 +143,15 @@ class Workload:
             for s in range(3):
                 net.forward_tiled(pack(s), self.patch, full=self.full[s:s + 1], batch_tiles=(self.batch == "window"))
         rgb = None
+        use_gather = self.gather is not None and self.gather_world > 1
+        dst = self.gather.buffer(self.step_index) if use_gather else self.yuv     # (waits on the stream for the gather that last read it)
         for s in range(3):
             yuv, rgb = self._timed("unpack_output", 1, lambda: net.unpack_output(self.full[s]))   # FISRnet.py:883, 903-909
-            self.yuv[s] = yuv
-        if self.gather_world > 1:
-            # cfg4: the uint8 output frames of every rank travel to rank 0 (RCCL gather over xGMI)
-            from fisr_amd import dist as fdist
-            self.gathered = fdist.gather_to(self.yuv, dst=0)
-        return self.yuv, rgb
+            dst[s] = yuv
+        if use_gather:
+            self.gather.submit(self.step_index)
+        self.step_index += 1
+        return dst, rgb
 
     def _step_tile(self, net):
         from fisr_amd import dist as fdist
@@ -309,48 +316,145 @@ def time_warp(net, wl, reps=8):
     return rec
 
 
-def time_flow_pipeline(net, wl, torch, local_rank, reps=2):
-    """cfg5 of BASELINE.json ("FISR_for_video end-to-end: on-GPU PWC-Net flow + warp + FISRnet"): the same 5-frame stack
-    with NOTHING pre-made -- PWC-Net-large in both directions for the 4 frame pairs (fp32, fisr_amd/pwcnet.py), the 8
-    frame warps, then the timed step of this engine.  Seeded stand-in PWC-Net weights (no checkpoint in the reference tree)."""
+def _psnr_shift(torch, out, ref, seed=7):
+    """PSNR protocol of SURVEY.md 8c-ii on the GPU: pseudo ground truth = ref + Gaussian noise at the reference's published PSNRs
+    (37.86 dB on the FI-SR channels, 48.07 dB on the SR channels, README.md:97); returns max over the channel groups of
+    |PSNR(out, gt) - PSNR(ref, gt)| in dB.  out, ref: [..., 9] float tensors, clipped to [0, 1] here."""
+    g = torch.Generator(device=out.device).manual_seed(seed)
+    a, b = out.clamp(0, 1).double(), ref.clamp(0, 1).double()
+    worst = 0.0
+    for ch, db in ((slice(0, 3), 37.86), (slice(3, 6), 48.07), (slice(6, 9), 37.86)):
+        gt = b[..., ch] + torch.randn(b[..., ch].shape, generator=g, device=out.device, dtype=torch.float64) * 10 ** (-db / 20)
+        ps = lambda t: 10 * torch.log10(1.0 / ((t - gt) ** 2).mean())
+        worst = max(worst, abs(float(ps(a[..., ch]) - ps(b[..., ch]))))
+    return worst
+
+
+def cfg5_pipeline(torch, dev, W, wl, net32, local_rank, reps=3):
+    """cfg5 of BASELINE.json -- "FISR_for_video end-to-end: on-GPU PWC-Net flow + warp + FISRnet fused pipeline, bf16, 1xMI355X" -- on
+    the same 5-frame 1080p stack with NOTHING pre-made: PWC-Net-large for the 8 directions in one fisr_pwc_flow_stack call (one
+    pyramid per frame, the directions batched), the 8 frame warps, then the FISRnet step.  16-bit arithmetic as the config
+    reads: flow engine FISR_PREC_F16 (fp16 features, fp32 accumulation, fp32 flows), network engine `mixed` (fp16 / fp16 + fp8
+    remainder).  Timed serially and as a two-stream pipeline (flow + warps of stack k+1 on a side stream under the network of
+    stack k, two sets of flow / warp buffers).  Accuracy: the 16-bit pipeline's output frames against the all-fp32 pipeline's
+    (fp32 flow, fp32 network) with the PSNR protocol, the fp16 flow against the fp32 flow, and the fp16 flow of the committed
+    1080p golden pair against the float64 oracle (tests/golden/pwc_flow_1080p_sparse.npz).  Seeded stand-in weights (neither
+    checkpoint is in the reference tree)."""
     from fisr_amd import pwcnet
-    pwc = pwcnet.PWCNet(f"cuda:{local_rank}")
-    pwc.set_weights(pwcnet.synthetic_weights(595000))
-    dev = wl.dev
+    from fisr_amd.fisrnet import FISRnet
+    Wp = pwcnet.synthetic_weights(595000)
+    out = {"what": "5-frame 1080p stack, nothing pre-made: flow of 8 directions (PWC-Net-large on the x2 up-scaled frames, one pyramid per "
+                   "frame, directions batched) + 8 warps + the FISRnet step -> 7 unique 4K frames",
+           "unit": "frames/s", "weights": "synthetic seeded (neither checkpoint is in the reference tree)"}
+    eng = FISRnet(device=f"cuda:{local_rank}", precision="mixed")
+    eng.set_weights(W)
+    keep = (wl.flows, wl.warps)
+    try:
+        res = {}
+        for tag, fprec, net in (("f32", "fp32", net32), ("16bit", "fp16", eng)):
+            pwc = pwcnet.PWCNet(f"cuda:{local_rank}", precision=fprec)
+            pwc.set_weights(Wp)
+            bufs = [torch.empty((4, 2, 1080, 1920, 2), dtype=torch.float32, device=dev) for _ in range(2)]
 
-    def flows():
-        out = []
-        for p in range(4):
-            ab, ba = pwc.flow_pair(wl.frames[p], wl.frames[p + 1])
-            out += [ab, ba]
-        return out
+            def produce(k):
+                fl = pwc.flow_stack(wl.frames, out=bufs[k & 1])
+                flows = [fl[p, d] for p in range(4) for d in range(2)]
+                warps = []
+                for p in range(4):
+                    warps.append(net.warp(wl.frames[p + 1], flows[2 * p]))
+                    warps.append(net.warp(wl.frames[p], flows[2 * p + 1]))
+                return flows, warps
 
-    fl = flows()
-    torch.cuda.synchronize(dev)
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    e[0].record()
-    for _ in range(reps):
-        fl = flows()
-    e[1].record()
-    keep_flows, keep_warps = wl.flows, wl.warps
-    wl.flows = fl
-    for _ in range(reps):
-        wl.premake_warps(net)
-    e[2].record()
-    for _ in range(reps):
-        wl.step(net)
-    e[3].record()
-    torch.cuda.synchronize(dev)
-    wl.flows, wl.warps = keep_flows, keep_warps
-    pwc.close()
-    t_flow, t_warp, t_net = (e[i].elapsed_time(e[i + 1]) / reps for i in range(3))
-    tot = t_flow + t_warp + t_net
-    # 182-variable PWC-Net-large at 2176x3840 (x2 up-scaled, padded to 64): ~3.5 TFLOP per direction
-    return {"what": "5-frame 1080p stack, flow (4 pairs x 2 directions, PWC-Net-large on the x2 up-scaled frames, fp32) + "
-                    "8 warps + the timed FISRnet step",
-            "flow_ms": round(t_flow, 2), "warp_ms": round(t_warp, 3), "fisrnet_ms": round(t_net, 2),
-            "value": round(UNIQUE_PER_STACK / (tot * 1e-3), 3), "unit": "frames/s", "flow_dtype": "f32",
-            "weights": "synthetic seeded (PWC-Net checkpoint absent from the reference tree)"}
+            # serial, three sections timed with events on the one stream
+            wl.flows, wl.warps = produce(0)
+            wl.step(net)
+            torch.cuda.synchronize(dev)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+            for k in range(reps):
+                fl = pwc.flow_stack(wl.frames, out=bufs[0])
+            e[1].record()
+            flows = [fl[p, d] for p in range(4) for d in range(2)]
+            for k in range(reps):
+                wl.flows = flows
+                wl.premake_warps(net)
+            e[2].record()
+            for k in range(reps):
+                wl.step(net)
+            e[3].record()
+            torch.cuda.synchronize(dev)
+            t_flow, t_warp, t_net = (e[i].elapsed_time(e[i + 1]) / reps for i in range(3))
+            rec = {"flow_dtype": "f32" if fprec == "fp32" else "f16 features, f32 accumulate, f32 flows", "network_engine": net.engine_description(),
+                   "flow_ms": round(t_flow, 2), "warp_ms": round(t_warp, 3), "fisrnet_ms": round(t_net, 2),
+                   "serial_fps": round(UNIQUE_PER_STACK / ((t_flow + t_warp + t_net) * 1e-3), 3)}
+            res[tag] = {"full": wl.full.clone(), "flows": torch.stack(flows).clone()}
+            # two-stream pipeline: the side stream prepares stack k+1 while the main stream runs the network on stack k
+            side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            ready = [torch.cuda.Event() for _ in range(2)]
+            freed = [torch.cuda.Event() for _ in range(2)]
+            sets = [None, None]
+
+            def run_pipeline(n):
+                with torch.cuda.stream(side):
+                    sets[0] = produce(0)
+                    ready[0].record(side)
+                for k in range(n):
+                    if k + 1 < n:
+                        with torch.cuda.stream(side):
+                            if k >= 1:
+                                side.wait_event(freed[(k + 1) & 1])          # its buffers were the network's input two stacks ago
+                            sets[(k + 1) & 1] = produce(k + 1)
+                            ready[(k + 1) & 1].record(side)
+                    main.wait_event(ready[k & 1])
+                    wl.flows, wl.warps = sets[k & 1]
+                    wl.step(net)
+                    freed[k & 1].record(main)
+
+            run_pipeline(2)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            n = max(4, 2 * reps)
+            run_pipeline(n)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / n
+            rec["pipelined_ms_per_stack"] = round(dt * 1e3, 2)
+            rec["pipelined_fps"] = round(UNIQUE_PER_STACK / dt, 3)
+            out["all_f32" if tag == "f32" else "sixteen_bit"] = rec
+            pwc.close()
+        sx = out["sixteen_bit"]
+        out["value"] = max(sx["serial_fps"], sx["pipelined_fps"])
+        out["dtype"] = "16-bit: fp16 flow features + the mixed FISRnet engine (fp32 accumulation everywhere, fp32 flows)"
+        d = (res["16bit"]["flows"] - res["f32"]["flows"]).double()
+        out["flow_16bit_vs_f32_px"] = {"max_abs": float(d.abs().max()), "rms": float((d * d).mean().sqrt()),
+                                       "flow_abs_max": float(res["f32"]["flows"].abs().max())}
+        a, b = res["16bit"]["full"], res["f32"]["full"]
+        dd = (a.clamp(0, 1) - b.clamp(0, 1)).double()
+        out["frames_16bit_vs_all_f32"] = {"what": "all 3x2048x3840x9 output values of the stack, 16-bit pipeline vs fp32 flow + fp32 network",
+                                          "max_abs": float(dd.abs().max()), "rms": float((dd * dd).mean().sqrt()),
+                                          "psnr_shift_db": round(_psnr_shift(torch, a, b), 5)}
+        out["frames_16bit_vs_all_f32"]["within_0p02_db"] = bool(out["frames_16bit_vs_all_f32"]["psnr_shift_db"] <= 0.02)
+        del res
+        # the fp16 flow engine against the float64 oracle on the committed full-size golden
+        gpath = os.path.join(ROOT, "tests", "golden", "pwc_flow_1080p_sparse.npz")
+        if os.path.isfile(gpath):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from tests_support import make_flow_frames
+            g = np.load(gpath)
+            fa, fb = make_flow_frames(int(g["seed"]), 1080, 1920)
+            pg = pwcnet.PWCNet(f"cuda:{local_rank}", precision="fp16")
+            pg.set_weights(pwcnet.synthetic_weights(595000, flow_gain=float(g["flow_gain"])))
+            fl = pg.flow_stack([torch.from_numpy(fa).to(dev), torch.from_numpy(fb).to(dev)])
+            st = int(g["stride"])
+            dg = fl[0, :, ::st, ::st].double().cpu().numpy() - g["flow_sparse"]
+            out["flow_fp16_vs_oracle_golden_px"] = {"what": "one 1080p pair, both directions, every 8th LR pixel, vs the float64 oracle",
+                                                    "max_abs": float(np.abs(dg).max()), "rms": float(np.sqrt((dg ** 2).mean()))}
+            pg.close()
+    finally:
+        wl.flows, wl.warps = keep
+        eng.close()
+        torch.cuda.empty_cache()
+    return out
 
 
 def time_training_step(W, torch, local_rank, steps=3):
@@ -411,6 +515,12 @@ def oracle_tile_check(net, torch):
     return out
 
 
+def _timeit(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
 def cpu_baselines(W, wl):
     """Bounded CPU sample on the host cores: ONE full 544x992 reference tile (2.85 TFLOP, 1/12 of a step's
     tiles) through (a) the C oracle, the parity checker itself ("port", naive OpenMP loops) and (b) the
@@ -418,6 +528,40 @@ def cpu_baselines(W, wl):
     reference's TF-1.13 Eigen/MKL-DNN CPU path, which cannot be installed here)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    # what the process may actually use: scheduler affinity and the cgroup CPU quota (a 128-core host with a quota of 16 cores
+    # explains a "1.5 % of peak" oneDNN figure better than oneDNN does); threads are pinned to cores, one per core
+    host = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota_cores": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    host["cgroup_cpu_quota_cores"] = round(int(parts[0]) / int(parts[1]), 2)
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        host["cgroup_cpu_quota_cores"] = round(q / int(f2.read()), 2)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    try:
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+        cores = {(b.split("physical id")[1].split("\n")[0], b.split("core id")[1].split("\n")[0]) for b in txt.split("\n\n") if "core id" in b}
+        host["physical_cores"] = len(cores) or None
+    except (OSError, IndexError):
+        host["physical_cores"] = None
+    usable = host["affinity_cpus"]
+    if host["physical_cores"]:
+        usable = min(usable, host["physical_cores"])
+    if host["cgroup_cpu_quota_cores"]:
+        usable = max(1, min(usable, int(host["cgroup_cpu_quota_cores"])))
+    host["threads_used"] = usable
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import c_oracle
     from tests_support import make_full_size_input
     ch, cw = 544, 992
@@ -434,21 +578,29 @@ def cpu_baselines(W, wl):
     except OSError:
         pass
     blob = c_oracle.pack_blob(W)
-    c_oracle.forward(x[:, :32, :32], blob, double=False)           # warm up threads
+    # (explicit thread count: the OpenMP runtime was initialised when torch was imported, it no longer reads the environment)
+    c_oracle.forward(x[:, :32, :32], blob, double=False, threads=usable)           # warm up threads
     t0 = time.perf_counter()
-    c_oracle.forward(x, blob, double=False)
+    c_oracle.forward(x, blob, double=False, threads=usable)
     dt = time.perf_counter() - t0
     cores = int(c_oracle.lib().fisr_oracle_num_threads())
     port = {"value": round(UNIQUE_PER_STACK / (dt * tiles_per_stack), 5), "unit": "frames/s", "cores": cores,
-            "kind": "port", "cpu_model": cpu_model,
+            "kind": "port", "cpu_model": cpu_model, "host": host,
             "sample": f"1x one full {ch}x{cw}x29 tile through oracle/fisr_oracle.c (fp32, OpenMP, {dt:.2f} s, "
                       f"{tile_flop / dt / 1e9:.1f} GFLOP/s), x{tiles_per_stack:.0f} tiles per 1080p stack"}
     onednn = None
     try:
         import torch
         import torch_cpu
-        # torch's own default intra-op thread count (physical cores visible to the process); forcing the SMT
-        # thread count oversubscribes the box and is several times slower
+        # one thread per usable physical core (affinity / cgroup quota respected); the SMT thread count oversubscribes the box
+        # and is several times slower
+        torch.set_num_threads(usable)
+        # what these cores deliver on a dense fp32 GEMM (4096^3, best of 3): the yardstick for the conv figures below
+        ga, gb = torch.randn(4096, 4096), torch.randn(4096, 4096)
+        torch.mm(ga, gb)
+        tg = min(_timeit(lambda: torch.mm(ga, gb)) for _ in range(3))
+        host["sgemm_4096_gflops"] = round(2 * 4096 ** 3 / tg / 1e9, 1)
+        del ga, gb
         Wt = torch_cpu.prepare_weights(W)
         torch_cpu.forward(x[:, :96, :96], Wt)                       # warm-up (primitive creation)
         qh, qw = 256, 480                                          # ~a quarter of the tile, multiples of 32
@@ -469,7 +621,7 @@ def cpu_baselines(W, wl):
             what = f"1x one {qh}x{qw}x29 sample (a full tile would exceed the bench's CPU budget)"
         s_flop = sh * sw * FLOP_PER_LR_PX
         onednn = {"value": round(UNIQUE_PER_STACK / (wl.flop_per_stack / (s_flop / dt)), 5), "unit": "frames/s",
-                  "cores": int(torch.get_num_threads()), "kind": "port", "cpu_model": cpu_model,
+                  "cores": int(torch.get_num_threads()), "kind": "port", "cpu_model": cpu_model, "host": host,
                   "sample": f"{what} through oracle/torch_cpu.py (torch {torch.__version__} CPU, oneDNN, fp32, "
                             f"channels-last, {dt:.2f} s, {s_flop / dt / 1e9:.1f} GFLOP/s), extrapolated by FLOPs to the "
                             f"{tiles_per_stack:.0f} tiles of a 1080p stack"}
@@ -541,6 +693,8 @@ def main():
     stacks = topo.n_groups if topo else world            # independent 5-frame stacks per step over the job
     stack_id = topo.group_index if topo else rank
 
+    from fisr_amd import lib as _flib
+    flib_version = _flib.lib().fisr_version().decode()       # carries a hash of csrc/: ties the line to the binary's sources
     W = weights.synthetic_weights(2020)
     net = FISRnet(device=f"cuda:{local_rank}", precision=args.precision)
     net.set_weights(W)
@@ -554,18 +708,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def drain():
+        if wl.gather is not None:
+            wl.gather.wait()                       # the timed region ends when the last gathered frames have ARRIVED on rank 0
+
     for _ in range(args.warmup):
         wl.step(net)
+    drain()
     sync()
+    if wl.gather is not None:
+        wl.gather.gather_ms = 0.0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         wl.step(net)
+    ev1.record()                                   # this rank's own compute stream is done here ...
+    drain()                                        # ... the gathers that were still in flight here
+    t_local = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank picture, so that a scaling curve explains itself: each rank's own step time (HIP events on its compute stream),
+        # its wall time up to "my last gather has arrived", and the host time it spent inside the collective calls
+        mine = {"rank": rank, "compute_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 3),
+                "wall_ms_per_step_incl_gather_drain": round(t_local / args.steps * 1e3, 3),
+                "host_ms_in_gather_calls_per_step": round(wl.gather.gather_ms / args.steps, 3) if wl.gather is not None else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     value = stacks * UNIQUE_PER_STACK * args.steps / elapsed
 
     solo = rank == 0 and world == 1
@@ -583,7 +757,7 @@ def main():
     cfg5 = None
     if solo and not args.no_flow:
         try:
-            cfg5 = time_flow_pipeline(net, wl, torch, local_rank)
+            cfg5 = cfg5_pipeline(torch, dev, W, wl, net, local_rank)
         except Exception as e:                                      # noqa: BLE001 -- must not kill the headline line
             cfg5 = {"error": repr(e)}
     if solo:
@@ -622,10 +796,6 @@ def main():
                                                    "kernels") if k in rl} if rl else None,
                    "parity_vs_" + args.precision: compare(out_alt, out_main, f"{alt} vs the {args.precision} engine"),
                    "parity_vs_oracle": None if args.no_parity else oracle_tile_check(eng, torch)}
-            if cfg5 and "flow_ms" in cfg5:   # cfg5 of BASELINE.json names a 16-bit engine: the same flow + warps in front of THIS engine's step
-                tot = cfg5["flow_ms"] + cfg5["warp_ms"] + dt * 1e3
-                rec["cfg5_flow_pipeline"] = {"value": round(UNIQUE_PER_STACK / (tot * 1e-3), 3), "unit": "frames/s",
-                                             "flow_ms": cfg5["flow_ms"], "warp_ms": cfg5["warp_ms"], "fisrnet_ms": round(dt * 1e3, 2)}
             other[alt] = rec
             eng.close()
             del eng, out_alt
@@ -669,8 +839,17 @@ def main():
                        "raw_fps": round(stacks * 9 * args.steps / elapsed, 3),
                        "forwards_per_s": round(stacks * 3 * args.steps / elapsed, 3),
                        "achieved_tflops_whole_step": round(stacks * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
+            "per_rank": per_rank,
+            "collective": (None if world == 1 else
+                           {"what": "frame-parallel: asynchronous gather of every rank's uint8 output frames to rank 0 (side stream, double-buffered)"
+                                    if parallelism == "frame" and not args.no_gather else
+                                    ("tile-parallel: all-gather of the 32-px halo rings and of the uint8 output tiles inside each tile group"
+                                     if parallelism == "tile" else "none"),
+                            "bytes_per_rank_per_step": int(wl.yuv.numel()) if parallelism == "frame" and not args.no_gather else None,
+                            "backend": backend}),
+            "library": flib_version,
             "roofline": roofline, "cpu_baseline": cpu_port, "cpu_baseline_onednn": cpu_onednn,
-            "parity_vs_oracle": parity_oracle, "cfg5_flow_pipeline": cfg5, "training_step": training,
+            "parity_vs_oracle": parity_oracle, "cfg5": cfg5, "training_step": training,
             "other_precisions": other or None,
         }
         print(json.dumps(line), flush=True)

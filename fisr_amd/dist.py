@@ -124,6 +124,108 @@ def gather_to(t, dst: int = 0, group=None):
     return out.to(t.device) if staged else out
 
 
+class AsyncGather:
+    """Frame-parallel output collection (cfg4 of BASELINE.json: "RCCL gather of outputs") that does not stall the compute stream.
+
+    Every rank hands its uint8 output frames to `submit()`; the gather to rank `dst` runs on a SIDE stream into a receive buffer
+    [world, *shape] allocated once (no per-step allocation, no torch.stack copy), while the compute stream goes on with the next
+    stack.  The caller alternates between `n_buffers` send buffers (`buffer(i)`): buffer i may be overwritten again only after the
+    gather that read it has finished, which `submit()` of the same slot / `wait()` enforce with events -- nothing blocks the host.
+    Under RCCL ("nccl") the collective is device-to-device over xGMI; other backends (gloo in the one-box tests) stage through the
+    host, synchronously (they exist to test the control flow, not to be fast)."""
+
+    def __init__(self, shape, dtype, device, dst: int = 0, group=None, n_buffers: int = 2):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group, self.dst = group, dst
+        self.rank, self.world = _group_rank_size(group)
+        self.gdst = dst if group is None else dist.get_global_rank(group, dst)
+        self.device = torch.device(device)
+        self.staged = self.device.type == "cuda" and dist.get_backend(group) != "nccl"
+        self.send = [torch.zeros(tuple(shape), dtype=dtype, device=self.device) for _ in range(n_buffers)]
+        rdev = "cpu" if self.staged else self.device
+        self.recv = torch.zeros((self.world,) + tuple(shape), dtype=dtype, device=rdev) if self.rank == dst else None
+        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.done = [None] * n_buffers             # event per send buffer: its last gather has read it
+        self.submitted = 0
+        self.gather_ms = 0.0                       # host time spent inside the collective calls (diagnostic)
+
+    def buffer(self, i: int):
+        """Send buffer i, safe to overwrite on the compute stream: waits (on the stream, not the host) for the gather that last read it."""
+        k = i % len(self.send)
+        if self.done[k] is not None and self.side is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(self.done[k])
+        return self.send[k]
+
+    def submit(self, i: int):
+        """Gather send buffer i (already written on the current stream) to rank dst.  Returns immediately under RCCL."""
+        import time
+        torch, dist = self.torch, self.dist
+        k = i % len(self.send)
+        t0 = time.perf_counter()
+        parts = [self.recv[r] for r in range(self.world)] if self.rank == self.dst else None
+        if self.side is None:                                   # CPU tensors (gloo tests)
+            dist.gather(self.send[k], parts, dst=self.gdst, group=self.group)
+        elif self.staged:                                       # device tensors over a host-only backend
+            torch.cuda.current_stream(self.device).synchronize()
+            dist.gather(self.send[k].cpu(), parts, dst=self.gdst, group=self.group)
+        else:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                dist.gather(self.send[k], parts, dst=self.gdst, group=self.group)     # enqueued behind `ready` on RCCL's stream
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self.done[k] = ev
+        self.submitted += 1
+        self.gather_ms += (time.perf_counter() - t0) * 1e3
+
+    def wait(self):
+        """Everything submitted so far has arrived (call before reading `recv` or before a timed region ends)."""
+        if self.side is not None and not self.staged:
+            self.side.synchronize()
+        return self.recv
+
+
+class HaloPrefetcher:
+    """Tile-parallel: the halo all-gather of window k+1 under the forward of window k.  `start(core)` launches border-ring
+    extraction + all-gather + tile assembly on a side stream and returns a handle; `finish(handle)` makes the compute stream wait
+    for it and returns the halo'd tile input.  (Host-only backends run it synchronously.)"""
+
+    def __init__(self, num_patch: Tuple[int, int], device, group=None, pb: int = PB):
+        import torch
+        import torch.distributed as dist
+        self.torch = torch
+        self.num_patch, self.group, self.pb = num_patch, group, pb
+        self.device = torch.device(device)
+        self.sync = self.device.type != "cuda" or dist.get_backend(group) != "nccl"
+        self.side = None if self.sync else torch.cuda.Stream(device=self.device)
+
+    def start(self, core):
+        torch = self.torch
+        if self.sync:
+            return (exchange_halos(core, self.num_patch, self.group, self.pb), None)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            tile_in = exchange_halos(core, self.num_patch, self.group, self.pb)
+            core.record_stream(self.side)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return (tile_in, ev)
+
+    def finish(self, handle):
+        tile_in, ev = handle
+        if ev is not None:
+            cur = self.torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            tile_in.record_stream(cur)
+        return tile_in
+
+
 # ----------------------------------------------------------------------------- halo exchange
 def border_ring(core, pb: int = PB):
     """core [..., sH, sW, C] -> flat buffer [top pb rows | bottom pb rows | left pb cols | right pb cols]
@@ -208,7 +310,7 @@ def gather_tiles(my_tile, num_patch: Tuple[int, int], group=None):
 
 
 def tile_parallel_window(core_input, num_patch: Tuple[int, int], forward: Callable, sf: int = 2, group=None,
-                         postprocess: Callable | None = None, pb: int = PB):
+                         postprocess: Callable | None = None, pb: int = PB, tile_in=None):
     """One window (or a batch of B windows), one tile per rank of the tile group.  core_input [sH,sW,29] /
     [B,sH,sW,29] is this rank's core region of the packed input; `forward(tile_in [B,H,W,29]) ->
     [B,H*sf,W*sf,9]` is the FISRnet forward (net.model(...)[2] on the GPU path).  Returns the full frame(s)
@@ -217,7 +319,8 @@ def tile_parallel_window(core_input, num_patch: Tuple[int, int], forward: Callab
     nh, nw = num_patch
     pH, pW = rank // nw, rank % nw
     batched = core_input.dim() == 4
-    tile_in = exchange_halos(core_input, num_patch, group, pb)
+    if tile_in is None:                  # (else: already exchanged, e.g. by a HaloPrefetcher under the previous window's forward)
+        tile_in = exchange_halos(core_input, num_patch, group, pb)
     pred = forward(tile_in if batched else tile_in.unsqueeze(0))
     if not batched:
         pred = pred[0]
@@ -248,7 +351,7 @@ def pack_core(net, frames_u8, flows, warps, h: int, w: int, num_patch: Tuple[int
                           y1 - y0, x1 - x0)
 
 
-def tile_parallel_engine_window(net, cores, num_patch: Tuple[int, int], group=None, want_rgb: bool = False):
+def tile_parallel_engine_window(net, cores, num_patch: Tuple[int, int], group=None, want_rgb: bool = False, tile_in=None):
     """The tile-parallel path with the real engine: cores [B,sH,sW,29] (this rank's core of B windows) ->
     halo all-gather -> fisr_forward on the halo'd tile (batch B) -> trim -> on-GPU clip/quantise/colour
     (fisr_unpack_output, per pixel, so per tile is exact) -> all-gather of the uint8 tiles.  Returns the
@@ -268,7 +371,7 @@ def tile_parallel_engine_window(net, cores, num_patch: Tuple[int, int], group=No
             outs.append(yuv)
         return torch.stack(outs)
 
-    out = tile_parallel_window(cores, num_patch, fwd, sf=net.scale_factor, group=group, postprocess=quantise)
+    out = tile_parallel_window(cores, num_patch, fwd, sf=net.scale_factor, group=group, postprocess=quantise, tile_in=tile_in)
     if not want_rgb:
         return out
     B, H2, W2, _ = out.shape

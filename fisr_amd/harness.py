@@ -269,15 +269,31 @@ def run_fisr_for_video(net, flow_file_name, warp_file_name, parallel=None):
         my_windows = list(range(n_win))
         writer = True
     h, w = tiling.crop_hw(H, W, num_patch)
-    for fr in my_windows:
-        frames = [torch.from_numpy(fio.read_png(paths[fr + k])).to(net.device) for k in range(3)]
-        flows = [torch.from_numpy(np.ascontiguousarray(flow[fr, k])).to(net.device) for k in range(4)]
-        warps = [torch.from_numpy(np.ascontiguousarray(warp[fr, k])).to(net.device) for k in range(4)]
+
+    def window_tensors(fr):
+        return ([torch.from_numpy(fio.read_png(paths[fr + k])).to(net.device) for k in range(3)],
+                [torch.from_numpy(np.ascontiguousarray(flow[fr, k])).to(net.device) for k in range(4)],
+                [torch.from_numpy(np.ascontiguousarray(warp[fr, k])).to(net.device) for k in range(4)])
+
+    # tile-parallel: the core packing + halo all-gather of the NEXT window run on a side stream under this window's forward
+    prefetch = fdist.HaloPrefetcher(num_patch, net.device, group=grp) if parallel == "tile" else None
+    pending = None
+    if prefetch is not None and my_windows:
+        fr0 = my_windows[0]
+        core0 = fdist.pack_core(net, *window_tensors(fr0), h, w, num_patch, topo.tile)
+        pending = (core0, prefetch.start(core0))
+    for wi, fr in enumerate(my_windows):
+        if parallel != "tile":
+            frames, flows, warps = window_tensors(fr)
         if parallel == "tile":
             torch.cuda.synchronize(net.device)
             t0 = time.time()
-            core = fdist.pack_core(net, frames, flows, warps, h, w, num_patch, topo.tile)
-            yuv_b, rgb_b = fdist.tile_parallel_engine_window(net, core, num_patch, group=grp, want_rgb=True)
+            core, handle = pending
+            tile_in = prefetch.finish(handle)
+            if wi + 1 < len(my_windows):
+                nxt = fdist.pack_core(net, *window_tensors(my_windows[wi + 1]), h, w, num_patch, topo.tile)
+                pending = (nxt, prefetch.start(nxt))
+            yuv_b, rgb_b = fdist.tile_parallel_engine_window(net, core, num_patch, group=grp, want_rgb=True, tile_in=tile_in)
             yuv_u8, rgb_u8 = yuv_b[0], rgb_b[0]
             torch.cuda.synchronize(net.device)
             # the reference's figure is (mean time of one tile forward) x tiles: here the tiles run

@@ -72,6 +72,19 @@ def _worker(rank, world, port, num_patch, q):
         mine = torch.full((2, 3), rank, dtype=torch.uint8)
         got = fdist.gather_to(mine, dst=0)
         ok_units = ok_units and ((got is None) if rank else (got.shape == (world, 2, 3) and got[:, 0, 0].tolist() == list(range(world))))
+        # 3c. the asynchronous form bench.py uses: alternating send buffers, a receive buffer allocated once, several steps
+        ag = fdist.AsyncGather((2, 3), torch.uint8, "cpu", dst=0)
+        recv_id = id(ag.recv)
+        for step in range(5):
+            ag.buffer(step).fill_(10 * step + rank)
+            ag.submit(step)
+            r = ag.wait()
+            ok_units = ok_units and ((r is None) if rank else (id(r) == recv_id and r[:, 1, 2].tolist() == [10 * step + k for k in range(world)]))
+        # 3d. the halo exchange started ahead (tile-parallel: under the previous window's forward) gives the same tile input
+        pf = fdist.HaloPrefetcher(num_patch, "cpu", group=grp)
+        ok_halo = ok_halo and torch.equal(pf.finish(pf.start(core)), tile_in)
+        frame_pf = fdist.tile_parallel_window(core, num_patch, _fake_forward, group=grp, tile_in=pf.finish(pf.start(core)))
+        ok_frame = ok_frame and torch.equal(frame_pf, frame)
         # 4. max-over-ranks timing reduction used by bench.py
         tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

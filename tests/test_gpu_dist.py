@@ -88,3 +88,76 @@ def test_tile_parallel_real_engine_bit_exact(num_patch, groups, precision):
     for r in sorted(res):
         assert r[1], r
         assert r[2] == (2, 2 * H, 2 * W, 9)
+
+
+def _run_bench(world, extra, port):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FISR_BENCH_BACKEND="gloo", FISR_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--precision", "fp16", "--batch", "tile", "--no-roofline"] + extra
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                 # exactly ONE JSON line, printed by rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("parallelism", ["frame", "tile"])
+def test_bench_eight_ranks_end_to_end_on_one_device(parallelism):
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one process per rank), both parallelism modes, with
+    the ranks sharing cuda:0 over gloo (a 1-GPU box cannot host RCCL ranks): rendezvous, 8 engines, the asynchronous gather of
+    the output frames (frame) / halo + tile all-gathers in 2 groups of 2x2 (tile), barriers, max-over-ranks timing, per-rank
+    report, one JSON line.  The arithmetic is the single-GPU engine's (bit-exactness of the sharding: the tests above)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    line = _run_bench(8, ["--parallelism", parallelism], _free_port())
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert ("frame-parallel x8" in line["config"]["parallelism"]) if parallelism == "frame" else ("2 stack(s) x 4 tiles" in line["config"]["parallelism"])
+    assert len(line["per_rank"]) == 8 and sorted(r["rank"] for r in line["per_rank"]) == list(range(8))
+    assert all(r["compute_ms_per_step"] > 0 for r in line["per_rank"])
+    # value = units of all ranks / max-over-ranks time: 8 stacks (frame) or 2 stacks (tile) of 7 unique frames per step
+    stacks = 8 if parallelism == "frame" else 2
+    assert abs(line["value"] - stacks * 7 * 2 / (line["ms_per_step"] * 2e-3)) < 0.02 * line["value"]
+    if parallelism == "frame":
+        assert line["collective"]["bytes_per_rank_per_step"] == 3 * 2048 * 3840 * 9
+
+
+def _comm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fisr_amd import dist as fdist
+        torch.cuda.set_device(rank)
+        comm = fdist.FisrComm.from_torch_group(rank)
+        mine = torch.full((4, 1000), rank + 1, dtype=torch.uint8, device=f"cuda:{rank}")
+        got = comm.allgather(mine)
+        peer = comm.sendrecv(mine, (rank + 1) % world)
+        torch.cuda.synchronize()
+        ok = got.shape == (world, 4, 1000) and got[:, 0, 0].tolist() == [r + 1 for r in range(world)] and int(peer[0, 0]) == (rank + 1) % world + 1
+        comm.close()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fisr_comm_two_ranks_over_rccl():
+    """The C-ABI's own RCCL communicator (fisr_comm_*: unique id, init, all-gather, send/recv) between two GPUs.  Needs two
+    devices: skipped on the one-GPU box, runs wherever a node is available."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
