@@ -179,12 +179,14 @@ def _pmc_table():
 
 
 def _pmc_key(name):
+    if name.startswith("conv3x3_dma"):
+        return "conv3x3_dma_f16_kernel<false>"
     tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
     if name.startswith("conv3x3_wino"):
         return "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
-    if name.startswith("conv3x3_dma"):
-        return f"conv3x3_dma_kernel<{tname}"
     nt = name.split("NT")[1][0]
+    if tname == "_Float16":        # (rocprofv3 leaves the _Float16 instantiations mangled)
+        return f"_ZN4fisr19conv3x3_mfma_kernelIDF16_Li{nt}ELb{1 if 'f32out' in name else 0}E"
     return f"conv3x3_mfma_kernel<{tname}, {nt}, {'true' if 'f32out' in name else 'false'}"
 
 

@@ -2,11 +2,12 @@
 # rocprofv3 passes over the bench command (run on the GPU box via gpurun).  Summaries land in
 # gpurun_out/prof_*; copy what should be judged into profiles/.
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
-PREC="${PREC:-bf16x3}"
+PREC="${PREC:-fp32}"
+OTHERS="${OTHERS:-fp32d,bf16x3,f16f8,mixed}"     # every engine in one run: one pmc_traffic.json for all kernel names
 OUT="$REPO/gpurun_out/prof_${PREC}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps ${STEPS:-2} --warmup 1 --precision $PREC --others none --no-cpu-baseline --no-roofline --no-parity --no-flow --no-train"
+CMD="python $REPO/bench.py --steps ${STEPS:-2} --warmup 1 --precision $PREC --others $OTHERS --no-cpu-baseline --no-roofline --no-parity --no-flow --no-train"
 echo "== kernel trace + stats"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 1 (SQ / MFMA busy)"
