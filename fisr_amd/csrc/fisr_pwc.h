@@ -49,6 +49,7 @@ struct PwcVar {
 
 struct PwcConv {                 // one packed convolution
   float* d_w = nullptr; float* d_b = nullptr;     // generic implicit-GEMM kernel (fp32 weights, any stride / dilation)
+  float* d_w1a = nullptr;        // conv1a (3 -> 16, stride 2): [9][4][16] + bias [16] for the vector-ALU kernel
   char* d_wu = nullptr;          // fp32 engine: Winograd slabs for conv3x3_wino8p_kernel (stride 1, Cout >= 32)
   void* d_wd = nullptr;          // fp16 engine: weight slabs of the LDS-DMA kernel conv3x3_dma.h (stride 1, Cout >= 16)
   int cout_pad_d = 0;
@@ -56,7 +57,10 @@ struct PwcConv {                 // one packed convolution
   bool have_dw = false;
   int cin_buf = 0, cout = 0, cout_pad = 0;
 };
-struct PwcDeconv { float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0; };
+struct PwcDeconv {
+  float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0;
+  void* d_wd = nullptr; float* d_bz = nullptr;   // fp16 engine, wide inputs: the 16 taps x 2 outputs as a 32-channel centre-tap conv on the LDS-DMA kernel
+};
 
 }  // namespace
 
@@ -126,6 +130,15 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
   HIP_OK(nullptr, hipMalloc((void**)&pc.d_b, bp.size() * 4));
   HIP_OK(nullptr, hipMemcpy(pc.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(nullptr, hipMemcpy(pc.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  if (ci == 3 && co == 16 && cin_buf == 4) {          // conv1a: [9][4][16] + bias for pwc_conv1a_kernel
+    std::vector<float> w1((size_t)9 * 64 + 16, 0.f);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int j = 0; j < 3; ++j)
+        for (int n = 0; n < 16; ++n) w1[(size_t)tap * 64 + chmap[j] * 16 + n] = kw.v[((size_t)tap * 3 + j) * 16 + n];
+    for (int n = 0; n < 16; ++n) w1[9 * 64 + n] = kb.v[n];
+    HIP_OK(nullptr, hipMalloc((void**)&pc.d_w1a, w1.size() * 4));
+    HIP_OK(nullptr, hipMemcpy(pc.d_w1a, w1.data(), w1.size() * 4, hipMemcpyHostToDevice));
+  }
   if (!wino) return 0;
   // the same kernel scattered to the buffer channels it reads, for FISRnet's fast kernels
   std::vector<float> dense((size_t)9 * cin_buf * co, 0.f);
@@ -182,6 +195,19 @@ int pwc_pack_deconv(fisr_pwc* ctx, const std::string& name, const std::vector<in
   HIP_OK(nullptr, hipMalloc((void**)&pd.d_b, 8));
   HIP_OK(nullptr, hipMemcpy(pd.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(nullptr, hipMemcpy(pd.d_b, kb.v.data(), 8, hipMemcpyHostToDevice));
+  if (ctx->precision == FISR_PREC_F16 && cin4 >= 32 && cin4 % D_CH == 0) {
+    // P[pixel][tap * 2 + o] as a 3x3 convolution with 32 output channels whose only non-zero tap is the centre
+    std::vector<float> dense((size_t)9 * cin4 * 32, 0.f);
+    for (int k = 0; k < 16; ++k)
+      for (int o = 0; o < 2; ++o)
+        for (int j = 0; j < ci; ++j) dense[((size_t)4 * cin4 + chmap[j]) * 32 + k * 2 + o] = kw.v[((size_t)k * 2 + o) * ci + j];
+    std::vector<char> wd;
+    pack_weights_dma(dense.data(), cin4, 32, cin4, D_BN, wd);
+    HIP_OK(nullptr, hipMalloc(&pd.d_wd, wd.size()));
+    HIP_OK(nullptr, hipMemcpy(pd.d_wd, wd.data(), wd.size(), hipMemcpyHostToDevice));
+    HIP_OK(nullptr, hipMalloc((void**)&pd.d_bz, D_BN * 4));
+    HIP_OK(nullptr, hipMemset(pd.d_bz, 0, D_BN * 4));
+  }
   return 0;
 }
 
@@ -310,8 +336,24 @@ struct PwcRunner {
   }
   template <typename TI>
   void deconv(const std::string& name, const TI* in, int in_cs, int in_co, TE* out, int out_cs, int out_co, int n, int h, int w) {
-    if (rc || ar.dry) return;
     const PwcDeconv& pd = ctx->deconvs[name];
+    if (HALF && std::is_same<TI, TE>::value && pd.d_wd && dma_fits(h, w, pd.cin4, 0, in_cs, 0)) {
+      // wide input: taps x outputs as 32 channels of a centre-tap convolution on the matrix pipe, then the 2x2 gather
+      TE* P = ealloc((size_t)n * h * w * 32);
+      if (rc || ar.dry) return;
+      ConvArgs a;
+      a.in0 = (const TE*)in + in_co; a.in1 = nullptr; a.wpk = pd.d_wd; a.bias = pd.d_bz; a.res = nullptr; a.out = P;
+      a.C0 = pd.cin4; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = 32; a.CoutPad = D_BN;
+      a.relu_in = 0; a.relu_out = 0; a.d2s = 0; a.d2s_shift = 0;
+      a.out_cstride = 32; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
+      a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = 32; a.rec_co = 0; a.slope = 0.f; a.dil = 1; a.trace = nullptr;
+      hipError_t e = launch_conv_dma(a, st);
+      if (e != hipSuccess && rc == 0) { rc = pfail(ctx, FISR_EHIP, name + " (lds-dma): " + hipGetErrorString(e)); return; }
+      hipLaunchKernelGGL(pwc_deconv_combine_kernel<TE>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, out, out_cs, out_co, n, h, w);
+      check(name.c_str());
+      return;
+    }
+    if (rc || ar.dry) return;
     hipLaunchKernelGGL((pwc_deconv_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w * 8)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
                        pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w);
     check(name.c_str());
@@ -333,7 +375,14 @@ struct PwcRunner {
       const size_t keep = ar.off;
       TE* A = ealloc(px * PWC_CH[l]); TE* B = ealloc(px * PWC_CH[l]);
       const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
-      conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, false, PWC_CH[l], 0, nf, hh[l - 1], ww[l - 1], 2, 1, 0.1f);
+      const PwcConv& pa = ctx->convs[p + "a"];
+      if (l == 1 && pa.d_w1a) {
+        if (!rc && !ar.dry) {
+          hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for(px)), dim3(256), 0, st, F[0], pa.d_w1a, pa.d_w1a + 9 * 64, A, nf, hh[0], ww[0], 0.1f);
+          check("conv1a");
+        }
+      } else
+        conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, false, PWC_CH[l], 0, nf, hh[l - 1], ww[l - 1], 2, 1, 0.1f);
       conv(p + "aa", A, PWC_CH[l], 0, B, false, PWC_CH[l], 0, nf, hh[l], ww[l], 1, 1, 0.1f);
       conv(p + "b", B, PWC_CH[l], 0, F[l], false, PWC_CH[l], 0, nf, hh[l], ww[l], 1, 1, 0.1f);
       (void)mark;
@@ -354,7 +403,13 @@ struct PwcRunner {
       const int h = hh[l], w = ww[l];
       const size_t px = (size_t)h * w, npx = px * N;
       TE* D = ealloc(npx * L.total);
-      zero(D, npx * L.total * sizeof(TE));                           // channel padding must read as finite zeros
+      // channel padding must read as finite zeros (its weights are zero); every other channel is written before it is read
+      auto zero_ch = [&](int c0, int nc) {
+        if (nc > 0 && !rc && !ar.dry)
+          hipLaunchKernelGGL(pwc_zero_channels_kernel<TE>, dim3(grid_for(npx * nc)), dim3(256), 0, st, D, L.total, c0, nc, npx);
+      };
+      zero_ch(L.off_corr + 81, L.off_c1 - (L.off_corr + 81));
+      if (L.c1) { zero_ch(L.off_upflow + 2, 2); zero_ch(L.off_upfeat + 2, 2); }
       const std::string ls = std::to_string(l);
       if (l != PWC_LVLS) {
         // up-sampled flow / features of the level above land directly in this level's buffer (:1577-1578, :1424)
@@ -484,9 +539,13 @@ static void pwc_release_packed(fisr_pwc* c) {
   for (auto& kv : c->convs) {
     PwcConv& pc = kv.second;
     if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd);
+    if (pc.d_w1a) (void)hipFree(pc.d_w1a);
     if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
   }
-  for (auto& kv : c->deconvs) { if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b); }
+  for (auto& kv : c->deconvs) {
+    if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b);
+    if (kv.second.d_wd) (void)hipFree(kv.second.d_wd); if (kv.second.d_bz) (void)hipFree(kv.second.d_bz);
+  }
   c->convs.clear(); c->deconvs.clear();
 }
 
@@ -720,9 +779,15 @@ int fisr_pwc_op_deconv(const void* in, int in_f32, int in_cs, int in_co, int cin
     rc = with_pwc_elem(&tmp, [&](auto tag) {
       typedef decltype(tag) TE;
       PwcRunner<TE> r; r.ctx = &tmp; r.st = (hipStream_t)stream;
+      // (the wide-input path of the fp16 engine stages its 32 tap sums per pixel in the runner's arena)
+      void* scratch = nullptr;
+      const size_t sbytes = (size_t)n * h * w * 32 * sizeof(TE) + 512;
+      if (hipMalloc(&scratch, sbytes) != hipSuccess) return pfail(nullptr, FISR_EHIP, "fisr_pwc_op_deconv: hipMalloc");
+      r.ar.base = (char*)scratch; r.ar.cap = sbytes;
       if (in_f32) r.template deconv<float>("op", (const float*)in, in_cs, in_co, (TE*)out, out_cs, out_co, n, h, w);
       else r.template deconv<TE>("op", (const TE*)in, in_cs, in_co, (TE*)out, out_cs, out_co, n, h, w);
       hipError_t e = hipStreamSynchronize(r.st);
+      (void)hipFree(scratch);
       return r.rc ? r.rc : (e != hipSuccess ? pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_deconv: ") + hipGetErrorString(e)) : 0);
     });
   pwc_release_packed(&tmp);

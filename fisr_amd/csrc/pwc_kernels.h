@@ -210,6 +210,82 @@ __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_c
   }
 }
 
+// The transpose conv of a WIDE tensor (up_feat: 565 -> 2 channels) in two steps, fp16 engine: the 16 taps x 2 outputs are 32 output
+// channels of a 1x1 convolution, P[pixel][tap * 2 + o] = sum_c in[pixel][c] * kernel[tap][o][c] -- run as a 3x3 convolution whose
+// only non-zero tap is the centre on the LDS-DMA kernel (conv3x3_dma.h), so the matrix pipe shares every weight fragment among 32
+// pixels -- and this kernel gathers the four taps that reach an output pixel: out[2i + k - 1] += P[i][k].  (Eight lanes per output
+// pixel re-read the 78 KB of weights from L2 for every pixel: 4.1 ms on the 608-channel level-2 buffer of a 5-frame stack.)
+template <typename TE>
+__global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float* __restrict__ bias, TE* __restrict__ out, int out_cs, int out_co,
+                                          int N, int H, int W) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((size_t)OW * OH));
+    float a0 = bias[0], a1 = bias[1];
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+      const int ky = ((oy + 1) & 1) + 2 * ty, iy = (oy + 1 - ky) / 2;
+      if ((oy + 1 - ky) < 0 || iy >= H) continue;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int kx = ((ox + 1) & 1) + 2 * tx, ix = (ox + 1 - kx) / 2;
+        if ((ox + 1 - kx) < 0 || ix >= W) continue;
+        const TE* q = P + ((size_t)(n * H + iy) * W + ix) * 32 + (ky * 4 + kx) * 2;
+        a0 += (float)q[0]; a1 += (float)q[1];
+      }
+    }
+    TE* o = out + i * out_cs + out_co;
+    o[0] = (TE)a0; o[1] = (TE)a1;
+  }
+}
+
+// zero the channel range [c0, c0 + nc) of every pixel (the padding channels of a decoder buffer: everything else is written
+// before it is read, so a memset of the whole 608-channel buffer -- 5 GB at level 2 of a 5-frame stack -- is not needed)
+template <typename TE>
+__global__ void pwc_zero_channels_kernel(TE* __restrict__ buf, int cs, int c0, int nc, size_t npix) {
+  const size_t total = npix * nc;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    buf[(i / nc) * cs + c0 + (int)(i % nc)] = (TE)0.f;
+}
+
+// conv1a of the feature pyramid (model_pwcnet.py:1092: 3 -> 16 channels, stride 2, 'same' = pad (0, 1) on the even sizes the
+// network runs on, leaky relu) on the vector ALU: [N, H, W, 4] -> [N, H/2, W/2, 16].  432 FMAs per output pixel, weights
+// [9][4][16] + bias [16] uniform (scalar loads); the 64-wide generic MFMA kernel spent 2 ms on it per 5-frame stack.
+template <typename TE>
+__global__ __launch_bounds__(256) void pwc_conv1a_kernel(const TE* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         TE* __restrict__ out, int N, int H, int W, float slope) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((size_t)OW * OH));
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = bias[o];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox + kx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy < H && ix < W) v = PwcElem<TE>::ld4(in + ((size_t)(n * H + iy) * W + ix) * 4);
+        const float* wt = w + (ky * 3 + kx) * 64;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] += v.x * wt[o] + v.y * wt[16 + o] + v.z * wt[32 + o];
+      }
+    }
+    TE* ob = out + i * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = acc[4 * q + e]; r[e] = t >= 0.f ? t : t * slope; }
+      PwcElem<TE>::st4(ob + 4 * q, r);
+    }
+  }
+}
+
 // cost volume: out[px][(dy+4)*9 + (dx+4)] = leaky_relu(mean_c c1[px][c] * w2[px + (dy, dx)][c], 0.1), zero outside.
 // One workgroup per 8x32 pixel tile, one thread per pixel with all 81 sums in registers; the (8+8) x (32+8) halo of w2
 // goes through LDS 16 channels at a time (80-byte records: a ds_read_b128 phase of 16 neighbouring pixels hits every
