@@ -49,7 +49,7 @@ struct PwcVar {
 
 struct PwcConv {                 // one packed convolution
   float* d_w = nullptr; float* d_b = nullptr;     // generic implicit-GEMM kernel (fp32 weights, any stride / dilation)
-  float* d_w1a = nullptr;        // conv1a (3 -> 16, stride 2): [9][4][16] + bias [16] for the vector-ALU kernel
+  Conv1aWeights* w1a = nullptr;  // conv1a (3 -> 16, stride 2): [9][4][16] + bias [16] for the vector-ALU kernel (host copy, passed by value)
   char* d_wu = nullptr;          // fp32 engine: Winograd slabs for conv3x3_wino8p_kernel (stride 1, Cout >= 32)
   void* d_wd = nullptr;          // fp16 engine: weight slabs of the LDS-DMA kernel conv3x3_dma.h (stride 1, Cout >= 16)
   int cout_pad_d = 0;
@@ -131,13 +131,13 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
   HIP_OK(nullptr, hipMemcpy(pc.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(nullptr, hipMemcpy(pc.d_b, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
   if (ci == 3 && co == 16 && cin_buf == 4) {          // conv1a: [9][4][16] + bias for pwc_conv1a_kernel
-    std::vector<float> w1((size_t)9 * 64 + 16, 0.f);
+    delete pc.w1a;
+    pc.w1a = new Conv1aWeights();
+    memset(pc.w1a, 0, sizeof(Conv1aWeights));
     for (int tap = 0; tap < 9; ++tap)
       for (int j = 0; j < 3; ++j)
-        for (int n = 0; n < 16; ++n) w1[(size_t)tap * 64 + chmap[j] * 16 + n] = kw.v[((size_t)tap * 3 + j) * 16 + n];
-    for (int n = 0; n < 16; ++n) w1[9 * 64 + n] = kb.v[n];
-    HIP_OK(nullptr, hipMalloc((void**)&pc.d_w1a, w1.size() * 4));
-    HIP_OK(nullptr, hipMemcpy(pc.d_w1a, w1.data(), w1.size() * 4, hipMemcpyHostToDevice));
+        for (int n = 0; n < 16; ++n) pc.w1a->w[(size_t)tap * 64 + chmap[j] * 16 + n] = kw.v[((size_t)tap * 3 + j) * 16 + n];
+    for (int n = 0; n < 16; ++n) pc.w1a->bias[n] = kb.v[n];
   }
   if (!wino) return 0;
   // the same kernel scattered to the buffer channels it reads, for FISRnet's fast kernels
@@ -376,9 +376,9 @@ struct PwcRunner {
       TE* A = ealloc(px * PWC_CH[l]); TE* B = ealloc(px * PWC_CH[l]);
       const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
       const PwcConv& pa = ctx->convs[p + "a"];
-      if (l == 1 && pa.d_w1a) {
+      if (l == 1 && pa.w1a) {
         if (!rc && !ar.dry) {
-          hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for(px)), dim3(256), 0, st, F[0], pa.d_w1a, pa.d_w1a + 9 * 64, A, nf, hh[0], ww[0], 0.1f);
+          hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for(px)), dim3(256), 0, st, F[0], *pa.w1a, A, nf, hh[0], ww[0], 0.1f);
           check("conv1a");
         }
       } else
@@ -539,7 +539,7 @@ static void pwc_release_packed(fisr_pwc* c) {
   for (auto& kv : c->convs) {
     PwcConv& pc = kv.second;
     if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd);
-    if (pc.d_w1a) (void)hipFree(pc.d_w1a);
+    delete pc.w1a; pc.w1a = nullptr;
     if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
   }
   for (auto& kv : c->deconvs) {

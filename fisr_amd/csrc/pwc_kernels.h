@@ -251,10 +251,14 @@ __global__ void pwc_zero_channels_kernel(TE* __restrict__ buf, int cs, int c0, i
 
 // conv1a of the feature pyramid (model_pwcnet.py:1092: 3 -> 16 channels, stride 2, 'same' = pad (0, 1) on the even sizes the
 // network runs on, leaky relu) on the vector ALU: [N, H, W, 4] -> [N, H/2, W/2, 16].  432 FMAs per output pixel, weights
-// [9][4][16] + bias [16] uniform (scalar loads); the 64-wide generic MFMA kernel spent 2 ms on it per 5-frame stack.
+// [9][4][16] + bias [16] passed BY VALUE (kernel-argument memory: scalar loads, no vector load per lane and weight); the 64-wide
+// generic MFMA kernel spent 2 ms on it per 5-frame stack.
+struct Conv1aWeights { float w[9 * 64]; float bias[16]; };      // by value: kernel-argument memory, read with scalar loads
 template <typename TE>
-__global__ __launch_bounds__(256) void pwc_conv1a_kernel(const TE* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                                                         TE* __restrict__ out, int N, int H, int W, float slope) {
+__global__ __launch_bounds__(256) void pwc_conv1a_kernel(const TE* __restrict__ in, const Conv1aWeights cw, TE* __restrict__ out, int N, int H,
+                                                         int W, float slope) {
+  const float* const w = cw.w;
+  const float* const bias = cw.bias;
   const int OH = H / 2, OW = W / 2;
   const size_t total = (size_t)N * OH * OW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
