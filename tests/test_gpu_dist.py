@@ -161,3 +161,62 @@ def test_fisr_comm_two_ranks_over_rccl():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _rccl_single_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from fisr_amd import dist as fdist
+        ok = True
+        # the asynchronous output gather exactly as bench.py drives it, on the real backend: side stream, events, views of
+        # one receive buffer as the gather list, alternating send buffers, several steps in flight
+        ag = fdist.AsyncGather((3, 64, 96, 9), torch.uint8, "cuda:0", dst=0)
+        for step in range(4):
+            buf = ag.buffer(step)
+            buf.fill_(step + 1)
+            ag.submit(step)
+        r = ag.wait()
+        torch.cuda.synchronize()
+        ok = ok and tuple(r.shape) == (1, 3, 64, 96, 9) and int(r.max()) == 4 and int(r.min()) == 4
+        # halo all-gather + tile gather (a 1x1 "tile group"), prefetched on the side stream
+        core = torch.rand((2, 64, 96, 29), device="cuda:0")
+        pf = fdist.HaloPrefetcher((1, 1), "cuda:0")
+        tile_in = pf.finish(pf.start(core))
+        ok = ok and torch.equal(tile_in, core)
+        full = fdist.gather_tiles(torch.ones((2, 128, 192, 9), dtype=torch.uint8, device="cuda:0"), (1, 1))
+        ok = ok and tuple(full.shape) == (2, 128, 192, 9)
+        # the reductions / object gathers of bench.py's report
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        objs = [None]
+        dist.all_gather_object(objs, {"rank": 0})
+        dist.barrier()
+        ok = ok and float(t.item()) == 1.5 and objs[0] == {"rank": 0}
+        # the C-ABI's own communicator on the same device
+        comm = fdist.FisrComm.from_torch_group(0)
+        got = comm.allgather(torch.arange(1000, dtype=torch.int32, device="cuda:0"))
+        torch.cuda.synchronize()
+        ok = ok and tuple(got.shape) == (1, 1000) and int(got[0, 999]) == 999
+        comm.close()
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank_collectives():
+    """Every collective call this code makes -- the asynchronous gather on its side stream, the halo / tile all-gathers, the
+    reductions and object gathers of bench.py, fisr_comm_* -- once through REAL RCCL (`backend="nccl"`): a world of one rank is
+    all a one-GPU box can host, so the data path is a self-copy, but the API use, stream / event ordering and librccl loading are
+    the ones an 8-GPU node runs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_worker, args=(_free_port(), q))
+    p.start()
+    ok = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and ok
