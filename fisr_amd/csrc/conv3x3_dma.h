@@ -38,14 +38,14 @@ constexpr int D_TH = 8, D_TW = 64;                 // pixel tile of a workgroup
 constexpr int D_HW = D_TW + 2, D_HH = D_TH + 2;    // halo tile
 constexpr int D_REC = 32;                          // bytes per LDS record: 16 fp16 channels
 constexpr int D_CH = 16;                           // channels per K chunk
-constexpr int D_BN = 64;                           // output channels per workgroup
+constexpr int D_BN = 64;                           // output channels per workgroup (NT = 2; 32 with NT = 1)
 constexpr int D_HALO_UNITS = D_HH * D_HW * 2;      // 16-byte units of a halo chunk: 1320 = 20 full wave copies + 40 lanes
 constexpr int D_HALO_COPIES = (D_HALO_UNITS + 63) / 64;            // 21
 constexpr int D_HALO_BYTES = D_HALO_COPIES * 1024;                 // 21504: the last copy's idle lanes write zeros into the tail
 constexpr int D_W_BYTES = 9 * D_BN * D_REC;                        // 18432: one weight slab (16 channels x 9 taps x 64 rows)
 constexpr int D_W_COPIES = D_W_BYTES / 1024;                       // 18
 constexpr int D_STAGES = 2;
-constexpr size_t dma_lds_bytes() { return (size_t)D_STAGES * (D_HALO_BYTES + D_W_BYTES); }     // 79872
+constexpr size_t dma_lds_bytes() { return (size_t)D_STAGES * (D_HALO_BYTES + D_W_BYTES); }     // 79872 (NT = 2; NT = 1 uses less)
 
 // One LDS-DMA copy: lane l moves 16 bytes from (buffer base + soffset + voffset) to LDS byte address M0 + 16*l; zeros when
 // soffset + voffset >= num_records.  Hidden from the compiler (see above); completion is counted by hand (vmcnt).
@@ -57,9 +57,13 @@ constexpr size_t dma_lds_bytes() { return (size_t)D_STAGES * (D_HALO_BYTES + D_W
 struct dma_stage0_t { static constexpr int value = 0; };
 struct dma_stage1_t { static constexpr int value = 1; };
 
-template <bool GENERAL>
+// NT: 32-channel MFMA row tiles per wave = N block of 32 * NT output channels per workgroup.  NT = 1 exists for the flow network's
+// layers with Cout = 32 / 96 (a 64-channel block would compute 2x / 1.33x their work); FISRnet's layers all take NT = 2.
+template <bool GENERAL, int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs p) {
   typedef _Float16 T;
+  constexpr int BN = 32 * NT;
+  constexpr int WB = 9 * BN * D_REC;                  // bytes of one weight slab: 18432 (NT = 2) / 9216 (NT = 1)
   typedef f16x8 Frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [halo stage 0][halo stage 1][weights stage 0][weights stage 1]
@@ -86,10 +90,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
     const int xcd = v & 7, loc = v >> 3;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int nblocks = p.CoutPad / D_BN;
+  const int nblocks = p.CoutPad / BN;
   int t = v / nblocks;
   const int nblk = v - t * nblocks;
-  const int n0 = nblk * D_BN;
+  const int n0 = nblk * BN;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y; t /= tiles_y;
   const int sub = GENERAL ? t % (dil * dil) : 0;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? (const T*)p.in1 + (size_t)nb * img_elems : (const T*)p.in0), 0, img_bytes, 0x00020000);
   const int nch0 = p.C0 / D_CH, nch = (p.C0 + p.C1) / D_CH;
   // weight slabs: [chunk][N block][9 x 64 x 32 B], the LDS image
-  const size_t w_bytes = (size_t)nch * nblocks * D_W_BYTES;
+  const size_t w_bytes = (size_t)nch * nblocks * WB;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (unsigned)w_bytes, 0x00020000);
   const unsigned woff = (unsigned)lane * 16u;
   const unsigned lds_h = (unsigned)(size_t)(dma_lds_ptr_t)sH + (unsigned)wave * 1024u;
@@ -151,22 +155,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
     }
     if (first) { FISR_DMA_HALO(rs0) } else { FISR_DMA_HALO(rs1) }
 #undef FISR_DMA_HALO
-    // weight slab: 18 linear copies of 1 KB; wave w takes copies w, w + 4, ... (waves 0, 1: five, waves 2, 3: four)
-    const unsigned sw = (unsigned)(((size_t)kc * nblocks + nblk) * D_W_BYTES);
-    const unsigned lw = lds_w + (unsigned)stage * (unsigned)D_W_BYTES;
+    // weight slab: 9 * NT linear copies of 1 KB; wave w takes copies w, w + 4, ... (NT = 2: waves 0, 1 five, waves 2, 3 four;
+    // NT = 1: wave 0 three, the others two)
+    const unsigned sw = (unsigned)(((size_t)kc * nblocks + nblk) * WB);
+    const unsigned lw = lds_w + (unsigned)stage * (unsigned)WB;
     const unsigned s0 = sw + (unsigned)wave * 1024u, s1 = s0 + 4096u, s2 = s0 + 8192u, s3 = s0 + 12288u, s4 = s0 + 16384u;
-    if (wave < 2) {
+    const int ncopies = (9 * NT - wave + 3) >> 2;
+    if (ncopies == 5) {
       asm volatile(FISR_BLDS_BEGIN(keep, lds) FISR_BLDS_COPY(o, rs, s0) FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s1)
                    FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s2) FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s3)
                    FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s4) FISR_BLDS_END(keep)
                    : [keep] "=&s"(keep) : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff), [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2),
                      [s3] "s"(s3), [s4] "s"(s4) : "memory", "scc");
-    } else {
+    } else if (ncopies == 4) {
       asm volatile(FISR_BLDS_BEGIN(keep, lds) FISR_BLDS_COPY(o, rs, s0) FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s1)
                    FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s2) FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s3)
                    FISR_BLDS_END(keep)
                    : [keep] "=&s"(keep) : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff), [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2),
                      [s3] "s"(s3) : "memory", "scc");
+    } else if (ncopies == 3) {
+      asm volatile(FISR_BLDS_BEGIN(keep, lds) FISR_BLDS_COPY(o, rs, s0) FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s1)
+                   FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s2) FISR_BLDS_END(keep)
+                   : [keep] "=&s"(keep) : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff), [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2) : "memory", "scc");
+    } else {
+      asm volatile(FISR_BLDS_BEGIN(keep, lds) FISR_BLDS_COPY(o, rs, s0) FISR_BLDS_NEXT(0x1000) FISR_BLDS_COPY(o, rs, s1) FISR_BLDS_END(keep)
+                   : [keep] "=&s"(keep) : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff), [s0] "s"(s0), [s1] "s"(s1) : "memory", "scc");
     }
   };
   auto copies_landed_barrier = [&]() {
@@ -180,17 +193,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
   // ---- accumulators start from bias (+ residual), as in conv3x3.h: lane (li, kh) of tile [m][j] owns pixel
   //      (y0 + 4 rg + m, x0 + 32 cg + li), channels n0 + 32 j + 16 kh + r
   typedef Rec16<T> R16;
-  f32x16 acc[4][2];
+  f32x16 acc[4][NT];
   {
     const bool use_res = p.res != nullptr;
-    uint4 rres[4][2][R16::NV];
+    uint4 rres[4][NT][R16::NV];
     if (use_res) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int y = min((y0 + 4 * rg + m) * dil + ry, p.H - 1), x = min((x0 + 32 * cg + li) * dil + rx, p.W - 1);   // clamped: never stored when outside
         const size_t gp = (size_t)(nb * p.H + y) * p.W + x;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NT; ++j) {
           const int c0 = min(n0 + 32 * j + 16 * kh, p.Cout - 16);
           const uint4* q = reinterpret_cast<const uint4*>((const T*)p.res + gp * rec_cs + rec_co + c0);
 #pragma unroll
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const f32x4* bq = reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * j + 16 * kh);
       float bv[16];
 #pragma unroll
@@ -241,13 +254,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
       for (int k = 0; k < 4; ++k) asm("v_pk_max_f16 %0, %1, %0" : "+v"(q[k]) : "s"(relu_floor_in));
     }
   };
-  auto load_b = [&](Frag (&b)[2], int S, int tap) {
-    b[0] = *reinterpret_cast<const Frag*>(b_base + S * D_W_BYTES + (tap * D_BN) * D_REC);
-    b[1] = *reinterpret_cast<const Frag*>(b_base + S * D_W_BYTES + (tap * D_BN + 32) * D_REC);
+  auto load_b = [&](Frag (&b)[NT], int S, int tap) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const Frag*>(b_base + S * WB + (tap * BN + 32 * j) * D_REC);
   };
   auto compute = [&](auto stage_tag) {
     constexpr int S = decltype(stage_tag)::value;
-    Frag rows[2][6], bf[2][2];
+    Frag rows[2][6], bf[2][NT];
     load_rows(rows[0], S, 0);
     load_b(bf[0], S, 0);
 #pragma unroll
@@ -260,26 +273,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
         if (blk + 1 < 9) load_b(bf[(blk + 1) & 1], S, ((blk + 1) % 3) * 3 + (blk + 1) / 3);      // tap index = dy * 3 + dx
         if (dy == 0 && dx + 1 < 3) load_rows(rows[(dx + 1) & 1], S, dx + 1);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[blk & 1][0], rows[dx & 1][m + dy], acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[blk & 1][1], rows[dx & 1][m + dy], acc[m][1], 0, 0, 0);
-        }
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[blk & 1][j], rows[dx & 1][m + dy], acc[m][j], 0, 0, 0);
         // pin the interleave.  First tap of a column: the relu of the row an MFMA pair needs (4 VALU) in front of it, the rest
         // and the LDS reads (next column's rows, next tap's weights) in the MFMAs' shadow; other taps: MFMAs and reads only.
         if (dy == 0) {
           __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, NT == 1 ? 2 : 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, NT == 1 ? 6 : 3, 0);
+            }
           }
         } else {
 #pragma unroll
-          for (int g = 0; g < 8; ++g) {
+          for (int g = 0; g < 4 * NT; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
     const int y = (y0 + 4 * rg + m) * dil + ry;
     if (y >= p.H || x >= p.W) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const int c0 = n0 + 32 * j + 16 * kh;
       if (c0 >= p.Cout) continue;
       float vv[16];

@@ -323,16 +323,17 @@ void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<
 // fp16 weights for the LDS-DMA kernel (conv3x3_dma.h): [Cin/16][CoutPad/64][tap 9][row 64][32-byte record] -- a slab is the
 // kernel's LDS image: rows in the MFMA row order of pack_weights, the two 16-byte halves (channels 0-7 | 8-15 of the chunk)
 // swapped when bit 3 of the row is set.
-void pack_weights_dma(const float* w, int ci, int co, int cin_pad, int cout_pad, std::vector<char>& wp) {
-  const int nb = cout_pad / D_BN, nch = cin_pad / D_CH;
-  wp.assign((size_t)nch * nb * D_W_BYTES, 0);
+void pack_weights_dma(const float* w, int ci, int co, int cin_pad, int cout_pad, std::vector<char>& wp, int bn = D_BN) {
+  const int nb = cout_pad / bn, nch = cin_pad / D_CH;
+  const size_t wb = (size_t)9 * bn * D_REC;
+  wp.assign((size_t)nch * nb * wb, 0);
   for (int tap = 0; tap < 9; ++tap)
     for (int c = 0; c < ci; ++c)
       for (int n = 0; n < co; ++n) {
         const int kc = c / D_CH, cc = c % D_CH, h = cc >> 3, e = cc & 7;
-        const int blk = n / D_BN, nl = n % D_BN, wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+        const int blk = n / bn, nl = n % bn, wi = nl & 31, wk = wi >> 4, wr = wi & 15;
         const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
-        char* rec = wp.data() + ((size_t)kc * nb + blk) * D_W_BYTES + ((size_t)tap * D_BN + row) * D_REC + ((h ^ ((row >> 3) & 1)) * 16);
+        char* rec = wp.data() + ((size_t)kc * nb + blk) * wb + ((size_t)tap * bn + row) * D_REC + ((h ^ ((row >> 3) & 1)) * 16);
         reinterpret_cast<_Float16*>(rec)[e] = (_Float16)w[((size_t)tap * ci + c) * co + n];
       }
 }
@@ -539,14 +540,15 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
 }
 
 // The LDS-DMA fp16 kernel (conv3x3_dma.h; a.wpk = the conv's d_wd, a.CoutPad = its cout_pad_d).
-hipError_t launch_conv_dma(const ConvArgs& a, hipStream_t st) {
+hipError_t launch_conv_dma(const ConvArgs& a, hipStream_t st, int nt = 2) {
   static bool attr_done[64] = {};
   constexpr size_t lds = dma_lds_bytes();
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
-    for (const void* k : {reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<false>), reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<true>)}) {
+    for (const void* k : {reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<false, 2>), reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<true, 2>),
+                          reinterpret_cast<const void*>(conv3x3_dma_f16_kernel<true, 1>)}) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
@@ -556,9 +558,10 @@ hipError_t launch_conv_dma(const ConvArgs& a, hipStream_t st) {
   if (d < 1 || (d > 1 && a.d2s) || !dma_fits(a.H, a.W, a.C0, a.C1, a.in0_cs, a.in1_cs)) return hipErrorInvalidValue;
   const int tiles = (((a.W + d - 1) / d + D_TW - 1) / D_TW) * (((a.H + d - 1) / d + D_TH - 1) / D_TH) * d * d * a.N;
   const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && d == 1;
-  const dim3 grid(tiles * (a.CoutPad / D_BN));
-  if (plain) hipLaunchKernelGGL(conv3x3_dma_f16_kernel<false>, grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(conv3x3_dma_f16_kernel<true>, grid, dim3(256), lds, st, a);
+  const dim3 grid(tiles * (a.CoutPad / (32 * nt)));
+  if (nt == 1) hipLaunchKernelGGL((conv3x3_dma_f16_kernel<true, 1>), grid, dim3(256), lds, st, a);      // (the flow network's 32 / 96-channel layers)
+  else if (plain) hipLaunchKernelGGL((conv3x3_dma_f16_kernel<false, 2>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((conv3x3_dma_f16_kernel<true, 2>), grid, dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ struct PwcConv {                 // one packed convolution
   Conv1aWeights* w1a = nullptr;  // conv1a (3 -> 16, stride 2): [9][4][16] + bias [16] for the vector-ALU kernel (host copy, passed by value)
   char* d_wu = nullptr;          // fp32 engine: Winograd slabs for conv3x3_wino8p_kernel (stride 1, Cout >= 32)
   void* d_wd = nullptr;          // fp16 engine: weight slabs of the LDS-DMA kernel conv3x3_dma.h (stride 1, Cout >= 16)
-  int cout_pad_d = 0;
+  int cout_pad_d = 0, nt_d = 2;  // ... its Cout padding and N block (32 * nt_d channels: 32 when Cout % 64 == 32)
   ConvW dw;                      // FISRnet's direct kernel in the engine's arithmetic (stride 1, dilation 1: the 2-channel flow heads; fp32: also level 1)
   bool have_dw = false;
   int cin_buf = 0, cout = 0, cout_pad = 0;
@@ -150,8 +150,9 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
     // heads on FISRnet's 16-row direct kernel with fp32 output
     if (co >= 16 && co % 16 == 0 && cin_buf % D_CH == 0) {
       std::vector<char> wd;
-      pc.cout_pad_d = round_up(co, D_BN);
-      pack_weights_dma(dense.data(), cin_buf, co, cin_buf, pc.cout_pad_d, wd);
+      pc.nt_d = co % 64 == 32 ? 1 : 2;               // 32 / 96 output channels: 32-channel N blocks, nothing computed for padding
+      pc.cout_pad_d = round_up(co, 32 * pc.nt_d);
+      pack_weights_dma(dense.data(), cin_buf, co, cin_buf, pc.cout_pad_d, wd, 32 * pc.nt_d);
       HIP_OK(nullptr, hipMalloc(&pc.d_wd, wd.size()));
       HIP_OK(nullptr, hipMemcpy(pc.d_wd, wd.data(), wd.size(), hipMemcpyHostToDevice));
     } else if (co < 16 && cin_buf % 32 == 0) {
@@ -202,7 +203,7 @@ int pwc_pack_deconv(fisr_pwc* ctx, const std::string& name, const std::vector<in
       for (int o = 0; o < 2; ++o)
         for (int j = 0; j < ci; ++j) dense[((size_t)4 * cin4 + chmap[j]) * 32 + k * 2 + o] = kw.v[((size_t)k * 2 + o) * ci + j];
     std::vector<char> wd;
-    pack_weights_dma(dense.data(), cin4, 32, cin4, D_BN, wd);
+    pack_weights_dma(dense.data(), cin4, 32, cin4, 32, wd, 32);        // one 32-channel N block (NT = 1)
     HIP_OK(nullptr, hipMalloc(&pd.d_wd, wd.size()));
     HIP_OK(nullptr, hipMemcpy(pd.d_wd, wd.data(), wd.size(), hipMemcpyHostToDevice));
     HIP_OK(nullptr, hipMalloc((void**)&pd.d_bz, D_BN * 4));
@@ -289,7 +290,7 @@ struct PwcRunner {
       a.C0 = pc.cin_buf; a.C1 = 0; a.CoutPad = route == 2 ? round_up(pc.cout, W_BN) : pc.cout_pad_d;
       a.rec_cs = out_cs; a.rec_co = out_co; a.dil = dil;
       hipError_t e = hipSuccess;
-      if (route == 4) e = launch_conv_dma(a, st);
+      if (route == 4) e = launch_conv_dma(a, st, pc.nt_d);
       else if (wino_fits(n, h, w, in_cs, 0, out_cs)) e = launch_conv_wino(a, st);
       else {
         // the Winograd kernel addresses its whole input batch with 32-bit byte offsets: one image per launch when the batch is too big
@@ -343,11 +344,11 @@ struct PwcRunner {
       if (rc || ar.dry) return;
       ConvArgs a;
       a.in0 = (const TE*)in + in_co; a.in1 = nullptr; a.wpk = pd.d_wd; a.bias = pd.d_bz; a.res = nullptr; a.out = P;
-      a.C0 = pd.cin4; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = 32; a.CoutPad = D_BN;
+      a.C0 = pd.cin4; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = 32; a.CoutPad = 32;
       a.relu_in = 0; a.relu_out = 0; a.d2s = 0; a.d2s_shift = 0;
       a.out_cstride = 32; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
       a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = 32; a.rec_co = 0; a.slope = 0.f; a.dil = 1; a.trace = nullptr;
-      hipError_t e = launch_conv_dma(a, st);
+      hipError_t e = launch_conv_dma(a, st, 1);
       if (e != hipSuccess && rc == 0) { rc = pfail(ctx, FISR_EHIP, name + " (lds-dma): " + hipGetErrorString(e)); return; }
       hipLaunchKernelGGL(pwc_deconv_combine_kernel<TE>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, out, out_cs, out_co, n, h, w);
       check(name.c_str());

@@ -285,17 +285,19 @@ def _h16(a):
     return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
 
 
+@pytest.mark.parametrize("cout", [96, 128])
 @pytest.mark.parametrize("dil,shape", [(1, (272, 480)), (2, (272, 480)), (4, (136, 240)), (8, (136, 240)), (16, (136, 240)), (16, (272, 480)),
                                        (4, (75, 133)), (8, (139, 251))])
-def test_lds_dma_general_dilated_fp16_vs_oracle(dil, shape):
+def test_lds_dma_general_dilated_fp16_vs_oracle(dil, shape, cout):
     """The GENERAL instantiation of the fp16 LDS-DMA kernel (conv3x3_dma.h), which carries the dense and context layers of the fp16
-    flow engine: dilation as d x d interleaved sub-images, channel-range input and output of wider buffers, leaky relu, Cout = 1.5
-    N blocks, batch 2.  Inputs and weights are fp16 values, so the float64 oracle sees the same operands: what is left is the fp32
-    accumulation and ONE rounding of the result to fp16."""
+    flow engine: dilation as d x d interleaved sub-images, channel-range input and output of wider buffers, leaky relu, batch 2;
+    Cout = 96 runs the 32-channel N blocks (NT = 1: the network's 32 / 96-channel layers), Cout = 128 the 64-channel ones.  Inputs
+    and weights are fp16 values, so the float64 oracle sees the same operands: what is left is the fp32 accumulation and ONE
+    rounding of the result to fp16."""
     h, wd = shape
-    rng = np.random.default_rng(1000 * dil + h)
+    rng = np.random.default_rng(1000 * dil + h + cout)
     in_cs, in_co, cin = 160, 32, 96
-    out_cs, out_co, cout = 192, 64, 96
+    out_cs, out_co = 256, 64
     x = _h16(rng.standard_normal((2, h, wd, in_cs)) * 0.5)
     w = _h16(rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin)))
     b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
