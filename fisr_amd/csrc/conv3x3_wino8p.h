@@ -124,20 +124,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8p_kernel(const ConvArgs p
     const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)W_RAW;
     unsigned keep;
     if (cw < 2) {
-      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g)
-                   FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o2, g) FISR_GLDS_END(keep)
+      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY_RAW(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY_RAW(o1, g)
+                   FISR_GLDS_NEXT_ROW FISR_GLDS_COPY_RAW(o2, g) FISR_GLDS_END(keep)
                    : [keep] "=&s"(keep) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2) : "memory", "scc");
     } else if (cw == 2) {
       unsigned long long ex;
-      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g)
+      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY_RAW(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY_RAW(o1, g)
                    FISR_GLDS_NEXT_ROW
                    "s_mov_b64 %[ex], exec\n\ts_bfm_b64 exec, 40, 0\n\t"      // units 640..679: lanes 0..39
-                   FISR_GLDS_COPY(o2, g)
+                   FISR_GLDS_COPY_RAW(o2, g)
                    "s_mov_b64 exec, %[ex]\n\t" FISR_GLDS_END(keep)
                    : [keep] "=&s"(keep), [ex] "=&s"(ex) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2)
                    : "memory", "scc");
     } else {
-      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY(o1, g) FISR_GLDS_END(keep)
+      asm volatile(FISR_GLDS_BEGIN(keep, lds) FISR_GLDS_COPY_RAW(o0, g) FISR_GLDS_NEXT_ROW FISR_GLDS_COPY_RAW(o1, g) FISR_GLDS_END(keep)
                    : [keep] "=&s"(keep) : [g] "s"(g), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1) : "memory", "scc");
     }
   };

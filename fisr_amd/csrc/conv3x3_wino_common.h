@@ -60,6 +60,20 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // K loop whose wait the hidden copies could falsify.
 #define FISR_GLDS_BEGIN(KEEP, LDS)  "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
 #define FISR_GLDS_COPY(OFF, G)      "global_load_lds_dwordx4 %[" #OFF "], %[" #G "]\n\t"
+// (the raw activation chunks; -DFISR_RAW_AUX_MODE=1|2|3: A/B hook for cache-policy bits on that stream -- nt / sc1 / sc0 sc1)
+#ifndef FISR_RAW_AUX_MODE
+#define FISR_RAW_AUX_MODE 0
+#endif
+#if FISR_RAW_AUX_MODE == 1
+#define FISR_RAW_AUX " nt"
+#elif FISR_RAW_AUX_MODE == 2
+#define FISR_RAW_AUX " sc1"
+#elif FISR_RAW_AUX_MODE == 3
+#define FISR_RAW_AUX " sc0 sc1"
+#else
+#define FISR_RAW_AUX ""
+#endif
+#define FISR_GLDS_COPY_RAW(OFF, G)  "global_load_lds_dwordx4 %[" #OFF "], %[" #G "]" FISR_RAW_AUX "\n\t"
 #define FISR_GLDS_NEXT_ROW          "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
 #define FISR_GLDS_END(KEEP)         "s_mov_b32 m0, %[" #KEEP "]"
 
