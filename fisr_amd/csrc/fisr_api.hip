@@ -24,6 +24,7 @@
 #ifndef FISR_DIAG
 #undef FISR_ABL
 #undef FISR_WABL
+#undef FISR_GABL
 #undef FISR_RAW_AUX_MODE
 #endif
 #include "conv3x3.h"

@@ -51,15 +51,28 @@ int fisr_train_pack_wino(const float* d_w_hwio, int ci, int co, int transpose, v
   return 0;
 }
 
+/* All layouts of n convs in one launch: d_descs is a DEVICE array of n fisr_train_pack_desc (null destinations are skipped). */
+int fisr_train_pack_all(const fisr_train_pack_desc* d_descs, int n, void* stream) {
+  static_assert(sizeof(fisr_train_pack_desc) == sizeof(PackDesc), "descriptor layout");
+  if (!d_descs || n <= 0 || n > 16383) return fail(nullptr, FISR_EINVAL, "fisr_train_pack_all: bad argument");
+  DeviceGuard guard(device_of(d_descs));
+  HIP_OK(nullptr, guard.err);
+  hipLaunchKernelGGL(train_pack_all_kernel, dim3(96, 4 * n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackDesc*>(d_descs));
+  HIP_OK(nullptr, hipGetLastError());
+  return 0;
+}
+
 /* out = [relu]( conv3x3([relu](cat(in0, in1))) + bias [+ res] ), weights packed by fisr_train_pack (device).
- * d_packed_wino (nullable): the slabs of fisr_train_pack_wino; large dense layers then run on the Winograd kernel.  c0 + c1 is
- * the padded channel count (multiple of 16).  out_cstride == 0: dense [n,h,w,cout] records (or the depth_to_space layout
+ * d_packed_wino (nullable): the slabs of fisr_train_pack_wino; every dense layer they exist for then runs on the Winograd
+ * kernel (2.25 x fewer MFMAs; measured faster than the direct kernel at every map size of the training step, 3 x 3 pixels
+ * included); d_packed may then be NULL (the call fails if it turns out to need the direct kernel).  d_bias must be readable up to the N block's padding (cout rounded up to 64, 16 for the heads; what lies beyond
+ * cout is never used).  c0 + c1 is the padded channel count (multiple of 16).  out_cstride == 0: dense [n,h,w,cout] records (or the depth_to_space layout
  * with FISR_CONV_D2S); != 0: channel n is stored at n + out_coff + (n >= out_split ? out_gap : 0) of a pixel stride
  * out_cstride (the [fr1, SR, fr2] scatter of the heads, FISRnet.py:107-108). */
 int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed, const float* d_bias, int cout,
                        const float* res, float* out, int n, int h, int w, int flags, int out_cstride, int out_coff, int out_split,
                        int out_gap, const void* d_packed_wino, void* stream) {
-  if (!in0 || !d_packed || !d_bias || !out || n <= 0 || h <= 0 || w <= 0 || c0 <= 0 || c1 < 0 || (c0 % 16) || (c1 % 16) || (c1 && !in1))
+  if (!in0 || (!d_packed && !d_packed_wino) || !d_bias || !out || n <= 0 || h <= 0 || w <= 0 || c0 <= 0 || c1 < 0 || (c0 % 16) || (c1 % 16) || (c1 && !in1))
     return fail(nullptr, FISR_EINVAL, "fisr_train_conv3x3: bad argument");
   const int nt = nt_for<float>(cout);
   const bool scatter = out_cstride != 0;
@@ -77,44 +90,72 @@ int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const
   a.out_split = scatter ? out_split : 1 << 30; a.out_gap = scatter ? out_gap : 0;
   a.wexp = 0; a.trace = nullptr;
   a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
-  // the persistent Winograd kernel pays off from two rounds of work items per CU on; below that the direct kernel wins
   const long items = (long)((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n * (cout / W_BN);
-  if (d_packed_wino && !scatter && cout % W_BN == 0 && (c0 + c1) / W_CH >= 4 && items >= 512 && wino_fits(n, h, w, c0, c1, cout)) {
+  long min_items = 1;
+#ifdef FISR_DIAG
+  static const long env_items = [] { const char* e = getenv("FISR_TRAIN_WINO_ITEMS"); return e ? atol(e) : 0L; }();
+  if (env_items > 0) min_items = env_items;
+#endif
+  if (d_packed_wino && !scatter && cout % W_BN == 0 && (c0 + c1) / W_CH >= 4 && items >= min_items && wino_fits(n, h, w, c0, c1, cout)) {
     a.wpk = d_packed_wino;
     a.CoutPad = cout;
     HIP_OK(nullptr, launch_conv_wino(a, (hipStream_t)stream));
     return 0;
   }
+  if (!d_packed) return fail(nullptr, FISR_EINVAL, "fisr_train_conv3x3: this call needs the direct kernel's packed weights (d_packed)");
   HIP_OK(nullptr, launch_conv<float>(a, nt, scatter, (hipStream_t)stream));
   return 0;
 }
 
-/* dw[3][3][ci][co] += sum_pixels [relu](cat(x0, x1))[p + tap][ci] * g[p][co], and (db != NULL) db[co] += sum_pixels g[p][co];
- * c0 + c1 >= ci (padded channels are read and dropped), cg >= co, c0 % 4 == c1 % 4 == cg % 4 == 0 */
-int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
-                     int ci, int co, int n, int h, int w, void* stream) {
+}  // extern "C"
+
+static int wgrad_impl(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
+                      int ci, int co, int n, int h, int w, void* stream, unsigned long long* trace) {
   if (!x0 || !g || !dw || c0 <= 0 || c1 < 0 || (c0 % 4) || (c1 % 4) || (cg % 4) || ci > c0 + c1 || co > cg || (c1 && !x1) || n <= 0)
     return fail(nullptr, FISR_EINVAL, "fisr_train_wgrad: bad argument");
   DeviceGuard guard(device_of(dw));
   HIP_OK(nullptr, guard.err);
-  static bool attr_done[64] = {};
+  const WgradTile tl = wgrad_tile(h, w);
+  void (*kern)(const WgradArgs) = nullptr;
+  int slot = 0;
+#define FISR_WGRAD_CASE(TW, TH, S) if (tl.tw == TW && tl.th == TH) { kern = train_wgrad_kernel<TW, TH>; slot = S; }
+  FISR_WGRAD_CASE(32, 4, 0) FISR_WGRAD_CASE(16, 8, 1) FISR_WGRAD_CASE(16, 4, 2)
+  FISR_WGRAD_CASE(8, 16, 3) FISR_WGRAD_CASE(8, 8, 4) FISR_WGRAD_CASE(8, 4, 5)
+#undef FISR_WGRAD_CASE
+  if (!kern) return fail(nullptr, FISR_EINVAL, "fisr_train_wgrad: no kernel for the tile");
+  static bool attr_done[64][6] = {};
   int dev = 0; (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-    HIP_OK(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(train_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (dev >= 0 && dev < 64 && !attr_done[dev][slot]) {
+    HIP_OK(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)wgrad_lds_bytes()));
-    attr_done[dev] = true;
+    attr_done[dev][slot] = true;
   }
   WgradArgs a;
   a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.g = g; a.Cg = cg; a.dw = dw; a.db = db; a.ci = ci; a.co = co;
-  a.N = n; a.H = h; a.W = w; a.relu_in = relu_in;
+  a.N = n; a.H = h; a.W = w; a.relu_in = relu_in; a.trace = trace;
   const int blocks = ((ci + 31) / 32) * ((co + 31) / 32);
-  const int ntiles = ((w + WG_TW - 1) / WG_TW) * ((h + WG_TH - 1) / WG_TH) * n;
+  const int ntiles = ((w + tl.tw - 1) / tl.tw) * ((h + tl.th - 1) / tl.th) * n;
   a.ksplit = std::max(1, std::min(ntiles, (512 + blocks - 1) / blocks));       // about two workgroups per CU in total (each ends
                                                                                 // with 9216 atomics: few, long-running workgroups)
-  hipLaunchKernelGGL(train_wgrad_kernel, dim3(blocks * a.ksplit), dim3(256), wgrad_lds_bytes(), (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3(blocks * a.ksplit), dim3(256), wgrad_lds_bytes(), (hipStream_t)stream, a);
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }
+extern "C" {
+/* dw[3][3][ci][co] += sum_pixels [relu](cat(x0, x1))[p + tap][ci] * g[p][co], and (db != NULL) db[co] += sum_pixels g[p][co];
+ * c0 + c1 >= ci (padded channels are read and dropped), cg >= co, c0 % 4 == c1 % 4 == cg % 4 == 0 */
+int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
+                     int ci, int co, int n, int h, int w, void* stream) {
+  return wgrad_impl(x0, c0, x1, c1, relu_in, g, cg, dw, db, ci, co, n, h, w, stream, nullptr);
+}
+#ifdef FISR_DIAG
+/* diagnostics builds: the same launch with a per-workgroup cycle trace (8 words per workgroup, device memory, at least
+ * 1024 workgroups' worth) */
+int fisr_diag_wgrad_trace(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
+                          int ci, int co, int n, int h, int w, void* stream, unsigned long long* d_trace) {
+  return wgrad_impl(x0, c0, x1, c1, relu_in, g, cg, dw, db, ci, co, n, h, w, stream, d_trace);
+}
+#endif
 
 int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream) {
   if (!g || !db || cg <= 0 || co > cg) return fail(nullptr, FISR_EINVAL, "fisr_train_bgrad: bad argument");
@@ -193,7 +234,7 @@ int fisr_train_loss(const float* const* pred4, const float* gt, float* const* gr
   a.k_recn = k7[0]; a.k_tm = k7[1]; a.k_tmm = k7[2]; a.k_td = k7[3]; a.k_recn2 = k7[4]; a.k_td2 = k7[5]; a.k_tm2 = k7[6];
   DeviceGuard guard(device_of(sums));
   HIP_OK(nullptr, guard.err);
-  hipLaunchKernelGGL(train_loss_kernel, dim3(grid_for(npix * 3)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(train_loss_kernel, dim3(std::min(grid_for(npix * 3), 1024)), dim3(256), 0, (hipStream_t)stream, a);
   HIP_OK(nullptr, hipGetLastError());
   return 0;
 }

@@ -18,10 +18,10 @@ namespace fisr {
 
 // ---- weights: HWIO -> packed rows of the direct fp32 kernel (pack_weights<float> in fisr_api.hip, on the device) ----
 // transpose = 0: src[tap][c][n]; transpose = 1: the conv has ci' = co, co' = ci and src'[tap][c'][n'] = src[8 - tap][n'][c'].
-__global__ void train_pack_kernel(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
-                                  int cin_pad, int cout_pad, float* __restrict__ out) {
+__device__ __forceinline__ void train_pack_body(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
+                                                int cin_pad, int cout_pad, float* __restrict__ out, size_t first, size_t stride) {
   const size_t total = (size_t)(cin_pad / 16) * 9 * cout_pad * 16;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = first; i < total; i += stride) {
     const int cc = (int)(i & 15);
     size_t t = i >> 4;
     const int row = (int)(t % cout_pad); t /= cout_pad;
@@ -41,61 +41,134 @@ __global__ void train_pack_kernel(const float* __restrict__ w, int ci_src, int c
     out[i] = v;
   }
 }
+__global__ void train_pack_kernel(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
+                                  int cin_pad, int cout_pad, float* __restrict__ out) {
+  train_pack_body(w, ci_src, co_src, transpose, ci, co, cin_pad, cout_pad, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (size_t)gridDim.x * blockDim.x);
+}
 
 // ---- weights: HWIO -> Winograd slabs U = G g G^T of conv3x3_wino8p.h (pack_weights_wino in fisr_api.hip, on the device, fp32) ----
 // One thread per (input channel c < cin_pad, output channel n < nb * 64); transpose as in train_pack_kernel.
-__global__ void train_pack_wino_kernel(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
-                                       int cin_pad, int nb, char* __restrict__ out) {
-  const size_t total = (size_t)cin_pad * nb * 64;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i % (nb * 64)), c = (int)(i / (nb * 64));
-    float g[3][3];
+__device__ __forceinline__ void train_pack_wino_body(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
+                                                     int cin_pad, int nb, char* __restrict__ out, size_t first, size_t stride) {
+  // one thread per (output channel n, four input channels c .. c+3 = one 16-byte half record): 16 stores of 16 bytes
+  const size_t total = (size_t)(cin_pad / 4) * nb * 64;
+  for (size_t i = first; i < total; i += stride) {
+    const int n = (int)(i % (nb * 64)), c0 = 4 * (int)(i / (nb * 64));
+    f32x4 u[16];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      float g[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int tap = a * 3 + b;
+          g[a][b] = (c < ci && n < co) ? (transpose ? w[((size_t)(8 - tap) * ci_src + n) * co_src + c] : w[((size_t)tap * ci_src + c) * co_src + n]) : 0.f;
+        }
+      float t[4][3];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        const int tap = a * 3 + b;
-        g[a][b] = (c < ci && n < co) ? (transpose ? w[((size_t)(8 - tap) * ci_src + n) * co_src + c] : w[((size_t)tap * ci_src + c) * co_src + n]) : 0.f;
+        t[0][b] = g[0][b]; t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]); t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]); t[3][b] = g[2][b];
       }
-    float t[4][3], u[4][4];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      t[0][b] = g[0][b]; t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]); t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]); t[3][b] = g[2][b];
+      for (int a = 0; a < 4; ++a) {
+        u[4 * a][e] = t[a][0]; u[4 * a + 1][e] = 0.5f * (t[a][0] + t[a][1] + t[a][2]); u[4 * a + 2][e] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        u[4 * a + 3][e] = t[a][2];
+      }
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      u[a][0] = t[a][0]; u[a][1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]); u[a][2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]); u[a][3] = t[a][2];
-    }
-    const int kc = c / W_CH, cc = c % W_CH, h = cc >> 2, e = cc & 3;
+    const int kc = c0 / W_CH, h = (c0 % W_CH) >> 2;
     const int blk = n / W_BN, nl = n % W_BN;
     const int wi = nl & 31, wk = wi >> 4, wr = wi & 15;
     const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
     char* slab = out + ((size_t)kc * nb + blk) * W_SLAB;
 #pragma unroll
     for (int pos = 0; pos < 16; ++pos)
-      reinterpret_cast<float*>(slab + ((size_t)pos * 64 + row) * W_REC + ((h ^ ((row >> 3) & 1)) * 16))[e] = u[pos >> 2][pos & 3];
+      *reinterpret_cast<f32x4*>(slab + ((size_t)pos * 64 + row) * W_REC + ((h ^ ((row >> 3) & 1)) * 16)) = u[pos];
+  }
+}
+__global__ void train_pack_wino_kernel(const float* __restrict__ w, int ci_src, int co_src, int transpose, int ci, int co,
+                                       int cin_pad, int nb, char* __restrict__ out) {
+  train_pack_wino_body(w, ci_src, co_src, transpose, ci, co, cin_pad, nb, out, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                       (size_t)gridDim.x * blockDim.x);
+}
+
+// Every layout of every conv in ONE launch (the training step repacks all 138 convs after Adam: 640 launches of a few
+// microseconds each otherwise).  blockIdx.y = 4 * conv + layout (0 direct, 1 direct transposed, 2 Winograd, 3 Winograd
+// transposed); a null destination skips the layout.  PackDesc mirrors fisr_train_pack_desc (include/fisr.h).
+struct PackDesc { const float* w; float* pk; float* pk_t; void* pkw; void* pkw_t; int ci, co; };
+__global__ void train_pack_all_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y >> 2];
+  const int which = blockIdx.y & 3, transpose = which & 1;
+  const int ci = transpose ? d.co : d.ci, co = transpose ? d.ci : d.co;
+  const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  const int cin_pad = (ci + 15) / 16 * 16;
+  if (which < 2) {
+    float* out = transpose ? d.pk_t : d.pk;
+    if (!out) return;
+    const int nt = co < 16 ? 0 : (co <= 32 ? 1 : 2);       // nt_for<float> (fisr_api.hip)
+    const int cout_pad = nt == 0 ? 16 : (co + 32 * nt - 1) / (32 * nt) * (32 * nt);
+    train_pack_body(d.w, d.ci, d.co, transpose, ci, co, cin_pad, cout_pad, out, first, stride);
+  } else {
+    char* out = (char*)(transpose ? d.pkw_t : d.pkw);
+    if (!out) return;
+    train_pack_wino_body(d.w, d.ci, d.co, transpose, ci, co, cin_pad, (co + 15) / 16 * 16 / W_BN, out, first, stride);
   }
 }
 
 // ---- weight gradient ----
+// FISR_GABL (diagnostics builds only, WRONG results): 1 tiles staged once only, 2 no MFMAs, 4 no final reduction / atomics
+#ifndef FISR_GABL
+#define FISR_GABL 0
+#endif
 struct WgradArgs {
   const float* x0; const float* x1; int C0, C1;     // conv input: cat(x0, x1) along channels (x1 nullable), pixel strides C0, C1
   const float* g;  int Cg;                          // gradient of the conv output [N,H,W,Cg] (dense)
   float* dw;       int ci, co;                      // HWIO [3][3][ci][co], accumulated (ci <= C0 + C1, co <= Cg)
   float* db;                                        // nullable: db[co] += sum over pixels of g (done by the first ci block)
   int N, H, W, relu_in, ksplit;
+  unsigned long long* trace;                        // diagnostics builds: 8 words per workgroup (cycle counters), else null
 };
-constexpr int WG_TH = 4, WG_TW = 32;     // 4 rows = one per wave: the register tile prefetch stays small enough for two workgroups per CU
-// (the tiles, or the two 36 KB slots of the final reduction, whichever is larger)
-constexpr size_t wgrad_lds_bytes() {
-  return (size_t)((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4 > (size_t)2 * 9 * 16 * 64 * 4
-             ? (size_t)((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4 : (size_t)2 * 9 * 16 * 64 * 4;
+// Tile geometry is a template parameter: the U-Net's maps go down to 3 x 3 pixels (level 1 at R/8 of a 24 x 24 patch), and a fixed
+// 32-wide tile spends most of its MFMAs on padding there.  wgrad_tile() picks, per launch, the (TW, TH) with the least padding.
+// TH is a multiple of 4 (one to four rows per wave); at most 128 pixels per tile keeps the register prefetch small enough for two
+// workgroups per CU.
+// LDS: the two 36 KB slots of the final reduction (the tiles, smaller, live in the same bytes before it) + the four waves' bias sums
+constexpr size_t WG_RED_BYTES = (size_t)2 * 9 * 16 * 64 * 4;
+constexpr size_t wgrad_lds_bytes() { return WG_RED_BYTES + 4 * 32 * 4; }
+struct WgradTile { int tw, th; };
+inline WgradTile wgrad_tile(int h, int w) {
+  static const WgradTile cand[] = {{32, 4}, {16, 8}, {16, 4}, {8, 16}, {8, 8}, {8, 4}};   // larger tiles first: ties go to them
+  WgradTile best = cand[0];
+  double best_eff = -1.0;
+  for (const WgradTile& c : cand) {
+    const double eff = ((double)w / (((w + c.tw - 1) / c.tw) * c.tw)) * ((double)h / (((h + c.th - 1) / c.th) * c.th));
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+  }
+  return best;
 }
 
+template <int LO, int HI> __device__ __forceinline__ void wg_put(float* dst, const f32x16 (&acc)[9], int lane) {
+#pragma unroll
+  for (int tap = LO; tap < HI; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[((tap - LO) * 16 + r) * 64 + lane] = acc[tap][r];
+}
+template <int LO, int HI> __device__ __forceinline__ void wg_take(const float* src, f32x16 (&acc)[9], int lane) {
+#pragma unroll
+  for (int tap = LO; tap < HI; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tap][r] += src[((tap - LO) * 16 + r) * 64 + lane];
+}
+
+template <int WG_TW, int WG_TH>
 __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) {
+  static_assert(WG_TH % 4 == 0 && WG_TW % 2 == 0 && WG_TW * WG_TH <= 128 && WG_TW * WG_TH * 8 % 256 == 0, "tile geometry");
+  static_assert(((WG_TH + 2) * (WG_TW + 2) + WG_TH * WG_TW) * 32 * 4 <= (int)WG_RED_BYTES, "tile LDS");
   extern __shared__ __attribute__((aligned(16))) char wg_smem[];
-  float* const sX = reinterpret_cast<float*>(wg_smem);                       // [(8+2) x (32+2) px][32 ci]
-  float* const sG = sX + (WG_TH + 2) * (WG_TW + 2) * 32;                     // [8 x 32 px][32 co]
+  float* const sX = reinterpret_cast<float*>(wg_smem);                       // [(TH+2) x (TW+2) px][32 ci]
+  float* const sG = sX + (WG_TH + 2) * (WG_TW + 2) * 32;                     // [TH x TW px][32 co]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int nci = (p.ci + 31) / 32, nco = (p.co + 31) / 32;
   const int blk = blockIdx.x % (nci * nco), ks = blockIdx.x / (nci * nco);
@@ -163,63 +236,98 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) 
       *reinterpret_cast<f32x4*>(sG + (i >> 3) * 32 + 4 * (i & 7)) = rg[k];
     }
   };
+  unsigned long long t_start = 0, t_mfma = 0, t_stage = 0, t_mark = 0, t_real = 0;
+  if (p.trace) { t_start = t_mark = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
   if (ks < ntiles) load_tile(ks);
   for (int tile = ks; tile < ntiles; tile += p.ksplit) {
+    if (!((FISR_GABL & 1) && tile != ks)) {
     __syncthreads();                                 // every wave is done with the previous tile
     store_tile();
     __syncthreads();
     if (tile + p.ksplit < ntiles) load_tile(tile + p.ksplit);
-    // wave w: tile row w; K steps of two neighbouring pixels
-    {
-      const int row = wave;
-#pragma unroll 2
-      for (int col = 0; col < WG_TW; col += 2) {
-        const float b = sG[(row * WG_TW + col + kh) * 32 + li];
-        bsum += b;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const float a = sX[((row + tap / 3) * (WG_TW + 2) + col + kh + tap % 3) * 32 + li];
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
-        }
-      }
     }
+    if (FISR_GABL & 2) continue;
+    if (p.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_stage += t - t_mark; t_mark = t; }
+    // wave w: tile rows w * TH/4 ..; K steps of two neighbouring pixels.  The ten LDS operands of step k+1 are requested
+    // before the nine MFMAs of step k (the compiler's own schedule waited for each read right in front of its MFMA: the
+    // matrix pipe was busy 64 % of the time on the largest layers).
+    constexpr int NSTEP = (WG_TH / 4) * (WG_TW / 2);
+    const float* const gx = sG + (wave * (WG_TH / 4) * WG_TW + kh) * 32 + li;
+    const float* const ax = sX + (wave * (WG_TH / 4) * (WG_TW + 2) + kh) * 32 + li;
+    auto fetch = [&](int step, float (&a)[9], float& b) {
+      const int r = step / (WG_TW / 2), col = 2 * (step % (WG_TW / 2));
+      b = gx[(r * WG_TW + col) * 32];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) a[tap] = ax[((r + tap / 3) * (WG_TW + 2) + col + tap % 3) * 32];
+    };
+    // (fully unrolled: every LDS offset is an immediate; the scheduling barriers keep the reads in front of the MFMAs)
+    float av[2][9], bv[2];
+    fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) fetch(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += bv[step & 1];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][tap], bv[step & 1], acc[tap], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_mfma += t - t_mark; t_mark = t; }
   }
+  const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0;
   // D layout: column (co) = lane & 31, row (ci) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int n = cob + li;
-  if (p.db != nullptr && cib == 0 && n < p.co) unsafeAtomicAdd(p.db + n, bsum);
-  // The four waves hold partial sums over different pixel rows: add them up through LDS (the tiles are dead by now;
-  // 36 KB per wave, two rounds) so that one wave, not four, sends the 9216 atomics of this workgroup.
+  // bias gradient: ONE atomic per output channel and workgroup (all 256 lanes sending theirs put 8 x ksplit x ... same-address
+  // atomics on each of a few dozen words: 60 us of serialisation per launch on the 64-channel layers)
+  bsum += __shfl_xor(bsum, 32);
+  float* const sB = reinterpret_cast<float*>(wg_smem + WG_RED_BYTES);
+  if ((FISR_GABL & 4) && acc[0][0] != 123.456f) return;
+  // The four waves hold partial sums over different pixel rows.  Two exchange rounds through LDS (the tiles are dead by now; a
+  // tap of one wave is 4 KB) leave every wave with the complete sums of two or three taps, and all four waves send their share
+  // of the workgroup's 9216 atomics (one wave sending all of them spent 11 % of the workgroup's life doing so).
+  //   round 1: waves 0 <-> 1 and 2 <-> 3 swap halves (the even wave keeps taps 0-4, the odd one taps 5-8)
+  //   round 2: waves 0 <-> 2 (taps 0-2 / 3-4) and 1 <-> 3 (taps 5-6 / 7-8)
   float* const red = reinterpret_cast<float*>(wg_smem);
-  auto put = [&](int slot) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((slot * 9 + tap) * 16 + r) * 64 + lane] = acc[tap][r];
-  };
-  auto take = [&](int slot) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tap][r] += red[((slot * 9 + tap) * 16 + r) * 64 + lane];
-  };
+  constexpr int TAPF = 16 * 64;                      // floats per tap
   __syncthreads();
-  if (wave == 1) put(0);
-  if (wave == 3) put(1);
+  if (wave == 0) wg_put<5, 9>(red, acc, lane);                    // 4 taps at 0
+  if (wave == 1) wg_put<0, 5>(red + 4 * TAPF, acc, lane);         // 5 taps
+  if (wave == 2) wg_put<5, 9>(red + 9 * TAPF, acc, lane);         // 4 taps
+  if (wave == 3) wg_put<0, 5>(red + 13 * TAPF, acc, lane);        // 5 taps (18 taps = 72 KB in all)
+  if (kh == 0) sB[wave * 32 + li] = bsum;
   __syncthreads();
-  if (wave == 0) take(0);
-  if (wave == 2) take(1);
+  if (wave == 0) wg_take<0, 5>(red + 4 * TAPF, acc, lane);
+  if (wave == 1) wg_take<5, 9>(red, acc, lane);
+  if (wave == 2) wg_take<0, 5>(red + 13 * TAPF, acc, lane);
+  if (wave == 3) wg_take<5, 9>(red + 9 * TAPF, acc, lane);
+  if (wave == 0 && kh == 0 && p.db != nullptr && cib == 0 && n < p.co)
+    unsafeAtomicAdd(p.db + n, (sB[li] + sB[32 + li]) + (sB[64 + li] + sB[96 + li]));
   __syncthreads();
-  if (wave == 2) put(0);
+  if (wave == 0) wg_put<3, 5>(red, acc, lane);                    // 2 taps at 0
+  if (wave == 2) wg_put<0, 3>(red + 2 * TAPF, acc, lane);         // 3 taps
+  if (wave == 1) wg_put<7, 9>(red + 5 * TAPF, acc, lane);         // 2 taps
+  if (wave == 3) wg_put<5, 7>(red + 7 * TAPF, acc, lane);         // 2 taps
   __syncthreads();
-  if (wave != 0) return;
-  take(0);
+  if (wave == 0) wg_take<0, 3>(red + 2 * TAPF, acc, lane);
+  if (wave == 2) wg_take<3, 5>(red, acc, lane);
+  if (wave == 1) wg_take<5, 7>(red + 7 * TAPF, acc, lane);
+  if (wave == 3) wg_take<7, 9>(red + 5 * TAPF, acc, lane);
+  const unsigned long long t_red = p.trace ? __builtin_readcyclecounter() : 0;
+  const int tap_lo = wave == 0 ? 0 : (wave == 2 ? 3 : (wave == 1 ? 5 : 7)), tap_hi = wave == 0 ? 3 : (wave == 2 ? 5 : (wave == 1 ? 7 : 9));
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
+    if (tap >= tap_lo && tap < tap_hi) {             // (wave-uniform)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = cib + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (c < p.ci && n < p.co) unsafeAtomicAdd(p.dw + ((size_t)tap * p.ci + c) * p.co + n, acc[tap][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int c = cib + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (c < p.ci && n < p.co) unsafeAtomicAdd(p.dw + ((size_t)tap * p.ci + c) * p.co + n, acc[tap][r]);
+      }
     }
+  if (p.trace && tid == 0) {          // wave 0's view: start, staging / MFMA cycles of the tile loop, reduction, atomics issued
+    unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
+    tr[0] = t_start; tr[1] = t_stage; tr[2] = t_mfma; tr[3] = t_loop; tr[4] = t_red; tr[5] = __builtin_readcyclecounter();
+    tr[6] = t_real; tr[7] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // db[c] += sum_p g[p][c]   (grid (pixel blocks, ceil(C / 64)); 256 threads = 64 channels x 4 pixel phases)
@@ -406,12 +514,17 @@ __global__ void train_loss_kernel(const LossArgs a) {
 #pragma unroll
     for (int f = 0; f < 3; ++f) a.grad[3][pix * 9 + 3 * f + c] = gq[f];
   }
+  // one atomic per term and WORKGROUP (the seven sums share a cache line: one atomic per wave of a 3456-workgroup grid
+  // serialised into 1.2 ms on the largest level)
+  __shared__ float s_part[4][8];
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     float v = acc[k];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(a.sums + k, v);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6][k] = v;
   }
+  __syncthreads();
+  if (threadIdx.x < 7) unsafeAtomicAdd(a.sums + threadIdx.x, (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]));
 }
 
 // tf.train.AdamOptimizer (TF 1.13 training/adam.py): m, v, var updated in place; lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) from the host

@@ -32,7 +32,7 @@ EXPORTS = [
     "fisr_pwc_flow_workspace_bytes", "fisr_pwc_flow_pair",
     "fisr_pwc_nn_workspace_bytes", "fisr_pwc_nn", "fisr_pwc_prep", "fisr_pwc_flow_out",
     "fisr_pwc_op_conv", "fisr_pwc_op_deconv", "fisr_pwc_op_costvol", "fisr_pwc_op_warp",
-    "fisr_train_packed_bytes", "fisr_train_pack", "fisr_train_wino_bytes", "fisr_train_pack_wino", "fisr_train_conv3x3", "fisr_train_wgrad", "fisr_train_bgrad",
+    "fisr_train_packed_bytes", "fisr_train_pack", "fisr_train_wino_bytes", "fisr_train_pack_wino", "fisr_train_pack_all", "fisr_train_conv3x3", "fisr_train_wgrad", "fisr_train_bgrad",
     "fisr_train_relu_bwd", "fisr_train_axpy", "fisr_train_maxpool2_bwd", "fisr_train_upsample2_bwd", "fisr_train_s2d",
     "fisr_train_copy_channels", "fisr_train_loss", "fisr_train_adam",
 ]
@@ -169,6 +169,7 @@ def lib():
     L.fisr_train_packed_bytes.argtypes = [c_int, c_int, c_int]
     L.fisr_train_packed_bytes.restype = c_size_t
     L.fisr_train_pack.argtypes = [vp, c_int, c_int, c_int, vp, vp]
+    L.fisr_train_pack_all.argtypes = [vp, c_int, vp]
     L.fisr_train_wino_bytes.argtypes = [c_int, c_int, c_int]
     L.fisr_train_wino_bytes.restype = c_size_t
     L.fisr_train_pack_wino.argtypes = [vp, c_int, c_int, c_int, vp, vp]

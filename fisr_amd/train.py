@@ -29,13 +29,17 @@ LAMBDAS = dict(recn=1.0, tm1=1.0, tm2=0.1, tmm=1.0, td=0.1, ss2=1.0)      # main
 LEVEL_SCALE = {"level_1": 4.0, "level_2": 2.0, "level_3": 1.0}            # FISRnet.py:326-328
 
 
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
 def _pad16(c):
     return (c + 15) // 16 * 16
 
 
 class _Conv:
     """One conv layer's device state: master weights (TF layout), gradients, Adam slots, the two packed copies."""
-    __slots__ = ("name", "ci", "co", "w", "b", "gw", "gb", "mw", "vw", "mb", "vb", "pk", "pk_t", "pkw", "pkw_t", "b_pad")
+    __slots__ = ("name", "ci", "co", "w", "b", "gw", "gb", "mw", "vw", "mb", "vb", "pk", "pk_t", "pkw", "pkw_t")
 
 
 class TrainNet:
@@ -51,28 +55,34 @@ class TrainNet:
         _weights.check_complete(W)
         self.convs = OrderedDict()
         f32 = torch.float32
-        # all gradients live in ONE flat buffer (views per tensor): data-parallel training all-reduces it in one call
+        # Weights, gradients and Adam's two slots live in FOUR flat buffers of one layout (views per tensor, every slot a
+        # multiple of four floats so that the conv kernels' 16-byte bias reads stay aligned, 64 floats of tail so that a bias
+        # read up to the N block's padding stays inside the buffer): the step's all-reduce and Adam are then one call each.
         specs = _weights.conv_specs()
-        total = sum(9 * ci * co + co for _, ci, co in specs)
-        self.gflat = torch.zeros(total, dtype=f32, device=self.device)
+        total = sum(_pad4(9 * ci * co) + _pad4(co) for _, ci, co in specs) + 64
+        self.wflat, self.gflat, self.mflat, self.vflat = (torch.zeros(total, dtype=f32, device=self.device) for _ in range(4))
         off = 0
-        for name, ci, co in specs:
+        descs = np.zeros(len(specs), dtype=[("w", "u8"), ("pk", "u8"), ("pk_t", "u8"), ("pkw", "u8"), ("pkw_t", "u8"), ("ci", "i4"), ("co", "i4")])
+        for k, (name, ci, co) in enumerate(specs):
             c = _Conv()
             c.name, c.ci, c.co = name, ci, co
-            c.w = torch.from_numpy(np.ascontiguousarray(W[name + "/w"], dtype=np.float32)).to(self.device)
-            c.b = torch.from_numpy(np.ascontiguousarray(W[name + "/b"], dtype=np.float32)).to(self.device)
-            c.gw = self.gflat[off:off + 9 * ci * co].view(3, 3, ci, co)
-            off += 9 * ci * co
-            c.gb = self.gflat[off:off + co]
-            off += co
-            c.mw, c.vw, c.mb, c.vb = (torch.zeros_like(c.w), torch.zeros_like(c.w), torch.zeros_like(c.b), torch.zeros_like(c.b))
-            c.pk = torch.empty(self.L.fisr_train_packed_bytes(ci, co, 0) // 4, dtype=f32, device=self.device)
-            c.pk_t = torch.empty(self.L.fisr_train_packed_bytes(ci, co, 1) // 4, dtype=f32, device=self.device)
-            nw, nwt = self.L.fisr_train_wino_bytes(ci, co, 0), self.L.fisr_train_wino_bytes(ci, co, 1)     # Winograd slabs (0 = not eligible)
+            nw_, nb_ = 9 * ci * co, co
+            c.w, c.gw, c.mw, c.vw = (f[off:off + nw_].view(3, 3, ci, co) for f in (self.wflat, self.gflat, self.mflat, self.vflat))
+            off += _pad4(nw_)
+            c.b, c.gb, c.mb, c.vb = (f[off:off + nb_] for f in (self.wflat, self.gflat, self.mflat, self.vflat))
+            off += _pad4(nb_)
+            c.w.copy_(torch.from_numpy(np.ascontiguousarray(W[name + "/w"], dtype=np.float32)))
+            c.b.copy_(torch.from_numpy(np.ascontiguousarray(W[name + "/b"], dtype=np.float32)))
+            # one packed layout per conv and orientation: Winograd slabs where the conv is eligible (0 bytes = it is not), the
+            # direct kernel's rows otherwise
+            nw, nwt = self.L.fisr_train_wino_bytes(ci, co, 0), self.L.fisr_train_wino_bytes(ci, co, 1)
             c.pkw = torch.empty(nw // 4, dtype=f32, device=self.device) if nw else None
             c.pkw_t = torch.empty(nwt // 4, dtype=f32, device=self.device) if nwt else None
-            c.b_pad = torch.zeros(max(64, _pad16(co) + 48), dtype=f32, device=self.device)     # bias, padded to the N block
+            c.pk = None if nw else torch.empty(self.L.fisr_train_packed_bytes(ci, co, 0) // 4, dtype=f32, device=self.device)
+            c.pk_t = None if nwt else torch.empty(self.L.fisr_train_packed_bytes(ci, co, 1) // 4, dtype=f32, device=self.device)
+            descs[k] = tuple(t.data_ptr() if t is not None else 0 for t in (c.w, c.pk, c.pk_t, c.pkw, c.pkw_t)) + (ci, co)
             self.convs[name] = c
+        self._pack_descs = torch.from_numpy(descs.view(np.uint8).copy()).to(self.device)       # fisr_train_pack_desc[], on the device
         self.zero_bias = torch.zeros(1024, dtype=f32, device=self.device)
         self.step_count = 0
         self.tape = []
@@ -101,14 +111,7 @@ class TrainNet:
 
     def repack(self):
         """Master weights -> the conv kernel's layouts (after construction and after every Adam step)."""
-        for c in self.convs.values():
-            self._ck(self.L.fisr_train_pack(self._p(c.w), c.ci, c.co, 0, self._p(c.pk), self._st()))
-            self._ck(self.L.fisr_train_pack(self._p(c.w), c.ci, c.co, 1, self._p(c.pk_t), self._st()))
-            if c.pkw is not None:
-                self._ck(self.L.fisr_train_pack_wino(self._p(c.w), c.ci, c.co, 0, self._p(c.pkw), self._st()))
-            if c.pkw_t is not None:
-                self._ck(self.L.fisr_train_pack_wino(self._p(c.w), c.ci, c.co, 1, self._p(c.pkw_t), self._st()))
-            c.b_pad[:c.co].copy_(c.b)
+        self._ck(self.L.fisr_train_pack_all(self._p(self._pack_descs), len(self.convs), self._st()))       # one launch for all 138 convs
 
     def weights_numpy(self):
         out = OrderedDict()
@@ -177,12 +180,12 @@ class TrainNet:
         c1 = x1.shape[3] if x1 is not None else 0
         if scatter is not None:
             dst, coff, split, gap = scatter
-            self._ck(self.L.fisr_train_conv3x3(self._p(x0), c0, self._p(x1), c1, self._p(c.pk), self._p(c.b_pad), c.co, None,
+            self._ck(self.L.fisr_train_conv3x3(self._p(x0), c0, self._p(x1), c1, self._p(c.pk), self._p(c.b), c.co, None,
                                                self._p(dst), n, h, w, flags, dst.shape[3], coff, split, gap, None, self._st()))
             self.tape.append(("conv", c, x0, x1, None, dst, flags, scatter))
             return dst
         y = out if out is not None else (self.new(n, 2 * h, 2 * w, c.co // 4) if flags & D2S else self.new(n, h, w, c.co))
-        self._ck(self.L.fisr_train_conv3x3(self._p(x0), c0, self._p(x1), c1, self._p(c.pk), self._p(c.b_pad), c.co, self._p(res),
+        self._ck(self.L.fisr_train_conv3x3(self._p(x0), c0, self._p(x1), c1, self._p(c.pk), self._p(c.b), c.co, self._p(res),
                                            self._p(y), n, h, w, flags, 0, 0, 0, 0, self._p(c.pkw), self._st()))
         self.tape.append(("conv", c, x0, x1, res, y, flags, None))
         return y
@@ -414,9 +417,8 @@ class TrainNet:
         self.step_count += 1
         t = self.step_count
         lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-        for c in self.convs.values():
-            self._ck(self.L.fisr_train_adam(self._p(c.w), self._p(c.gw), self._p(c.mw), self._p(c.vw), c.w.numel(), lr_t, b1, b2, eps, self._st()))
-            self._ck(self.L.fisr_train_adam(self._p(c.b), self._p(c.gb), self._p(c.mb), self._p(c.vb), c.b.numel(), lr_t, b1, b2, eps, self._st()))
+        self._ck(self.L.fisr_train_adam(self._p(self.wflat), self._p(self.gflat), self._p(self.mflat), self._p(self.vflat), self.wflat.numel(),
+                                        lr_t, b1, b2, eps, self._st()))                  # every tensor at once (the padding stays 0)
         self.repack()
 
     def train_step(self, batch, lr, group=None):

@@ -281,6 +281,15 @@ size_t fisr_train_packed_bytes(int ci, int co, int transpose);
 int fisr_train_pack(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
 size_t fisr_train_wino_bytes(int ci, int co, int transpose);      /* 0: not eligible for the Winograd kernel */
 int fisr_train_pack_wino(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
+/* every layout of n convs in ONE launch (what a training step does after Adam): d_descs is a DEVICE array of n descriptors;
+ * a null destination skips that layout */
+typedef struct fisr_train_pack_desc {
+  const float* w;            /* HWIO [3][3][ci][co], device */
+  float* pk; float* pk_t;    /* fisr_train_pack, transpose = 0 / 1 */
+  void* pkw; void* pkw_t;    /* fisr_train_pack_wino, transpose = 0 / 1 */
+  int ci, co;
+} fisr_train_pack_desc;
+int fisr_train_pack_all(const fisr_train_pack_desc* d_descs, int n, void* stream);
 int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed, const float* d_bias,
                        int cout, const float* res, float* out, int n, int h, int w, int flags, int out_cstride,
                        int out_coff, int out_split, int out_gap, const void* d_packed_wino /* nullable */, void* stream);

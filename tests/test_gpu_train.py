@@ -36,7 +36,10 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("n,h,w,c0,c1,ci,co,cg,relu_in", [
     (1, 8, 32, 64, 0, 64, 64, 64, 0), (2, 13, 45, 32, 0, 29, 64, 64, 0), (1, 16, 40, 64, 64, 128, 64, 64, 1),
-    (1, 24, 24, 64, 0, 64, 6, 16, 0), (3, 9, 33, 48, 0, 38, 96, 96, 1)])
+    (1, 24, 24, 64, 0, 64, 6, 16, 0), (3, 9, 33, 48, 0, 38, 96, 96, 1),
+    # the small maps of the U-Net's lower levels (each picks another tile geometry of the weight-gradient kernel)
+    (5, 3, 3, 64, 0, 64, 64, 64, 1), (3, 6, 6, 32, 32, 64, 32, 32, 0), (2, 12, 12, 64, 0, 64, 64, 64, 1), (1, 48, 48, 32, 0, 32, 64, 64, 0),
+    (2, 5, 24, 32, 0, 32, 32, 32, 0)])
 def test_wgrad_bgrad_dgrad_vs_autograd(env, n, h, w, c0, c1, ci, co, cg, relu_in):
     torch, L, lib = env
     import torch.nn.functional as F
@@ -366,3 +369,65 @@ def test_train_conv_winograd_path_equals_direct_path(env, transpose, flags, with
     assert np.abs(a).max() > 0.5
     assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
     assert not np.array_equal(a, b)          # (two different algorithms: identical bits would mean the slabs were ignored)
+
+
+def test_pack_all_equals_the_single_packs(env):
+    """fisr_train_pack_all (every layout of every conv in one launch, what the training step uses) writes the same bytes as
+    fisr_train_pack / fisr_train_pack_wino conv by conv; layouts a conv is not eligible for are skipped (null destination)."""
+    torch, L, lib = env
+    r = np.random.default_rng(5)
+    shapes = [(29, 64), (64, 64), (64, 48), (128, 256), (64, 3), (64, 6), (16, 64), (512, 256)]
+    keep, rows = [], []
+    for ci, co in shapes:
+        w = _dev(torch, r.standard_normal((3, 3, ci, co)).astype(np.float32))
+        bufs = []
+        for tr in (0, 1):
+            bufs.append(torch.full((L.fisr_train_packed_bytes(ci, co, tr) // 4,), 7.0, device="cuda:0"))
+        for tr in (0, 1):
+            nb = L.fisr_train_wino_bytes(ci, co, tr)
+            bufs.append(torch.full((nb // 4,), 7.0, device="cuda:0") if nb else None)
+        keep.append((w, bufs))
+        rows.append((w.data_ptr(),) + tuple(b.data_ptr() if b is not None else 0 for b in bufs) + (ci, co))
+    descs = np.array(rows, dtype=[("w", "u8"), ("pk", "u8"), ("pk_t", "u8"), ("pkw", "u8"), ("pkw_t", "u8"), ("ci", "i4"), ("co", "i4")])
+    assert descs.itemsize == 48
+    table = torch.from_numpy(descs.view(np.uint8).copy()).to("cuda:0")
+    assert L.fisr_train_pack_all(_ptr(table), len(shapes), None) == 0
+    torch.cuda.synchronize()
+    n_wino = 0
+    for (ci, co), (w, bufs) in zip(shapes, keep):
+        for k, b in enumerate(bufs):
+            if b is None:
+                continue
+            ref = torch.full_like(b, 7.0)
+            if k < 2:
+                assert L.fisr_train_pack(_ptr(w), ci, co, k, _ptr(ref), None) == 0
+            else:
+                assert L.fisr_train_pack_wino(_ptr(w), ci, co, k - 2, _ptr(ref), None) == 0
+                n_wino += 1
+            assert torch.equal(b, ref), (ci, co, k)
+    assert n_wino >= 8
+    assert L.fisr_train_pack_all(None, 1, None) < 0
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(32, 3, 3, 256, 128), (8, 6, 6, 128, 128), (4, 12, 12, 64, 64), (2, 24, 24, 32, 64)])
+def test_train_conv_winograd_on_small_maps(env, n, h, w, ci, co):
+    """The training step sends every eligible layer to the Winograd kernel, the 3 x 3 ... 24 x 24 maps of the lower U-Net
+    levels included (one mostly empty 8 x 32 tile per image): same result as the direct kernel."""
+    torch, L, lib = env
+    r = np.random.default_rng(h)
+    wt = _dev(torch, (r.standard_normal((3, 3, ci, co)) * 0.05).astype(np.float32))
+    x = _dev(torch, r.standard_normal((n, h, w, ci)).astype(np.float32))
+    bias = _dev(torch, r.standard_normal(1024).astype(np.float32) * 0.1)
+    res = _dev(torch, r.standard_normal((n, h, w, co)).astype(np.float32))
+    pk = torch.empty(L.fisr_train_packed_bytes(ci, co, 0) // 4, device="cuda:0")
+    pkw = torch.empty(L.fisr_train_wino_bytes(ci, co, 0) // 4, device="cuda:0")
+    assert pkw.numel() > 0
+    assert L.fisr_train_pack(_ptr(wt), ci, co, 0, _ptr(pk), None) == 0
+    assert L.fisr_train_pack_wino(_ptr(wt), ci, co, 0, _ptr(pkw), None) == 0
+    y0, y1 = torch.empty((n, h, w, co), device="cuda:0"), torch.empty((n, h, w, co), device="cuda:0")
+    for y, slabs in ((y0, None), (y1, pkw)):
+        assert L.fisr_train_conv3x3(_ptr(x), ci, None, 0, _ptr(pk), _ptr(bias), co, _ptr(res), _ptr(y), n, h, w, 3, 0, 0, 0, 0, _ptr(slabs), None) == 0
+    a, b = y0.cpu().numpy(), y1.cpu().numpy()
+    assert np.abs(a).max() > 0.5
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
+    assert not np.array_equal(a, b)
