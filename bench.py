@@ -459,7 +459,7 @@ def cfg5_pipeline(torch, dev, W, wl, net32, local_rank, reps=3):
     return out
 
 
-def time_training_step(W, torch, local_rank, steps=3):
+def time_training_step(W, torch, local_rank, steps=5):
     """Row f4 (FISRnet.py:175-497): one training step of the reference's configuration -- batch 8 of 96x96 LR patches of 5
     frames (main.py:74), four weight-sharing passes forward and backward, seven loss terms, Adam -- on fisr_amd/train.py.
     Not part of `value`."""
@@ -472,7 +472,8 @@ def time_training_step(W, torch, local_rank, steps=3):
         flow_ss2=(r.standard_normal((b, p, p, 8)) * 0.04).astype(f32), warp_ss2=r.random((b, p, p, 12), dtype=f32)),
         f"cuda:{local_rank}")
     net = train.TrainNet(W, device=f"cuda:{local_rank}")
-    net.train_step(batch, 1e-4)
+    for _ in range(2):
+        net.train_step(batch, 1e-4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -751,7 +751,7 @@ struct Runner {
   }
   void up(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:69
     if (rc || ar.dry) return;
-    const size_t work = (size_t)n * h * w * c / Unit<T>::UC;   // one thread per input unit -> 2x2 output units
+    const size_t work = (size_t)n * ((h + UP_ROWS - 1) / UP_ROWS) * w * c / Unit<T>::UC;   // one thread per unit of a 16-row column segment
     ProfScope ps(ctx, st, "upsample2", 0, (double)n * h * w * c * sizeof(T) * 5.0);
     hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
     check(hipGetLastError(), "upsample2");
@@ -1306,7 +1306,7 @@ int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int
   if (!in || !out || !prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: bad argument");
   const int uc = prec_unit(precision);
   if (c % (prec_grouped16(precision) ? 16 : uc)) return fail(nullptr, FISR_EINVAL, "fisr_op_upsample2: c must be a multiple of the channel unit");
-  const size_t work = (size_t)n * h * w * c / uc;
+  const size_t work = (size_t)n * ((h + UP_ROWS - 1) / UP_ROWS) * w * c / uc;
   DeviceGuard guard(device_of(out));
   HIP_OK(nullptr, guard.err);
   with_prec(precision, [&](auto tag) {

@@ -115,6 +115,18 @@ static int wgrad_impl(const float* x0, int c0, const float* x1, int c1, int relu
     return fail(nullptr, FISR_EINVAL, "fisr_train_wgrad: bad argument");
   DeviceGuard guard(device_of(dw));
   HIP_OK(nullptr, guard.err);
+  if (co <= 8 && c1 == 0 && c0 == 64 && cg == 16) {   // the heads: vector-ALU kernel, one lane per input channel
+    WgradArgs a;
+    a.x0 = x0; a.x1 = nullptr; a.C0 = c0; a.C1 = 0; a.g = g; a.Cg = cg; a.dw = dw; a.db = db; a.ci = ci; a.co = co;
+    a.N = n; a.H = h; a.W = w; a.relu_in = relu_in; a.trace = nullptr;
+    const int nci = (ci + 63) / 64, units = n * h;
+    a.ksplit = std::max(1, std::min((units + 3) / 4, 768 / nci));
+    if (co <= 3) hipLaunchKernelGGL(train_wgrad_head_kernel<3>, dim3(nci * a.ksplit), dim3(256), 0, (hipStream_t)stream, a);
+    else if (co <= 6) hipLaunchKernelGGL(train_wgrad_head_kernel<6>, dim3(nci * a.ksplit), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(train_wgrad_head_kernel<8>, dim3(nci * a.ksplit), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_OK(nullptr, hipGetLastError());
+    return 0;
+  }
   const WgradTile tl = wgrad_tile(h, w);
   void (*kern)(const WgradArgs) = nullptr;
   int slot = 0;

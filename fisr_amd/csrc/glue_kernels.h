@@ -210,38 +210,47 @@ __global__ void maxpool2_kernel(const T* __restrict__ in, T* __restrict__ out, i
 // ---- x2 bilinear up-sample: ops.py:69 tf.image.resize_images(BILINEAR), TF-1.13 legacy kernel ----
 // in = out*0.5, lo = floor(in), hi = min(lo+1, n-1), t = in-lo;
 // top = tl+(tr-tl)*tx; bot = bl+(br-bl)*tx; out = top+(bot-top)*ty   
+constexpr int UP_ROWS = 16;        // input rows one thread walks down (the row below is re-read once per UP_ROWS rows)
 template <typename T>
 __global__ void upsample2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
 #pragma clang fp contract(off)
-  // One thread = one channel unit of one INPUT pixel: the 2x2 output quad (2y..2y+1, 2x..2x+1) blends the
-  // same four taps (x, x+1 clamped; y, y+1 clamped) with tx, ty in {0, 0.5}: 4 loads -> 4 stores.
+  // One thread = one channel unit of one INPUT column segment of UP_ROWS rows: the 2x2 output quad (2y..2y+1, 2x..2x+1)
+  // blends the four taps (x, x+1 clamped; y, y+1 clamped) with tx, ty in {0, 0.5}, and the bottom taps of a row are the
+  // top taps of the next one, kept in registers: every input unit is fetched once (plus the right-hand neighbour's, which
+  // is the next lanes' own fetch: same cache lines) instead of twice from rows that other workgroups read much later
+  // (r02: 1.39 GB of HBM traffic for 1.06 GB of algorithmic bytes).
   constexpr int UC = Unit<T>::UC;
-  const int ow = W * 2, cv = C / UC;
-  const size_t total = (size_t)N * H * W * cv;
+  const int ow = W * 2, cv = C / UC, rbs = (H + UP_ROWS - 1) / UP_ROWS;
+  const size_t total = (size_t)N * rbs * W * cv;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv);
-    const size_t pix = i / cv;
-    const int x0 = (int)(pix % W);
-    const int y0 = (int)((pix / W) % H);
-    const int n = (int)(pix / ((size_t)W * H));
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-    const size_t r0 = ((size_t)n * H + y0) * W, r1 = ((size_t)n * H + y1) * W;
+    size_t t = i / cv;
+    const int x0 = (int)(t % W); t /= W;
+    const int rb = (int)(t % rbs);
+    const int n = (int)(t / rbs);
+    const int x1 = min(x0 + 1, W - 1), ya = rb * UP_ROWS, yb = min(ya + UP_ROWS, H);
     float tl[UC], tr[UC], bl[UC], br[UC], o[UC];
+    const size_t r0 = ((size_t)n * H + ya) * W;
     Unit<T>::load(in + (r0 + x0) * C, c, tl);
     Unit<T>::load(in + (r0 + x1) * C, c, tr);
-    Unit<T>::load(in + (r1 + x0) * C, c, bl);
-    Unit<T>::load(in + (r1 + x1) * C, c, br);
+    for (int y0 = ya; y0 < yb; ++y0) {
+      const size_t r1 = ((size_t)n * H + min(y0 + 1, H - 1)) * W;
+      Unit<T>::load(in + (r1 + x0) * C, c, bl);
+      Unit<T>::load(in + (r1 + x1) * C, c, br);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float ty = (q & 2) ? 0.5f : 0.f, tx = (q & 1) ? 0.5f : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const float ty = (q & 2) ? 0.5f : 0.f, tx = (q & 1) ? 0.5f : 0.f;
 #pragma unroll
-      for (int k = 0; k < UC; ++k) {
-        const float top = tl[k] + (tr[k] - tl[k]) * tx;
-        const float bot = bl[k] + (br[k] - bl[k]) * tx;
-        o[k] = top + (bot - top) * ty;
+        for (int k = 0; k < UC; ++k) {
+          const float top = tl[k] + (tr[k] - tl[k]) * tx;
+          const float bot = bl[k] + (br[k] - bl[k]) * tx;
+          o[k] = top + (bot - top) * ty;
+        }
+        const size_t opix = ((size_t)n * 2 * H + 2 * y0 + (q >> 1)) * ow + 2 * x0 + (q & 1);
+        Unit<T>::store(out + opix * C, c, o);
       }
-      const size_t opix = ((size_t)n * 2 * H + 2 * y0 + (q >> 1)) * ow + 2 * x0 + (q & 1);
-      Unit<T>::store(out + opix * C, c, o);
+#pragma unroll
+      for (int k = 0; k < UC; ++k) { tl[k] = bl[k]; tr[k] = br[k]; }
     }
   }
 }

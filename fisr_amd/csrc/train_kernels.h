@@ -54,7 +54,10 @@ __device__ __forceinline__ void train_pack_wino_body(const float* __restrict__ w
   // one thread per (output channel n, four input channels c .. c+3 = one 16-byte half record): 16 stores of 16 bytes
   const size_t total = (size_t)(cin_pad / 4) * nb * 64;
   for (size_t i = first; i < total; i += stride) {
-    const int n = (int)(i % (nb * 64)), c0 = 4 * (int)(i / (nb * 64));
+    // lanes run along the source's contiguous axis: output channels of w[tap][c][n], input channels of the transposed
+    // w[8 - tap][n][c] (lanes along n there read 16 bytes out of every 128-byte line they touch)
+    const int n = transpose ? (int)(i / (cin_pad / 4)) : (int)(i % (nb * 64));
+    const int c0 = 4 * (transpose ? (int)(i % (cin_pad / 4)) : (int)(i / (nb * 64)));
     f32x4 u[16];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -328,6 +331,114 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) 
     tr[0] = t_start; tr[1] = t_stage; tr[2] = t_mfma; tr[3] = t_loop; tr[4] = t_red; tr[5] = __builtin_readcyclecounter();
     tr[6] = t_real; tr[7] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+// ---- weight gradient of the 3- and 6-channel heads (co <= 8, g padded to 16 channels) on the vector ALU ----
+// On train_wgrad_kernel a head fills 3 or 6 of the 32 MFMA columns (64 -> 6 at 192 x 192 x 32 images: 408 us).  Here a lane
+// owns one input channel and keeps all 9 x CO sums in registers; a wave walks along one image row with the 3 x 3 window of
+// its channel in registers (eight columns at a time, the next eight already requested), the CO gradients of the pixel come
+// from one 64-byte load and v_readlane as scalar FMA operands.  Four waves of a workgroup take different rows; their sums
+// meet in LDS and leave as one atomic per weight and workgroup.
+template <int CO>
+__global__ __launch_bounds__(256) void train_wgrad_head_kernel(const WgradArgs p) {
+  __shared__ float s_red[9 * CO * 64];
+  __shared__ float s_b[4][CO];
+  constexpr int CH = 8;                                        // columns per register chunk
+  constexpr int HC0 = 64, HCG = 16;                            // pixel strides of x and g (what the heads have; the launcher checks)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nci = (p.ci + 63) / 64;
+  const int blk = blockIdx.x % nci, ks = blockIdx.x / nci;
+  const int c = blk * 64 + lane;
+  const bool cok = c < HC0;
+  float acc[9][CO];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[t][o] = 0.f;
+  float bs = 0.f;
+  const int units = p.N * p.H;
+  for (int u = ks * 4 + wave; u < units; u += p.ksplit * 4) {
+    const int n = u / p.H, y = u - n * p.H;
+    const float* xr[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      xr[dy] = (cok && yy >= 0 && yy < p.H) ? p.x0 + ((size_t)(n * p.H + yy) * p.W) * HC0 + c : nullptr;
+    }
+    const float* gr = lane < HCG ? p.g + ((size_t)(n * p.H + y) * p.W) * HCG + lane : nullptr;
+    float cur[3][CH], nxt[3][CH], gc[CH], gn[CH], left[3] = {0.f, 0.f, 0.f};
+    // (the pixel strides are compile-time constants, HC0 and HCG: every load of a chunk is base + immediate offset)
+    auto fetch = [&](int x0, float (&xv)[3][CH], float (&gv)[CH]) {
+      const float* xb[3] = {xr[0] ? xr[0] + (size_t)x0 * HC0 : nullptr, xr[1] ? xr[1] + (size_t)x0 * HC0 : nullptr,
+                            xr[2] ? xr[2] + (size_t)x0 * HC0 : nullptr};
+      const float* gb = gr ? gr + (size_t)x0 * HCG : nullptr;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const bool in = x0 + j < p.W;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) xv[dy][j] = (in && xb[dy]) ? xb[dy][j * HC0] : 0.f;
+        gv[j] = (in && gb) ? gb[j * HCG] : 0.f;
+      }
+    };
+    fetch(0, cur, gc);
+    for (int x0 = 0; x0 < p.W; x0 += CH) {
+      fetch(x0 + CH, nxt, gn);                                 // (all zeros behind the row's end)
+      if (p.relu_in) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int j = 0; j < CH; ++j) cur[dy][j] = fmaxf(cur[dy][j], 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if (lane < CO) bs += gc[j];
+        float go[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) go[o] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gc[j]), o));
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const float l = j == 0 ? left[dy] : cur[dy][j - 1];
+          const float r = j == CH - 1 ? (p.relu_in ? fmaxf(nxt[dy][0], 0.f) : nxt[dy][0]) : cur[dy][j + 1];
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            acc[dy * 3 + 0][o] = fmaf(l, go[o], acc[dy * 3 + 0][o]);
+            acc[dy * 3 + 1][o] = fmaf(cur[dy][j], go[o], acc[dy * 3 + 1][o]);
+            acc[dy * 3 + 2][o] = fmaf(r, go[o], acc[dy * 3 + 2][o]);
+          }
+        }
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        left[dy] = cur[dy][CH - 1];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) cur[dy][j] = nxt[dy][j];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) gc[j] = gn[j];
+    }
+  }
+  // the four waves' sums -> LDS -> one atomic per weight
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) s_red[(t * CO + o) * 64 + lane] = acc[t][o];
+  }
+  if (lane < CO) s_b[wave][lane] = bs;
+  __syncthreads();
+  if (wave != 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) atomicAdd(&s_red[(t * CO + o) * 64 + lane], acc[t][o]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * CO * 64; i += 256) {
+    const int l = i & 63, to = i >> 6, o = to % CO, t = to / CO;
+    const int cc = blk * 64 + l;
+    if (cc < p.ci && o < p.co) unsafeAtomicAdd(p.dw + ((size_t)t * p.ci + cc) * p.co + o, s_red[i]);
+  }
+  if (p.db != nullptr && blk == 0 && tid < CO && tid < p.co) unsafeAtomicAdd(p.db + tid, (s_b[0][tid] + s_b[1][tid]) + (s_b[2][tid] + s_b[3][tid]));
 }
 
 // db[c] += sum_p g[p][c]   (grid (pixel blocks, ceil(C / 64)); 256 threads = 64 channels x 4 pixel phases)

@@ -89,6 +89,10 @@ class TrainNet:
         self.keep_preds = False        # loss_and_grads() then leaves the four passes' predictions in last_preds
         self.grad_scale = 1.0          # data parallel: 1 / world (see allreduce_grads)
         self.last_preds = None
+        # Weight gradients run on a second stream: nothing but Adam consumes them, so each wgrad launch overlaps the data-gradient
+        # chain of the layers below it and fills the CUs that the small maps of the lower U-Net levels leave idle.
+        self.overlap_wgrad = True
+        self._side = torch.cuda.Stream(device=self.device)
         self.repack()
 
     # ------------------------------------------------------------------ plumbing
@@ -260,12 +264,38 @@ class TrainNet:
         return p1, p2, p3
 
     # ------------------------------------------------------------------ backward
+    def _before_write(self, t):
+        """An in-place write to `t` on the main stream: a weight-gradient launch on the side stream may still be reading it."""
+        ev = getattr(t, "_fisr_side_ev", None)
+        if ev is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(ev)
+            t._fisr_side_ev = None
+
     def _acc(self, grads, t, g):
         k = t.data_ptr()
         if k in grads:
+            self._before_write(grads[k])
             self._ck(self.L.fisr_train_axpy(self._p(g), 1.0, self._p(grads[k]), g.numel(), self._st()))
         else:
             grads[k] = g
+
+    def _wgrad(self, c, x0, c0, x1, c1, relu_in, g, n, h, w):
+        """fisr_train_wgrad on the side stream (after everything the main stream has queued so far); the tensors it reads are
+        kept from reuse (record_stream) and from in-place writes (_before_write) until it is done."""
+        torch, L = self.torch, self.L
+        args = (self._p(x0), c0, self._p(x1), c1, relu_in, self._p(g), g.shape[3], self._p(c.gw), self._p(c.gb), c.ci, c.co, n, h, w)
+        if not self.overlap_wgrad:
+            self._ck(L.fisr_train_wgrad(*args, self._st()))
+            return
+        main, side = torch.cuda.current_stream(self.device), self._side
+        side.wait_stream(main)
+        self._ck(L.fisr_train_wgrad(*args, ctypes.c_void_p(side.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(side)
+        for t in (x0, x1, g):
+            if t is not None:
+                t.record_stream(side)
+        g._fisr_side_ev = ev
 
     def backward(self, pred_grads):
         """pred_grads: {prediction tensor: its gradient}.  Walks the tape in reverse; weight / bias gradients ACCUMULATE
@@ -295,6 +325,7 @@ class TrainNet:
                     if g is None:
                         continue
                     if flags & RELU_OUT:
+                        self._before_write(g)
                         self._ck(L.fisr_train_relu_bwd(self._p(g), self._p(y), self._p(g), g.numel(), self._st()))
                     if flags & D2S:
                         g_lr = self.new(n, h, w, c.co)
@@ -303,8 +334,7 @@ class TrainNet:
                     if res is not None:
                         self._acc(grads, res, g)
                 cg = g.shape[3]
-                self._ck(L.fisr_train_wgrad(self._p(x0), c0, self._p(x1), c1, 1 if flags & RELU_IN else 0, self._p(g), cg,
-                                            self._p(c.gw), self._p(c.gb), c.ci, c.co, n, h, w, self._st()))      # weight + bias gradient
+                self._wgrad(c, x0, c0, x1, c1, 1 if flags & RELU_IN else 0, g, n, h, w)                         # weight + bias gradient
                 if not getattr(x0, "_fisr_needs_grad", True):
                     continue
                 # data gradient: the same conv with rotated taps, input g (cg channels, cg % 16 == 0), output c0 + c1 channels
@@ -352,6 +382,7 @@ class TrainNet:
                     gp = self.zeros(*prev.shape)
                     grads[prev.data_ptr()] = gp
                 self._ck(L.fisr_train_copy_channels(self._p(g), cp, 29, self._p(gp), 9, 0, 9, n * h * w, 1, self._st()))
+        torch.cuda.current_stream(self.device).wait_stream(self._side)       # the weight gradients are complete from here on
         self.tape = []
 
     # ------------------------------------------------------------------ the training step (FISRnet.py:283-491)

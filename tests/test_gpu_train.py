@@ -39,7 +39,9 @@ def _rel(a, b):
     (1, 24, 24, 64, 0, 64, 6, 16, 0), (3, 9, 33, 48, 0, 38, 96, 96, 1),
     # the small maps of the U-Net's lower levels (each picks another tile geometry of the weight-gradient kernel)
     (5, 3, 3, 64, 0, 64, 64, 64, 1), (3, 6, 6, 32, 32, 64, 32, 32, 0), (2, 12, 12, 64, 0, 64, 64, 64, 1), (1, 48, 48, 32, 0, 32, 64, 64, 0),
-    (2, 5, 24, 32, 0, 32, 32, 32, 0)])
+    (2, 5, 24, 32, 0, 32, 32, 32, 0),
+    # the 3- / 6-channel heads (vector-ALU kernel: ragged widths, one-row images, relu on load, fewer real input channels than 64)
+    (2, 20, 37, 64, 0, 64, 3, 16, 1), (3, 1, 9, 64, 0, 64, 6, 16, 0), (1, 33, 8, 64, 0, 40, 3, 16, 0), (40, 7, 19, 64, 0, 64, 6, 16, 1)])
 def test_wgrad_bgrad_dgrad_vs_autograd(env, n, h, w, c0, c1, ci, co, cg, relu_in):
     torch, L, lib = env
     import torch.nn.functional as F
