@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the training step, binned by kernel and grid size (which map sizes the time goes to), after the
+# rocprofv3 kernel trace of the training step (weight gradients on the main stream: the durations add up), binned by kernel and grid size (which map sizes the time goes to), after the
 # gradient tests.  bash scripts/train_prof.sh   ->  gpurun_out/train_kernels.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -7,9 +7,10 @@ export TMPDIR=/tmp
 if [ -z "$SKIP_TESTS" ]; then
 timeout 1200 python -m pytest tests/test_gpu_train.py -q --no-header -x -p no:cacheprovider > gpurun_out/pytest_train.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_train.log
 fi
-timeout 600 python scripts/train_bench.py 8 96 5 2>&1 | tail -2
+timeout 600 python scripts/train_bench.py 8 96 5 2>&1 | tail -1
+timeout 600 python scripts/train_bench.py 8 96 5 serial 2>&1 | tail -1
 rm -rf /tmp/trprof
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/trprof -- python scripts/train_bench.py 8 96 3 > gpurun_out/train_prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/trprof -- python scripts/train_bench.py 8 96 3 serial > gpurun_out/train_prof.log 2>&1
 python - <<'PY' > gpurun_out/train_kernels.txt
 import csv, glob, collections
 f = glob.glob('/tmp/trprof/**/*kernel_trace.csv', recursive=True)[0]
