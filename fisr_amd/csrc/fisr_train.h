@@ -127,15 +127,38 @@ static int wgrad_impl(const float* x0, int c0, const float* x1, int c1, int relu
     HIP_OK(nullptr, hipGetLastError());
     return 0;
   }
-  const WgradTile tl = wgrad_tile(h, w);
+  WgradTile tl = wgrad_tile(h, w);
   void (*kern)(const WgradArgs) = nullptr;
   int slot = 0;
+  // Winograd-domain kernel (2.25 x fewer MFMAs) where one of its tiles (4 x 32, 8 x 16, 16 x 8 pixels) wastes at most a quarter
+  // of the map's pixels; the direct kernel with the tile geometry of wgrad_tile() otherwise
+  bool wino = false;
+  if (ci >= 32 && co >= 32) {
+    double best = 0.0;
+    for (int tw : {32, 16, 8}) {
+      const int th = 128 / tw;
+      const double eff = ((double)w / (((w + tw - 1) / tw) * tw)) * ((double)h / (((h + th - 1) / th) * th));
+      if (eff > best + 1e-9) { best = eff; tl.tw = tw; tl.th = th; }
+    }
+    wino = best >= 0.75;
+    if (!wino) tl = wgrad_tile(h, w);
+  }
+#ifdef FISR_DIAG
+  static const int env_wg = [] { const char* e = getenv("FISR_TRAIN_WGRAD_WINO"); return e ? atoi(e) : -1; }();
+  if (env_wg == 0 && wino) { wino = false; tl = wgrad_tile(h, w); }
+#endif
 #define FISR_WGRAD_CASE(TW, TH, S) if (tl.tw == TW && tl.th == TH) { kern = train_wgrad_kernel<TW, TH>; slot = S; }
+  if (wino) {
+    if (tl.tw == 32) { kern = train_wgrad_wino_kernel<32>; slot = 6; }
+    else if (tl.tw == 16) { kern = train_wgrad_wino_kernel<16>; slot = 7; }
+    else { kern = train_wgrad_wino_kernel<8>; slot = 8; }
+  } else {
   FISR_WGRAD_CASE(32, 4, 0) FISR_WGRAD_CASE(16, 8, 1) FISR_WGRAD_CASE(16, 4, 2)
   FISR_WGRAD_CASE(8, 16, 3) FISR_WGRAD_CASE(8, 8, 4) FISR_WGRAD_CASE(8, 4, 5)
+  }
 #undef FISR_WGRAD_CASE
   if (!kern) return fail(nullptr, FISR_EINVAL, "fisr_train_wgrad: no kernel for the tile");
-  static bool attr_done[64][6] = {};
+  static bool attr_done[64][9] = {};
   int dev = 0; (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_done[dev][slot]) {
     HIP_OK(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

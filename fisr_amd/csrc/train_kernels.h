@@ -152,6 +152,64 @@ inline WgradTile wgrad_tile(int h, int w) {
   return best;
 }
 
+// Register staging of one pixel tile of the weight-gradient kernels: halo tile of x (TH+2 x TW+2 pixels, 32 input channels from
+// cib on, zero outside the image and behind the last channel) and tile of g (TH x TW pixels, 32 output channels from cob on).
+template <int WG_TW, int WG_TH> struct WgStager {
+  static constexpr int NX = ((WG_TH + 2) * (WG_TW + 2) * 8 + 255) / 256, NG = WG_TH * WG_TW * 8 / 256;
+  f32x4 rx[NX], rg[NG];
+  __device__ __forceinline__ void load(const WgradArgs& p, int tile, int tiles_x, int tiles_y, int cib, int cob, int tid) {
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int nb = t / tiles_y;
+    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {                   // x halo tile, 4 channels per thread
+      const int i = tid + 256 * k;
+      const int px = min(i >> 3, (WG_TH + 2) * (WG_TW + 2) - 1), q = i & 7;
+      const int py = px / (WG_TW + 2), pxx = px - py * (WG_TW + 2);
+      const int gy = y0 - 1 + py, gx = x0 - 1 + pxx, c = cib + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        const size_t pix = ((size_t)nb * p.H + gy) * p.W + gx;
+        if (c < p.C0) v = *reinterpret_cast<const f32x4*>(p.x0 + pix * p.C0 + c);            // (C0 % 4 == 0)
+        else if (c < p.C0 + p.C1) v = *reinterpret_cast<const f32x4*>(p.x1 + pix * p.C1 + (c - p.C0));
+      }
+      rx[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {                   // g tile
+      const int i = tid + 256 * k;
+      const int px = i >> 3, q = i & 7;
+      const int py = px / WG_TW, pxx = px - py * WG_TW;
+      const int gy = y0 + py, gx = x0 + pxx, c = cob + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < p.H && gx < p.W) {
+        const float* src = p.g + (((size_t)nb * p.H + gy) * p.W + gx) * p.Cg + c;
+        if (c + 3 < p.Cg) v = *reinterpret_cast<const f32x4*>(src);                          // (Cg % 4 == 0 or a ragged tail)
+        else { if (c < p.Cg) v.x = src[0]; if (c + 1 < p.Cg) v.y = src[1]; if (c + 2 < p.Cg) v.z = src[2]; }
+      }
+      rg[k] = v;
+    }
+  }
+  __device__ __forceinline__ void store(const WgradArgs& p, float* sX, float* sG, int tid) {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int i = tid + 256 * k;
+      if (i < (WG_TH + 2) * (WG_TW + 2) * 8) {
+        f32x4 v = rx[k];
+        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<f32x4*>(sX + (i >> 3) * 32 + 4 * (i & 7)) = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+      const int i = tid + 256 * k;
+      *reinterpret_cast<f32x4*>(sG + (i >> 3) * 32 + 4 * (i & 7)) = rg[k];
+    }
+  }
+};
+
 template <int LO, int HI> __device__ __forceinline__ void wg_put(float* dst, const f32x16 (&acc)[9], int lane) {
 #pragma unroll
   for (int tap = LO; tap < HI; ++tap)
@@ -186,59 +244,9 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) 
   float bsum = 0.f;                                   // bias gradient: every g value passes through a lane as operand B
   // Software pipeline: the global loads of the NEXT tile are issued into registers before the MFMAs of this one and
   // written to LDS after them, so their latency (eleven + eight dependent round trips otherwise) hides under the MFMAs.
-  constexpr int NX = ((WG_TH + 2) * (WG_TW + 2) * 8 + 255) / 256, NG = WG_TH * WG_TW * 8 / 256;
-  f32x4 rx[NX], rg[NG];
-  auto load_tile = [&](int tile) {
-    int t = tile;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int nb = t / tiles_y;
-    const int x0 = tx * WG_TW, y0 = ty * WG_TH;
-#pragma unroll
-    for (int k = 0; k < NX; ++k) {                   // x halo tile, 4 channels per thread
-      const int i = tid + 256 * k;
-      const int px = min(i >> 3, (WG_TH + 2) * (WG_TW + 2) - 1), q = i & 7;
-      const int py = px / (WG_TW + 2), pxx = px - py * (WG_TW + 2);
-      const int gy = y0 - 1 + py, gx = x0 - 1 + pxx, c = cib + 4 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-        const size_t pix = ((size_t)nb * p.H + gy) * p.W + gx;
-        if (c < p.C0) v = *reinterpret_cast<const f32x4*>(p.x0 + pix * p.C0 + c);            // (C0 % 4 == 0)
-        else if (c < p.C0 + p.C1) v = *reinterpret_cast<const f32x4*>(p.x1 + pix * p.C1 + (c - p.C0));
-      }
-      rx[k] = v;
-    }
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {                   // g tile
-      const int i = tid + 256 * k;
-      const int px = i >> 3, q = i & 7;
-      const int py = px / WG_TW, pxx = px - py * WG_TW;
-      const int gy = y0 + py, gx = x0 + pxx, c = cob + 4 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy < p.H && gx < p.W) {
-        const float* src = p.g + (((size_t)nb * p.H + gy) * p.W + gx) * p.Cg + c;
-        if (c + 3 < p.Cg) v = *reinterpret_cast<const f32x4*>(src);                          // (Cg % 4 == 0 or a ragged tail)
-        else { if (c < p.Cg) v.x = src[0]; if (c + 1 < p.Cg) v.y = src[1]; if (c + 2 < p.Cg) v.z = src[2]; }
-      }
-      rg[k] = v;
-    }
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int k = 0; k < NX; ++k) {
-      const int i = tid + 256 * k;
-      if (i < (WG_TH + 2) * (WG_TW + 2) * 8) {
-        f32x4 v = rx[k];
-        if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<f32x4*>(sX + (i >> 3) * 32 + 4 * (i & 7)) = v;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-      const int i = tid + 256 * k;
-      *reinterpret_cast<f32x4*>(sG + (i >> 3) * 32 + 4 * (i & 7)) = rg[k];
-    }
-  };
+  WgStager<WG_TW, WG_TH> stg;
+  auto load_tile = [&](int tile) { stg.load(p, tile, tiles_x, tiles_y, cib, cob, tid); };
+  auto store_tile = [&]() { stg.store(p, sX, sG, tid); };
   unsigned long long t_start = 0, t_mfma = 0, t_stage = 0, t_mark = 0, t_real = 0;
   if (p.trace) { t_start = t_mark = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
   if (ks < ntiles) load_tile(ks);
@@ -327,6 +335,172 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) 
       }
     }
   if (p.trace && tid == 0) {          // wave 0's view: start, staging / MFMA cycles of the tile loop, reduction, atomics issued
+    unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
+    tr[0] = t_start; tr[1] = t_stage; tr[2] = t_mfma; tr[3] = t_loop; tr[4] = t_red; tr[5] = __builtin_readcyclecounter();
+    tr[6] = t_real; tr[7] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// The eight tile pairs of one wave and tile: operands transformed in registers, 8 MFMAs per pair (see train_wgrad_wino_kernel).
+template <int PH, int TW>
+__device__ __forceinline__ void wg_wino_tile(const float* xb, const float* gb, f32x16 (&acc)[8], float& bsum) {
+  constexpr int PPR = TW / 4;                        // tile pairs per Winograd-tile row (4 pixels per pair)
+  // (Requesting the raw operands of pair q + 1 before the MFMAs of pair q -- fully unrolled, scheduling barriers -- was measured
+  // and is SLOWER: 256 registers and spills, 148 -> 194 us on the 64 -> 64 layer at 96 x 96.  The compiler's own schedule stays.)
+#pragma unroll 2
+  for (int q = 0; q < 8; ++q) {
+    const float* xq = xb + ((q / PPR) * 2 * (TW + 2) + 4 * (q % PPR)) * 32;     // pair q: Winograd-tile row q / PPR, 4 pixels per pair
+    const float* gq = gb + ((q / PPR) * 2 * TW + 4 * (q % PPR)) * 32;
+    float d[3][4], y[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[i][j] = xq[(i * (TW + 2) + j) * 32];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) y[i][j] = gq[(i * TW + j) * 32];
+    // rows 2 PH, 2 PH + 1 of B^T d:  PH = 0: d0 - d2, d1 + d2 (patch rows 0, 1, 2);  PH = 1: d2 - d1, d1 - d3 (rows 1, 2, 3 = d[0..2])
+    float u[2][4], e[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u[0][j] = PH == 0 ? d[0][j] - d[2][j] : d[1][j] - d[0][j];
+      u[1][j] = PH == 0 ? d[1][j] + d[2][j] : d[0][j] - d[2][j];
+    }
+    // rows 2 PH, 2 PH + 1 of A dY:  PH = 0: y0, y0 + y1;  PH = 1: y0 - y1, -y1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      e[0][j] = PH == 0 ? y[0][j] : y[0][j] - y[1][j];
+      e[1][j] = PH == 0 ? y[0][j] + y[1][j] : -y[1][j];
+    }
+    if (PH == 0) bsum += (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // (u B): u0 - u2, u1 + u2, u2 - u1, u1 - u3;   (e A^T): e0, e0 + e1, e0 - e1, -e1
+      const float v0 = u[i][0] - u[i][2], v1 = u[i][1] + u[i][2], v2 = u[i][2] - u[i][1], v3 = u[i][1] - u[i][3];
+      const float d0 = e[i][0], d1 = e[i][0] + e[i][1], d2 = e[i][0] - e[i][1], d3 = -e[i][1];
+      acc[4 * i + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, d0, acc[4 * i + 0], 0, 0, 0);
+      acc[4 * i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, d1, acc[4 * i + 1], 0, 0, 0);
+      acc[4 * i + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2, d2, acc[4 * i + 2], 0, 0, 0);
+      acc[4 * i + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3, d3, acc[4 * i + 3], 0, 0, 0);
+    }
+  }
+}
+
+// ---- weight gradient in the Winograd domain: F(3x3 weights <- 2x2 output-gradient tiles) ----
+// The trilinear form sum y'_i g_k d_(i+k) that F(2x2,3x3) decomposes for the forward pass (Y = A^T[(G g G^T) . (B^T d B)]A) gives
+// the weight gradient by the same rank-16 decomposition read the other way:
+//     dW = G^T [ sum over tiles (A dY A^T) . (B^T X B) ] G
+// -- 16 products per 2 x 2 output pixels instead of 36, the transforms of both operands are adds.  Per transform position p the
+// sum over tiles is a GEMM M_p[ci][co] = sum_t V_p[ci][t] D_p[co][t] whose K is the TILE axis: v_mfma_f32_32x32x2_f32 with
+// A = 32 input channels x 2 tiles, B = 2 tiles x 32 output channels.  The lane that owns (channel, tile) of an operand is the
+// lane that computes its transform from the raw tiles in LDS, so V and D never exist in memory: 12 + 4 ds_read_b32 and ~30
+// adds feed 8 MFMAs.  Workgroup = 4 rows x 32 pixels of one image = 2 x 16 Winograd tiles; wave (ph, r): transform rows
+// 2 ph, 2 ph + 1 (8 of the 16 positions = 8 accumulators) of the tile row r.  After the tile loop: M G per wave (registers), the two
+// tile rows summed through LDS, G^T across the two position halves through LDS, one atomic per weight and workgroup.
+// Staging, work split and grid exactly as train_wgrad_kernel<TW, 128 / TW>; tiles of 4 x 32, 8 x 16 or 16 x 8 pixels (the launcher
+// takes the one that wastes the fewest columns of the map): always 32 Winograd tiles, the wave's eight pairs lie in 1, 2 or 4
+// Winograd-tile rows.
+template <int TW>
+__global__ __launch_bounds__(256, 2) void train_wgrad_wino_kernel(const WgradArgs p) {
+  constexpr int TH = 128 / TW;
+  static_assert(TW == 32 || TW == 16 || TW == 8, "tile width");
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+  float* const sX = reinterpret_cast<float*>(wg_smem);                       // [(TH+2) x (TW+2) px][32 ci]
+  float* const sG = sX + (TH + 2) * (TW + 2) * 32;                           // [TH x TW px][32 co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int ph = wave & 1, r = wave >> 1;
+  const int nci = (p.ci + 31) / 32, nco = (p.co + 31) / 32;
+  const int blk = blockIdx.x % (nci * nco), ks = blockIdx.x / (nci * nco);
+  const int cib = (blk / nco) * 32, cob = (blk % nco) * 32;
+  const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+  const int ntiles = tiles_x * tiles_y * p.N;
+  f32x16 acc[8];                                      // position (2 ph + i, j) at acc[4 i + j]
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  float bsum = 0.f;
+  WgStager<TW, TH> stg;
+  unsigned long long t_start = 0, t_mfma = 0, t_stage = 0, t_mark = 0, t_real = 0;
+  if (p.trace) { t_start = t_mark = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
+  if (ks < ntiles) stg.load(p, ks, tiles_x, tiles_y, cib, cob, tid);
+  // this lane's Winograd tile of pair q (TW = 32): output pixels (2 r .. 2 r + 1, 2 (2 q + kh) ..), input patch rows 2 r .. 2 r + 3 of the halo tile
+  // (wave r owns the Winograd-tile rows r TH/4 .. of the tile: output rows r TH/2 ..)
+  const float* const xb = sX + ((r * (TH / 2) + ph) * (TW + 2) + 2 * kh) * 32 + li;   // first patch row this wave reads (ph: rows 0-2 / 1-3)
+  const float* const gb = sG + (r * (TH / 2) * TW + 2 * kh) * 32 + li;
+  for (int tile = ks; tile < ntiles; tile += p.ksplit) {
+    __syncthreads();                                 // every wave is done with the previous tile
+    stg.store(p, sX, sG, tid);
+    __syncthreads();
+    if (tile + p.ksplit < ntiles) stg.load(p, tile + p.ksplit, tiles_x, tiles_y, cib, cob, tid);
+    if (p.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_stage += t - t_mark; t_mark = t; }
+    if (ph == 0) wg_wino_tile<0, TW>(xb, gb, acc, bsum);         // (wave-uniform)
+    else wg_wino_tile<1, TW>(xb, gb, acc, bsum);
+    if (p.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_mfma += t - t_mark; t_mark = t; }
+  }
+  const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0;
+  // ---- M G (per wave): R[i][0] = M0 + (M1 + M2)/2, R[i][1] = (M1 - M2)/2, R[i][2] = (M1 + M2)/2 + M3 ----
+  f32x16 R[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float hs = 0.5f * (acc[4 * i + 1][q] + acc[4 * i + 2][q]), hd = 0.5f * (acc[4 * i + 1][q] - acc[4 * i + 2][q]);
+      R[3 * i + 0][q] = acc[4 * i][q] + hs; R[3 * i + 1][q] = hd; R[3 * i + 2][q] = hs + acc[4 * i + 3][q];
+    }
+  const int n = cob + li;
+  bsum += __shfl_xor(bsum, 32);
+  float* const red = reinterpret_cast<float*>(wg_smem);
+  float* const sB = reinterpret_cast<float*>(wg_smem + WG_RED_BYTES);
+  constexpr int TAPF = 16 * 64;
+  __syncthreads();                                   // the tiles are dead
+  if (r == 1) {                                      // the second tile row's sums: 6 x 4 KB per wave, at ph * 24 KB
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) red[((ph * 6 + t) * 16 + q) * 64 + lane] = R[t][q];
+  }
+  if (kh == 0) sB[wave * 32 + li] = ph == 0 ? bsum : 0.f;
+  __syncthreads();
+  if (r == 0) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) R[t][q] += red[((ph * 6 + t) * 16 + q) * 64 + lane];
+  }
+  if (wave == 0 && kh == 0 && p.db != nullptr && cib == 0 && n < p.co)
+    unsafeAtomicAdd(p.db + n, (sB[li] + sB[32 + li]) + (sB[64 + li] + sB[96 + li]));
+  __syncthreads();
+  // ---- G^T across the position halves: dW0 = R0 + R1/2 + R2/2, dW1 = R1/2 - R2/2, dW2 = R1/2 + R2/2 + R3 (rows; R0, R1 in wave
+  // (0,0), R2, R3 in wave (1,0)): wave (1,0) hands over P = R2/2 and Q = R2/2 + R3 ----
+  if (wave == 1) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float half = 0.5f * R[j][q];
+        red[(j * 16 + q) * 64 + lane] = half;
+        red[((3 + j) * 16 + q) * 64 + lane] = half + R[3 + j][q];
+      }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const unsigned long long t_red = p.trace ? __builtin_readcyclecounter() : 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float h1 = 0.5f * R[3 + j][q], P = red[(j * 16 + q) * 64 + lane], Q = red[((3 + j) * 16 + q) * 64 + lane];
+      const float w0 = R[j][q] + h1 + P, w1 = h1 - P, w2 = h1 + Q;
+      const int c = cib + (q & 3) + 8 * (q >> 2) + 4 * kh;
+      if (c < p.ci && n < p.co) {
+        unsafeAtomicAdd(p.dw + ((size_t)(0 + j) * p.ci + c) * p.co + n, w0);
+        unsafeAtomicAdd(p.dw + ((size_t)(3 + j) * p.ci + c) * p.co + n, w1);
+        unsafeAtomicAdd(p.dw + ((size_t)(6 + j) * p.ci + c) * p.co + n, w2);
+      }
+    }
+  if (p.trace && tid == 0) {
     unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
     tr[0] = t_start; tr[1] = t_stage; tr[2] = t_mfma; tr[3] = t_loop; tr[4] = t_red; tr[5] = __builtin_readcyclecounter();
     tr[6] = t_real; tr[7] = __builtin_amdgcn_s_memrealtime();

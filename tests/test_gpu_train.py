@@ -40,6 +40,9 @@ def _rel(a, b):
     # the small maps of the U-Net's lower levels (each picks another tile geometry of the weight-gradient kernel)
     (5, 3, 3, 64, 0, 64, 64, 64, 1), (3, 6, 6, 32, 32, 64, 32, 32, 0), (2, 12, 12, 64, 0, 64, 64, 64, 1), (1, 48, 48, 32, 0, 32, 64, 64, 0),
     (2, 5, 24, 32, 0, 32, 32, 32, 0),
+    # the Winograd-domain kernel (W >= 24 with at most a quarter of the 32-pixel tile columns wasted): odd sizes, concat input, relu
+    (2, 13, 30, 64, 0, 64, 64, 64, 1), (1, 7, 61, 32, 32, 64, 32, 32, 0), (2, 96, 96, 64, 0, 64, 64, 64, 1), (1, 3, 24, 32, 0, 32, 96, 96, 0),
+    (2, 16, 8, 64, 0, 64, 32, 32, 1), (1, 30, 40, 32, 32, 64, 64, 64, 0), (3, 24, 24, 64, 0, 64, 64, 64, 1), (1, 17, 47, 64, 0, 40, 64, 64, 0),
     # the 3- / 6-channel heads (vector-ALU kernel: ragged widths, one-row images, relu on load, fewer real input channels than 64)
     (2, 20, 37, 64, 0, 64, 3, 16, 1), (3, 1, 9, 64, 0, 64, 6, 16, 0), (1, 33, 8, 64, 0, 40, 3, 16, 0), (40, 7, 19, 64, 0, 64, 6, 16, 1)])
 def test_wgrad_bgrad_dgrad_vs_autograd(env, n, h, w, c0, c1, ci, co, cg, relu_in):
