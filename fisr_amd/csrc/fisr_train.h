@@ -135,8 +135,9 @@ static int wgrad_impl(const float* x0, int c0, const float* x1, int c1, int relu
   bool wino = false;
   if (ci >= 32 && co >= 32) {
     double best = 0.0;
-    for (int tw : {32, 16, 8}) {
-      const int th = 128 / tw;
+    static const WgradTile wcand[] = {{32, 4}, {16, 8}, {8, 16}, {8, 8}};            // larger tiles first: ties go to them
+    for (const WgradTile& c : wcand) {
+      const int tw = c.tw, th = c.th;
       const double eff = ((double)w / (((w + tw - 1) / tw) * tw)) * ((double)h / (((h + th - 1) / th) * th));
       if (eff > best + 1e-9) { best = eff; tl.tw = tw; tl.th = th; }
     }
@@ -149,16 +150,17 @@ static int wgrad_impl(const float* x0, int c0, const float* x1, int c1, int relu
 #endif
 #define FISR_WGRAD_CASE(TW, TH, S) if (tl.tw == TW && tl.th == TH) { kern = train_wgrad_kernel<TW, TH>; slot = S; }
   if (wino) {
-    if (tl.tw == 32) { kern = train_wgrad_wino_kernel<32>; slot = 6; }
-    else if (tl.tw == 16) { kern = train_wgrad_wino_kernel<16>; slot = 7; }
-    else { kern = train_wgrad_wino_kernel<8>; slot = 8; }
+    if (tl.tw == 32) { kern = train_wgrad_wino_kernel<32, 4>; slot = 6; }
+    else if (tl.tw == 16) { kern = train_wgrad_wino_kernel<16, 8>; slot = 7; }
+    else if (tl.th == 16) { kern = train_wgrad_wino_kernel<8, 16>; slot = 8; }
+    else { kern = train_wgrad_wino_kernel<8, 8>; slot = 9; }
   } else {
   FISR_WGRAD_CASE(32, 4, 0) FISR_WGRAD_CASE(16, 8, 1) FISR_WGRAD_CASE(16, 4, 2)
   FISR_WGRAD_CASE(8, 16, 3) FISR_WGRAD_CASE(8, 8, 4) FISR_WGRAD_CASE(8, 4, 5)
   }
 #undef FISR_WGRAD_CASE
   if (!kern) return fail(nullptr, FISR_EINVAL, "fisr_train_wgrad: no kernel for the tile");
-  static bool attr_done[64][9] = {};
+  static bool attr_done[64][10] = {};
   int dev = 0; (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_done[dev][slot]) {
     HIP_OK(nullptr, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

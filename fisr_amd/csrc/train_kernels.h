@@ -342,13 +342,13 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) 
 }
 
 // The eight tile pairs of one wave and tile: operands transformed in registers, 8 MFMAs per pair (see train_wgrad_wino_kernel).
-template <int PH, int TW>
+template <int PH, int TW, int NPAIR>
 __device__ __forceinline__ void wg_wino_tile(const float* xb, const float* gb, f32x16 (&acc)[8], float& bsum) {
   constexpr int PPR = TW / 4;                        // tile pairs per Winograd-tile row (4 pixels per pair)
   // (Requesting the raw operands of pair q + 1 before the MFMAs of pair q -- fully unrolled, scheduling barriers -- was measured
   // and is SLOWER: 256 registers and spills, 148 -> 194 us on the 64 -> 64 layer at 96 x 96.  The compiler's own schedule stays.)
 #pragma unroll 2
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < NPAIR; ++q) {
     const float* xq = xb + ((q / PPR) * 2 * (TW + 2) + 4 * (q % PPR)) * 32;     // pair q: Winograd-tile row q / PPR, 4 pixels per pair
     const float* gq = gb + ((q / PPR) * 2 * TW + 4 * (q % PPR)) * 32;
     float d[3][4], y[2][2];
@@ -398,13 +398,13 @@ __device__ __forceinline__ void wg_wino_tile(const float* xb, const float* gb, f
 // adds feed 8 MFMAs.  Workgroup = 4 rows x 32 pixels of one image = 2 x 16 Winograd tiles; wave (ph, r): transform rows
 // 2 ph, 2 ph + 1 (8 of the 16 positions = 8 accumulators) of the tile row r.  After the tile loop: M G per wave (registers), the two
 // tile rows summed through LDS, G^T across the two position halves through LDS, one atomic per weight and workgroup.
-// Staging, work split and grid exactly as train_wgrad_kernel<TW, 128 / TW>; tiles of 4 x 32, 8 x 16 or 16 x 8 pixels (the launcher
-// takes the one that wastes the fewest columns of the map): always 32 Winograd tiles, the wave's eight pairs lie in 1, 2 or 4
+// Staging, work split and grid exactly as train_wgrad_kernel<TW, TH>; tiles of 4 x 32, 8 x 16, 16 x 8 or 8 x 8 pixels (the launcher
+// takes the one that wastes the fewest pixels of the map): 32 (16) Winograd tiles, the wave's eight (four) pairs lie in 1, 2 or 4
 // Winograd-tile rows.
-template <int TW>
+template <int TW, int TH>
 __global__ __launch_bounds__(256, 2) void train_wgrad_wino_kernel(const WgradArgs p) {
-  constexpr int TH = 128 / TW;
-  static_assert(TW == 32 || TW == 16 || TW == 8, "tile width");
+  static_assert((TW == 32 && TH == 4) || (TW == 16 && TH == 8) || (TW == 8 && TH == 16) || (TW == 8 && TH == 8), "tile geometry");
+  constexpr int NPAIR = TW * TH / 16;                // tile pairs per wave and tile
   extern __shared__ __attribute__((aligned(16))) char wg_smem[];
   float* const sX = reinterpret_cast<float*>(wg_smem);                       // [(TH+2) x (TW+2) px][32 ci]
   float* const sG = sX + (TH + 2) * (TW + 2) * 32;                           // [TH x TW px][32 co]
@@ -435,8 +435,8 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_wino_kernel(const WgradArg
     __syncthreads();
     if (tile + p.ksplit < ntiles) stg.load(p, tile + p.ksplit, tiles_x, tiles_y, cib, cob, tid);
     if (p.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_stage += t - t_mark; t_mark = t; }
-    if (ph == 0) wg_wino_tile<0, TW>(xb, gb, acc, bsum);         // (wave-uniform)
-    else wg_wino_tile<1, TW>(xb, gb, acc, bsum);
+    if (ph == 0) wg_wino_tile<0, TW, NPAIR>(xb, gb, acc, bsum);  // (wave-uniform)
+    else wg_wino_tile<1, TW, NPAIR>(xb, gb, acc, bsum);
     if (p.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_mfma += t - t_mark; t_mark = t; }
   }
   const unsigned long long t_loop = p.trace ? __builtin_readcyclecounter() : 0;
