@@ -6,6 +6,9 @@ MIOpen: a measuring stick, not the product), with fp16 rounding injected where a
   trunk     like mixed, but the convs of the exact region take fp16 OPERANDS (activations and weights rounded on load)
             and only the residual trunk / skip tensors stay exact; res-block intermediates are stored in fp16
   trunk_full  `trunk` at full resolution only, half resolution all-fp16
+  hi_w16    like mixed, but the exact region's WEIGHTS are rounded to fp16 (activations exact)
+  hi_a16    like mixed, but the exact region's conv ACTIVATION operands are rounded to fp16 on load (weights exact; storage exact)
+  hi_a16s   like hi_a16 and every tensor of the region is also STORED in fp16 (fp16 activations end to end, exact weights)
 Prints the PSNR shift of the SR / FI channels per plan (protocol of SURVEY.md 8c-ii: pseudo ground truth at the reference's
 published PSNRs).  python scripts/precision_plan_probe.py [h] [w] [n]"""
 import os, sys
@@ -29,17 +32,22 @@ class Plan:
         if self.name == "fp16": return False
         reg = HI_FULL if self.name in ("trunk_full", "mixed_full") else HI
         return any(lname.startswith(p) for p in reg)
-    def operands16(self, lname):        # conv reads fp16 operands (activations + weights)
-        return not self.hi(lname) or self.name in ("trunk", "trunk_full")
+    def operands16(self, lname):        # conv reads fp16 operands: (activations, weights)
+        if not self.hi(lname) or self.name in ("trunk", "trunk_full"): return (True, True)
+        if self.name == "hi_w16": return (False, True)
+        if self.name in ("hi_a16", "hi_a16s"): return (True, False)
+        return (False, False)
     def store(self, t, lname, kind):    # kind: "trunk" (residual stream, skips, level outputs) or "mid" (consumed by one conv)
         if self.name == "fp32": return t
-        if not self.hi(lname): return q16(t)
+        if not self.hi(lname) or self.name == "hi_a16s": return q16(t)
         if self.name in ("trunk", "trunk_full") and kind == "mid": return q16(t)
         return t
 
 def conv(x, W, name, P):
     w, b = W[name + "/w"], W[name + "/b"]
-    if P.operands16(name): x, w = q16(x), q16(w)
+    a16, w16 = P.operands16(name)
+    if a16: x = q16(x)
+    if w16: w = q16(w)
     return F.conv2d(x, w, b, padding=1)
 
 def res_block(x, W, name, P, relu_after=False):
@@ -110,7 +118,7 @@ for ws in ("default", "survey_spec", "harsh"):
     for seed in (12, 13):
         x = torch.from_numpy(make_full_size_input(seed, h, w, n)).permute(0, 3, 1, 2).contiguous().to(dev)
         ref = forward(x, W, Plan("fp32")).clamp(0, 1)
-        for plan in ("fp16", "mixed", "mixed_full", "trunk", "trunk_full"):
+        for plan in ("fp16", "mixed", "mixed_full", "trunk", "hi_w16", "hi_a16", "hi_a16s"):
             e = forward(x, W, Plan(plan)).clamp(0, 1) - ref
             sr = float((e[:, 3:6] ** 2).mean().sqrt()); fi = float((torch.cat([e[:, 0:3], e[:, 6:9]], 1) ** 2).mean().sqrt())
             print(f"{ws:12s} seed {seed} {plan:11s} SR rms {sr:.2e} dPSNR {psnr_shift(sr, 48.07):.4f} dB   FI rms {fi:.2e} dPSNR {psnr_shift(fi, 37.86):.4f} dB", flush=True)
