@@ -290,9 +290,14 @@ typedef struct fisr_train_pack_desc {
   int ci, co;
 } fisr_train_pack_desc;
 int fisr_train_pack_all(const fisr_train_pack_desc* d_descs, int n, void* stream);
-int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed, const float* d_bias,
-                       int cout, const float* res, float* out, int n, int h, int w, int flags, int out_cstride,
-                       int out_coff, int out_split, int out_gap, const void* d_packed_wino /* nullable */, void* stream);
+/* d_packed_wino (nullable): the slabs of fisr_train_pack_wino; the call then runs the Winograd kernel and d_packed may be
+ * NULL.  d_bias must be readable up to the N block's padding (cout rounded up to 64; 16 for the heads).
+ * fisr_train_wgrad picks its kernel by shape: the Winograd-domain weight gradient where a 4x32 / 8x16 / 16x8 / 8x8-pixel
+ * tile covers the map to >= 75 %, the direct pixel-axis GEMM otherwise, a vector-ALU kernel for co <= 8 (the heads). */
+int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed /* nullable, see above */,
+                       const float* d_bias, int cout, const float* res, float* out, int n, int h, int w, int flags,
+                       int out_cstride, int out_coff, int out_split, int out_gap, const void* d_packed_wino /* nullable */,
+                       void* stream);
 int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw,
                      float* db /* nullable */, int ci, int co, int n, int h, int w, void* stream);
 int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream);
