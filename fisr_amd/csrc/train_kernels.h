@@ -152,6 +152,14 @@ inline WgradTile wgrad_tile(int h, int w) {
   return best;
 }
 
+// Workgroup b runs on XCD b % 8 (observed; speed only).  The (ci block, co block) workgroups of one pixel-tile sequence read the
+// same x and g tiles: give every XCD a contiguous range of the virtual ids so that they share that XCD's L2 instead of
+// fetching the tiles once per XCD.
+__device__ __forceinline__ int wg_xcd_order(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 // Register staging of one pixel tile of the weight-gradient kernels: halo tile of x (TH+2 x TW+2 pixels, 32 input channels from
 // cib on, zero outside the image and behind the last channel) and tile of g (TH x TW pixels, 32 output channels from cob on).
 template <int WG_TW, int WG_TH> struct WgStager {
@@ -232,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_kernel(const WgradArgs p) 
   float* const sG = sX + (WG_TH + 2) * (WG_TW + 2) * 32;                     // [TH x TW px][32 co]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int nci = (p.ci + 31) / 32, nco = (p.co + 31) / 32;
-  const int blk = blockIdx.x % (nci * nco), ks = blockIdx.x / (nci * nco);
+  const int vid = wg_xcd_order(blockIdx.x, gridDim.x);
+  const int blk = vid % (nci * nco), ks = vid / (nci * nco);
   const int cib = (blk / nco) * 32, cob = (blk % nco) * 32;
   const int tiles_x = (p.W + WG_TW - 1) / WG_TW, tiles_y = (p.H + WG_TH - 1) / WG_TH;
   const int ntiles = tiles_x * tiles_y * p.N;
@@ -347,7 +356,13 @@ __device__ __forceinline__ void wg_wino_tile(const float* xb, const float* gb, f
   constexpr int PPR = TW / 4;                        // tile pairs per Winograd-tile row (4 pixels per pair)
   // (Requesting the raw operands of pair q + 1 before the MFMAs of pair q -- fully unrolled, scheduling barriers -- was measured
   // and is SLOWER: 256 registers and spills, 148 -> 194 us on the 64 -> 64 layer at 96 x 96.  The compiler's own schedule stays.)
+#if defined(FISR_WW_UNROLL) && FISR_WW_UNROLL == 1
+#pragma unroll 1
+#elif defined(FISR_WW_UNROLL) && FISR_WW_UNROLL == 4
+#pragma unroll 4
+#else
 #pragma unroll 2
+#endif
   for (int q = 0; q < NPAIR; ++q) {
     const float* xq = xb + ((q / PPR) * 2 * (TW + 2) + 4 * (q % PPR)) * 32;     // pair q: Winograd-tile row q / PPR, 4 pixels per pair
     const float* gq = gb + ((q / PPR) * 2 * TW + 4 * (q % PPR)) * 32;
@@ -411,7 +426,8 @@ __global__ __launch_bounds__(256, 2) void train_wgrad_wino_kernel(const WgradArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int ph = wave & 1, r = wave >> 1;
   const int nci = (p.ci + 31) / 32, nco = (p.co + 31) / 32;
-  const int blk = blockIdx.x % (nci * nco), ks = blockIdx.x / (nci * nco);
+  const int vid = wg_xcd_order(blockIdx.x, gridDim.x);
+  const int blk = vid % (nci * nco), ks = vid / (nci * nco);
   const int cib = (blk / nco) * 32, cob = (blk % nco) * 32;
   const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
   const int ntiles = tiles_x * tiles_y * p.N;
