@@ -29,6 +29,7 @@
 #endif
 #include "conv3x3.h"
 #include "conv3x3_wino8p.h"
+#include "conv3x3_wf4.h"
 #include "conv3x3_dma.h"
 #ifdef FISR_DIAG
 #include "diag/conv3x3_wino4.h"
@@ -53,6 +54,7 @@ struct ConvW {
   int cin_pad = 0, cout_pad = 0, nt = 2;
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino_common.h), else NULL
+  void* d_wu4 = nullptr;  // FISR_PREC_F32W4: U = G g G^T of F(4x4,3x3) in the LDS image of conv3x3_wf4.h, else NULL
   float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][4 | 6] for the vector-ALU head kernel (head_conv.h), else NULL
   void* d_wd = nullptr;   // FISR_PREC_F16, Cout > 32: the weight slabs of the LDS-DMA kernel (conv3x3_dma.h), else NULL
   int cout_pad_d = 0;     // ... and its Cout padded to the 64-channel block
@@ -70,7 +72,8 @@ struct ProfEntry {
 struct fisr_ctx {
   int dev = 0;
   int precision = -1;
-  bool wino = false;      // FISR_PREC_F32W: eligible convs run the Winograd F(2x2,3x3) kernel
+  bool wino = false;      // FISR_PREC_F32W / F32W4: eligible convs run the Winograd F(2x2,3x3) kernel
+  bool wf4 = false;       // FISR_PREC_F32W4: ... and those conv3x3_wf4.h takes (wf4_wins) the F(4x4,3x3) kernel
   bool finalized = false;
   std::map<std::string, ConvW> convs;  // keyed by conv name (without /w, /b)
   std::string err;
@@ -183,14 +186,14 @@ template <> struct PrecName<fsplit> { static const char* get() { return "f16f8";
 // call f(T()) with the activation type of `precision`
 template <typename F>
 auto with_prec(int precision, F&& f) {
-  if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W) return f(float());
+  if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4) return f(float());
   if (precision == FISR_PREC_F16 || precision == FISR_PREC_F16R) return f(_Float16());
   if (precision == FISR_PREC_F16F8) return f(fsplit());
   return f(bsplit());
 }
 inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
-         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W || precision == FISR_PREC_F16R;
+         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W || precision == FISR_PREC_F16R || precision == FISR_PREC_F32W4;
 }
 // FISR_PREC_MIXED: which layers keep a split-precision arithmetic (f16f8) -- everything that works at the full and at
 // the half resolution of level 3 (its first two encoder levels, its last two decoder levels, both heads: 55 % of the
@@ -228,7 +231,8 @@ inline uint8_t host_fp8_e4m3(float f) {
   return sign | (uint8_t)(((ex + 7) << 3) | ((int)r - 8));
 }
 inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 || precision == FISR_PREC_F16R ? 32 : 16; }
-inline int prec_unit(int precision) { return precision == FISR_PREC_F32 || precision == FISR_PREC_F32W ? 4 : 8; }   // glue kernels: channels per 16 bytes
+inline bool prec_f32w(int precision) { return precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4; }   // fp32 tensors, Winograd engines
+inline int prec_unit(int precision) { return precision == FISR_PREC_F32 || prec_f32w(precision) ? 4 : 8; }   // glue kernels: channels per 16 bytes
 constexpr int CONV_REC = 16;   // the conv kernel stores whole 16-channel records
 
 // host bf16 round-to-nearest-even (finite inputs)
@@ -322,6 +326,39 @@ void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<
     }
 }
 
+// Winograd F(4x4,3x3) weights (conv3x3_wf4.h): U = G g G^T per (ci, co) with the 6x3 G of the interpolation points 0, +-1, +-2, inf,
+// computed in double and rounded once to fp32, stored as the kernel's LDS image
+// [Cin/4][CoutPad/64][position quad 9][channel quarter 4][ci 4][channel 16][4 positions].
+void pack_weights_wf4(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
+  static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const int nb = (co + F4_BN - 1) / F4_BN, nch = cin_pad / F4_CH;
+  wp.assign((size_t)nch * nb * F4_U_BYTES, 0);
+  for (int c = 0; c < ci; ++c)
+    for (int n = 0; n < co; ++n) {
+      double g[3][3], t[6][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) g[a][b] = w[((size_t)(a * 3 + b) * ci + c) * co + n];
+      for (int i = 0; i < 6; ++i)
+        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+      const int kc = c / F4_CH, k = c % F4_CH, blk = n / F4_BN, q = (n % F4_BN) / 16, r = n % 16;
+      float* slab = reinterpret_cast<float*>(wp.data() + ((size_t)kc * nb + blk) * F4_U_BYTES);
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+          const int pos = i * 6 + j;
+          slab[(((pos >> 2) * 4 + q) * 64 + k * 16 + r) * 4 + (pos & 3)] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+    }
+}
+// what conv3x3_wf4.h takes: whole 64-channel output blocks, whole 4-channel chunks per concat source, images addressed with
+// 31-bit byte offsets (the out-of-range marker of its zero padding is 2^31)
+inline bool wf4_fits(int h, int w, int c0, int c1, int co) {
+  return co % F4_BN == 0 && c0 > 0 && c0 % F4_CH == 0 && c1 % F4_CH == 0 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
+}
+// ... and where it is the faster of the two Winograd kernels (measured per map size, scripts/conv_bench.py): its 16 x 32-pixel
+// items waste more of a small map than the 8 x 32 ones of conv3x3_wino8p.h
+inline bool wf4_wins(int h, int w) { return h >= 48 && w >= 64; }
+
 // fp16 weights for the LDS-DMA kernel (conv3x3_dma.h): [Cin/16][CoutPad/64][tap 9][row 64][32-byte record] -- a slab is the
 // kernel's LDS image: rows in the MFMA row order of pack_weights, the two 16-byte halves (channels 0-7 | 8-15 of the chunk)
 // swapped when bit 3 of the row is set.
@@ -358,7 +395,7 @@ template <typename T> inline int nt_for(int co) {
 }
 
 template <typename T>
-int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false) {
+int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, bool wf4 = false) {
   constexpr int CC = Prec<T>::CC;
   cw.nt = nt_for<T>(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
@@ -384,6 +421,12 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false) {
     pack_weights_wino(cw.w.data(), cw.ci, cw.co, cw.cin_pad, wp);
     HIP_OK(ctx, hipMalloc(&cw.d_wu, wp.size()));
     HIP_OK(ctx, hipMemcpy(cw.d_wu, wp.data(), wp.size(), hipMemcpyHostToDevice));
+  }
+  if (cw.d_wu4) { (void)hipFree(cw.d_wu4); cw.d_wu4 = nullptr; }
+  if (wf4 && std::is_same<T, float>::value && cw.co % F4_BN == 0 && cw.cin_pad % F4_CH == 0) {
+    pack_weights_wf4(cw.w.data(), cw.ci, cw.co, cw.cin_pad, wp);
+    HIP_OK(ctx, hipMalloc(&cw.d_wu4, wp.size()));
+    HIP_OK(ctx, hipMemcpy(cw.d_wu4, wp.data(), wp.size(), hipMemcpyHostToDevice));
   }
   if (cw.d_wd) { (void)hipFree(cw.d_wd); cw.d_wd = nullptr; }
   if (dma && std::is_same<T, _Float16>::value && cw.co > 32) {
@@ -538,6 +581,35 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   } else if (a.relu_in) FISR_W8P_LAUNCH(true, false);
   else FISR_W8P_LAUNCH(false, false);
 #undef FISR_W8P_LAUNCH
+  return hipGetLastError();
+}
+
+// The F(4x4,3x3) Winograd kernel (conv3x3_wf4.h; fp32, FISRnet's dense layers only; a.wpk = the conv's d_wu4).
+hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
+  static bool attr_done[64] = {};
+  constexpr size_t lds = wf4_lds_bytes();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    const void* kerns[] = {reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true>),
+                           reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, true>)};
+    for (const void* k : kerns) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    attr_done[dev] = true;
+  }
+  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && a.dil == 1;
+  if (!plain || !wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s) || a.CoutPad != a.Cout) return hipErrorInvalidValue;
+  const int items = ((a.W + F4_TW - 1) / F4_TW) * ((a.H + F4_TH - 1) / F4_TH) * a.N * (a.CoutPad / F4_BN);
+  if (a.relu_in) {
+    if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<true, true>), dim3(items), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_wf4_kernel<true, false>), dim3(items), dim3(512), lds, st, a);
+  } else {
+    if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true>), dim3(items), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false>), dim3(items), dim3(512), lds, st, a);
+  }
   return hipGetLastError();
 }
 
@@ -716,11 +788,14 @@ struct Runner {
     const double px = (double)n * h * w;
     const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
+    const bool use_wf4 = std::is_same<T, float>::value && ctx->wf4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cw.co) && wf4_wins(h, w);
+    if (use_wf4) a.wpk = cw.d_wu4;
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     const bool use_dma = std::is_same<T, _Float16>::value && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
     if (use_dma) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
     char cls[96];
     if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
+    else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
@@ -733,6 +808,7 @@ struct Runner {
     ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
                  px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
     check(use_dma ? launch_conv_dma(a, st)
+                  : use_wf4 ? launch_conv_wf4(a, st)
                   : use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
   }
 
@@ -1003,6 +1079,7 @@ void fisr_destroy(fisr_ctx* ctx) {
     if (kv.second.d_w) (void)hipFree(kv.second.d_w);
     if (kv.second.d_b) (void)hipFree(kv.second.d_b);
     if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
+    if (kv.second.d_wu4) (void)hipFree(kv.second.d_wu4);
     if (kv.second.d_wh) (void)hipFree(kv.second.d_wh);
     if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
   }
@@ -1057,11 +1134,12 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
     const int lp = layer_prec(precision, kv.first);
-    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, lp == FISR_PREC_F32W, lp == FISR_PREC_F16); });
+    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, prec_f32w(lp), lp == FISR_PREC_F16, lp == FISR_PREC_F32W4); });
     if (rc) return rc;
     kv.second.prec = lp;
   }
-  ctx->wino = precision == FISR_PREC_F32W;
+  ctx->wino = prec_f32w(precision);
+  ctx->wf4 = precision == FISR_PREC_F32W4;
   ctx->precision = precision;
   ctx->finalized = true;
   return 0;
@@ -1239,7 +1317,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   const int cc = prec_chunk(precision);
   if (cout % CONV_REC) {
     // partial 16-channel records only exist on the fp32-output heads (channel-scatter store, no residual)
-    if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W) out_f32 = 1;
+    if (precision == FISR_PREC_F32 || prec_f32w(precision)) out_f32 = 1;
     if (!out_f32) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: cout must be a multiple of 16 unless out_f32");
   }
   if (out_f32 && (res || (flags & FISR_CONV_D2S)))
@@ -1255,12 +1333,14 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
   cw.b.assign(b_host, b_host + cout);
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W, precision == FISR_PREC_F16); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), precision == FISR_PREC_F16, precision == FISR_PREC_F32W4); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cout);
+  // (FISR_PREC_F32W4 at op level: the F(4x4) kernel for every shape it takes -- the engine adds its map-size rule, wf4_wins)
+  const bool use_wf4 = precision == FISR_PREC_F32W4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cout) && !(res && (flags & FISR_CONV_D2S));
+  const bool use_wino = !use_wf4 && prec_f32w(precision) && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cout);
   const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wpk = use_dma ? cw.d_wd : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
+  a.in0 = in0; a.in1 = in1; a.wpk = use_dma ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
@@ -1270,8 +1350,9 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
   // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)
-  const bool use_head = precision == FISR_PREC_F32W && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
+  const bool use_head = prec_f32w(precision) && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
   hipError_t e = use_dma ? launch_conv_dma(a, st)
+                 : use_wf4 ? launch_conv_wf4(a, st)
                  : use_wino ? launch_conv_wino(a, st)
                  : use_head ? launch_head_valu(a, cw.d_wh, st)
                             : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
@@ -1279,6 +1360,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   (void)hipFree(cw.d_w);
   (void)hipFree(cw.d_b);
   if (cw.d_wu) (void)hipFree(cw.d_wu);
+  if (cw.d_wu4) (void)hipFree(cw.d_wu4);
   if (cw.d_wh) (void)hipFree(cw.d_wh);
   if (cw.d_wd) (void)hipFree(cw.d_wd);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
@@ -1334,9 +1416,10 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   cw.b.assign(cout, 0.01f);
   uint32_t st = 12345u;
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, precision == FISR_PREC_F32W, precision == FISR_PREC_F16); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), precision == FISR_PREC_F16, precision == FISR_PREC_F32W4); });
   if (rc) return rc;
-  const bool use_wino = precision == FISR_PREC_F32W && cw.d_wu && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
+  const bool use_wf4 = precision == FISR_PREC_F32W4 && cw.d_wu4 && wf4_fits(h, w, cin, 0, cout) && !(with_res && (flags & FISR_CONV_D2S));
+  const bool use_wino = !use_wf4 && prec_f32w(precision) && cw.d_wu && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
   const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && dma_fits(h, w, cin, 0, cin, 0);
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
@@ -1354,7 +1437,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
         HIP_OK(nullptr, hipMemcpy((char*)d_res + o, hbuf.data(), std::min(hbuf.size() * 2, out_b - o), hipMemcpyHostToDevice));
   }
   ConvArgs a;
-  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma ? cw.d_wd : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
+  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
   a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
@@ -1364,6 +1447,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   unsigned long long* d_trace = nullptr;
   const size_t nblocks = use_dma ? (size_t)(((w + D_TW - 1) / D_TW) * ((h + D_TH - 1) / D_TH) * n) * (cw.cout_pad_d / D_BN)
+                         : use_wf4 ? (size_t)(((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n) * (cw.cout_pad / F4_BN)
                                  : (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
                                        (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
   if (trace_file) {
@@ -1377,6 +1461,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   hipError_t e = hipSuccess;
   auto launch = [&]() -> hipError_t {
     if (use_dma) return launch_conv_dma(a, nullptr);
+    if (use_wf4) return launch_conv_wf4(a, nullptr);
     if (use_wino) return launch_conv_wino(a, nullptr);
     return with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
   };
@@ -1397,7 +1482,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
-  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wh) (void)hipFree(cw.d_wh); if (cw.d_wd) (void)hipFree(cw.d_wd);
+  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wu4) (void)hipFree(cw.d_wu4); if (cw.d_wh) (void)hipFree(cw.d_wh); if (cw.d_wd) (void)hipFree(cw.d_wd);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
   return 0;
 }

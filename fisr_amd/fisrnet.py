@@ -32,7 +32,7 @@ from .lib import FisrError
 # Cout % 64 == 0 (what cuDNN does for the reference's TF 1.13) -- "fp32w" names it explicitly; "fp32d" is the same
 # engine with the direct (exact fmaf-chain) MFMA kernel for every conv.
 _PREC = {"fp32": _lib.PREC_F32W, "f32": _lib.PREC_F32W, "float32": _lib.PREC_F32W, "fp32w": _lib.PREC_F32W,
-         "fp32d": _lib.PREC_F32,
+         "fp32d": _lib.PREC_F32, "fp32w4": _lib.PREC_F32W4,      # F(4x4,3x3) Winograd for the large maps (conv3x3_wf4.h)
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
          "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8, "mixed": _lib.PREC_MIXED,
          "fp16r": _lib.PREC_F16R, "mixedr": _lib.PREC_MIXEDR}          # round 1's register-staged fp16 kernel (A/B runs)

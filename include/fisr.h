@@ -70,7 +70,12 @@ enum {
   FISR_PREC_F16R = 6,  /* FISR_PREC_F16 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h);
                           FISR_PREC_F16 itself runs the convolutions with Cout > 32 on the LDS-DMA kernel (conv3x3_dma.h: same
                           products, another summation order inside a chunk -> results agree to fp32 rounding).  For A/B runs. */
-  FISR_PREC_MIXEDR = 7 /* engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
+  FISR_PREC_MIXEDR = 7, /* engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
+  FISR_PREC_F32W4 = 8  /* fp32 activations/weights and arithmetic like FISR_PREC_F32W, with Winograd F(4x4,3x3) (conv3x3_wf4.h: 36
+                          multiplies per 4x4 outputs on v_mfma_f32_16x16x4_f32, a quarter of the direct algorithm's) for the
+                          convolutions with Cout % 64 == 0 on maps of at least 48 x 64 pixels (op level: on every map); smaller maps
+                          and the rest as in FISR_PREC_F32W.  The F(4,3) transforms are worse conditioned: ~1e-5 instead of ~1e-6
+                          per convolution against float64 -- the accuracy class of FISR_PREC_BF16X3, still fp32 tensors. */
 };
 
 /* flags of fisr_op_conv3x3 */

@@ -80,13 +80,13 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
 
 
-PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}
+PREC_ID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4, "fp32w4": 8}
 
 
 def to_dev(x, prec):
     """numpy float32 [N,H,W,C] -> device tensor in the activation format of `prec`."""
     x = np.ascontiguousarray(x, np.float32)
-    if prec in ("fp32", "fp32w"):
+    if prec in ("fp32", "fp32w", "fp32w4"):
         return torch.from_numpy(x).cuda()
     if prec == "fp16":
         return torch.from_numpy(x).cuda().half().contiguous()
@@ -96,7 +96,7 @@ def to_dev(x, prec):
 
 
 def from_dev(t, prec, shape):
-    if prec in ("fp32", "fp32w"):
+    if prec in ("fp32", "fp32w", "fp32w4"):
         return t.cpu().numpy().reshape(shape)
     if prec == "fp16":
         return t.float().cpu().numpy().reshape(shape)
@@ -107,7 +107,7 @@ def from_dev(t, prec, shape):
 
 
 def empty_dev(shape, prec):
-    if prec in ("fp32", "fp32w"):
+    if prec in ("fp32", "fp32w", "fp32w4"):
         return torch.full(shape, float("nan"), dtype=torch.float32, device="cuda")
     if prec == "fp16":
         return torch.full(shape, float("nan"), dtype=torch.float16, device="cuda")
@@ -244,6 +244,59 @@ def test_conv3x3_fp32_winograd_residual_in_place(dev):
                                  ctypes.c_void_p(dr.data_ptr()), ctypes.c_void_p(dr.data_ptr()), n, h, w, 0, 4, 0, _stream()))
     torch.cuda.synchronize()
     _report(dr.cpu().numpy(), ref_conv(x, wt, b, None, r, 0), 4 * F32_OP_TOL, "winograd in-place residual")
+
+
+@pytest.mark.parametrize("shape", [
+    # n, h, w, c0, c1, cout, flags, use_res
+    (1, 16, 32, 16, 0, 64, 0, False),           # exactly one 16 x 32 work item, four 4-channel chunks
+    (1, 32, 64, 32, 0, 64, 3, True),            # relu in/out + residual, 2 x 2 items
+    (2, 24, 24, 64, 0, 128, 1, False),          # batch 2, ragged on both axes, two N blocks
+    (1, 3, 3, 32, 0, 64, 0, False),             # a map smaller than one 4 x 4 tile row
+    (1, 12, 12, 128, 0, 256, 2, False),
+    (1, 17, 45, 16, 0, 64, 0, False),           # odd sizes: partly filled 4 x 4 output tiles
+    (1, 16, 40, 64, 64, 64, 0, False),          # dual-source concat (decoder conv/0)
+    (1, 20, 40, 64, 128, 64, 1, False),         # concat with different widths of the two sources
+    (1, 8, 32, 64, 0, 256, 7, False),           # relu, relu, depth_to_space store (heads conv/1)
+    (1, 10, 33, 64, 0, 256, 6, False),          # d2s with ragged tile
+    (1, 8, 32, 48, 0, 64, 0, False),            # level-2/3 first conv (38 -> pad 48)
+    (1, 8, 8, 512, 0, 512, 0, True),            # bottleneck shape, 128 chunks
+    (3, 40, 100, 64, 0, 64, 3, True),           # many items: the XCD-aware work order covers every item once
+])
+def test_conv3x3_fp32_winograd_f4_vs_oracle(dev, shape):
+    """FISR_PREC_F32W4: Winograd F(4x4,3x3) in fp32 (conv3x3_wf4.h) against the fp64 direct oracle.  The F(4,3) transforms
+    (points 0, +-1, +-2, inf) amplify fp32 rounding about ten times more than F(2x2)'s: the bound is 40x the direct kernel's
+    (measured: 3e-5 worst on these shapes), the rms a tenth of that."""
+    n, h, w, c0, c1, cout, flags, use_res = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31) + 9)
+    x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+    wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+    got = hip_conv(x0, wt, b, x1, res, flags, prec="fp32w4")
+    exp = ref_conv(x0, wt, b, x1, res, flags)
+    err = np.abs(got.astype(np.float64) - exp)
+    print(f"winograd F(4x4) conv {shape}: max {np.nanmax(err):.3e} rms {np.sqrt(np.nanmean(err ** 2)):.3e}")
+    _report(got, exp, 40 * F32_OP_TOL, f"winograd F(4x4) conv {shape}")
+    assert np.sqrt((err ** 2).mean()) < 4 * F32_OP_TOL
+    if flags & flib.CONV_RELU_OUT:
+        assert got.min() >= 0
+
+
+def test_conv3x3_fp32_winograd_f4_residual_in_place(dev):
+    """res_block's conv/1 writes onto its residual (ops.py:43): every element is read and written by the same lane."""
+    L = flib.lib()
+    rng = np.random.default_rng(78)
+    n, h, w, c = 1, 24, 72, 64
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    r = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, c, c)) * np.sqrt(2.0 / (9 * c))).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    dx, dr = torch.from_numpy(x).cuda(), torch.from_numpy(r).cuda()
+    flib.check(L.fisr_op_conv3x3(ctypes.c_void_p(dx.data_ptr()), c, None, 0, _fp(wt), _fp(b), c,
+                                 ctypes.c_void_p(dr.data_ptr()), ctypes.c_void_p(dr.data_ptr()), n, h, w, 0, 8, 0, _stream()))
+    torch.cuda.synchronize()
+    _report(dr.cpu().numpy(), ref_conv(x, wt, b, None, r, 0), 40 * F32_OP_TOL, "winograd F(4x4) in-place residual")
 
 
 @pytest.mark.parametrize("shape", [
