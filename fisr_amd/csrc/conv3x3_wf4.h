@@ -19,10 +19,10 @@
 //     transposition (conv3x3_wino8p.h splits the positions over two waves and spends 10-14 % of a 64-channel item on that
 //     exchange and on the DPP transposes behind it).  The accumulator layout of the 16x16 MFMA gives a lane 4 consecutive channels
 //     of one tile: every output pixel is one 16-byte store, four lanes cover a 64-byte record.
-//   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (141 312 B):
+//   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (151 552 B):
 //       U[2]    36 positions x 64 channels x 4 ci       LDS-DMA of the host-made slab (the LDS image), one chunk ahead
-//       V[2]    36 positions x 32 tiles x 4 ci          B^T d B of the NEXT chunk, computed by waves 0-1 while everybody multiplies
-//       RAW[3]  18 x 34 halo pixels x 16 B              LDS-DMA from the activation tensor, three chunks ahead
+//       V[2]    36 positions x 32 tiles x 4 ci          B^T d B of the NEXT chunk, computed by waves 0-3 while everybody multiplies
+//       RAW[4]  18 x 34 halo pixels x 16 B              LDS-DMA from the activation tensor, four chunks ahead
 //     Every global byte goes global -> LDS by `buffer_load_dwordx4 ... lds` from inline asm (see conv3x3_dma.h: hidden from the
 //     compiler, counted by hand; a lane whose offset lies behind the buffer's end writes ZEROS -- the zero padding is free).
 //   * Fragments are 16-byte reads of four consecutive positions (9 + 9 ds_read_b128 feed the 36 MFMAs of a chunk): U as
@@ -32,6 +32,9 @@
 //   * The raw halo rows hold their columns grouped by column mod 4, so the 8 tiles x 4 channels of a ds_read_b32 phase read 32
 //     consecutive dwords.
 #pragma once
+#include <algorithm>
+#include <type_traits>
+#include <vector>
 #include "conv3x3.h"
 
 namespace fisr {
@@ -48,8 +51,16 @@ constexpr int F4_RAW_COPIES = 10;                      // 1 KB LDS-DMA copies pe
 constexpr int F4_RAW_BYTES = F4_RAW_COPIES * 1024;     // 10240
 constexpr int F4_U_BYTES = 36 * F4_BN * F4_CH * 4;     // 36864: one weight slab = 36 copies
 constexpr int F4_V_BYTES = 36 * 32 * F4_CH * 4;        // 18432
-constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 3 * F4_RAW_BYTES; }   // 141312
+// Position (i, j) of the 6 x 6 transform grid lives in slot 6 i + F4_PERM[j] of V, U and the accumulators: the order in which the
+// packed horizontal pass of the input transform leaves its outputs (t0 t5 t1 t3 t2 t4).
+__host__ __device__ constexpr int wf4_slot(int i, int j) { return 6 * i + (j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 4 : j == 3 ? 3 : j == 4 ? 5 : 1); }
+constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 4 * F4_RAW_BYTES; }   // 151552
 
+// FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
+// 2 no raw copies, 4 no input transform, 8 weight copies waited for one iteration later (latency vs bandwidth), 16 no MFMAs
+#ifndef FISR_F4ABL
+#define FISR_F4ABL 0
+#endif
 #define FISR_F4_BEGIN(KEEP, LDS)   "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
 #define FISR_F4_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen lds\n\t"
 #define FISR_F4_NEXT               "s_add_u32 m0, m0, 0x1800\n\ts_nop 0\n\t"
@@ -73,7 +84,7 @@ __device__ __forceinline__ void wf4_at(float m0, float m1, float m2, float m3, f
 }
 
 template <bool RELU_IN, bool HAS_RES>
-__global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sU = smem;
   char* const sV = smem + 2 * F4_U_BYTES;
@@ -83,126 +94,223 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // ---- work item: XCD-aware order as in conv3x3_dma.h (workgroup b runs on XCD b % 8; each XCD walks a contiguous range of
-  //      virtual ids in which the N blocks of one pixel tile are neighbours)
+  // ---- PERSISTENT: one workgroup per CU walks the work items blockIdx.x, + gridDim.x, ... and its copy / transform streams
+  //      simply run on into the next item (the last iterations of an item already request and transform the first chunks of
+  //      the next one): only a workgroup's first item pays the prologue, and no item waits for a workgroup launch.
+  //      Work item id -> (pixel tile, N block), XCD-aware as in conv3x3_wino8p.h: workgroup w runs on XCD w % 8, gridDim.x is a
+  //      multiple of 8, each XCD walks a contiguous range of virtual ids in which the N blocks of one pixel tile are neighbours.
   const int tiles_x = (p.W + F4_TW - 1) / F4_TW, tiles_y = (p.H + F4_TH - 1) / F4_TH;
   const int nblocks = p.CoutPad / F4_BN;
-  int v = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-    const int xcd = v & 7, loc = v >> 3;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  int t = v / nblocks;
-  const int nblk = v - t * nblocks;
-  const int tx = t % tiles_x; t /= tiles_x;
-  const int ty = t % tiles_y;
-  const int nb = t / tiles_y;
-  const int x0 = tx * F4_TW, y0 = ty * F4_TH;
-  const int nch0 = p.C0 / F4_CH, nch = (p.C0 + p.C1) / F4_CH;
+  struct Item { int x0, y0, nb, nblk; };
+  auto item_of = [&](int b) __attribute__((always_inline)) {
+    const int q = n_items >> 3, r = n_items & 7;
+    const int xcd = b & 7, loc = b >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    int t = v / nblocks;
+    Item it;
+    it.nblk = v - t * nblocks;
+    const int tx = t % tiles_x; t /= tiles_x;
+    it.x0 = tx * F4_TW;
+    it.y0 = (t % tiles_y) * F4_TH;
+    it.nb = t / tiles_y;
+    return it;
+  };
+  int b_cur = blockIdx.x;
+  Item cur = item_of(b_cur);
+  bool has_next = b_cur + (int)gridDim.x < n_items;
+  Item nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
+  const int nch0 = p.C0 / F4_CH, nch = (p.C0 + p.C1) / F4_CH;       // (the launcher guarantees nch >= 4)
 
-  unsigned long long t_start = 0, t_first = 0, t_main = 0, t_real = 0;
+  if (FISR_F4ABL & 128) { for (int i = 0; i < (int)((blockIdx.x * 7u) & 31u); ++i) __builtin_amdgcn_s_sleep(4); }     // ablation: de-phase the workgroups
+  unsigned long long t_start = 0, t_first = 0, t_main = 0, t_end1 = 0, t_real = 0;
   if (p.trace) { t_start = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
 
-  // =========================== copy side (waves 2-7; cw = 0..5) ===========================
-  // raw copy c (0..9) moves halo slots 64 c .. 64 c + 63; wave cw issues copy cw and (cw < 4) copy cw + 6.
+  // =========================== copies (LDS-DMA, 1 KB per wave instruction) ===========================
+  // weight copy c (0..35) is linear: wave w issues copies w, w + 8, w + 16, w + 24 and, waves 4-7, copy 28 + w.
+  // raw copy c (0..9) moves halo slots 64 c .. 64 c + 63; wave 4 + cw issues copies cw, cw + 4 and (cw < 2) cw + 8.
+  // (Measured and dropped: all weight copies on waves 0-3 and the raw copies alone on waves 4-7, so that the wait for the weights
+  // -- vmcnt is ONE in-order counter per wave -- does not also wait for the older raw copies: no gain, the transform waves carry
+  // the longer instruction stream already.)
   // slot s -> halo row s / 34, column from the position inside the row: columns 0,4,..,32 | 1,5,..,33 | 2,..,30 | 3,..,31.
-  // weight copy c (0..35) is linear; wave cw issues copies cw, cw + 6, ..., cw + 30.
-  const int cw = wave - 2;
+  const int cw = wave - 4;
   constexpr unsigned OOB = 0x80000000u;
-  int rpix[2] = {-1, -1};
-  if (wave >= 2) {
+  const size_t img_px = (size_t)p.H * p.W;
+  // the raw stream's item: pixel index of this lane's halo slots (or -1: outside the image), the image's buffer resources
+  int rpix[3] = {-1, -1, -1};
+  __amdgpu_buffer_rsrc_t rs0, rs1;
+  auto raw_geom = [&](const Item& it) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int s = 64 * (cw + 6 * q) + lane;
+    for (int q = 0; q < 3; ++q) {
+      int l = lane;
+      asm volatile("" : "+v"(l));                  // (recomputed per item: hoisted, the halo coordinates would stay live across the K loops)
+      const int s = 64 * (cw + 4 * q) + l;
       const int py = s / F4_HW, r = s - py * F4_HW;
       const int px = r < 9 ? 4 * r : r < 18 ? 4 * (r - 9) + 1 : r < 26 ? 4 * (r - 18) + 2 : 4 * (r - 26) + 3;
-      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
       const bool ok = s < F4_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       rpix[q] = ok ? gy * p.W + gx : -1;
+      if (FISR_F4ABL & 32) rpix[q] = ((it.y0 * p.W + it.x0) & ~15) + (s >> 2);        // ablation: 4 lanes per pixel (contiguous 64 B ... wrong data)
+      if (FISR_F4ABL & 64) rpix[q] = (it.y0 * p.W + it.x0) + s;                       // ablation: linear pixels
     }
-  }
-  const size_t img_px = (size_t)p.H * p.W;
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.in0 + (size_t)nb * img_px * p.C0), 0,
-                                                                       (unsigned)(img_px * p.C0 * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in1 ? (const float*)p.in1 + (size_t)nb * img_px * p.C1 : (const float*)p.in0), 0, (unsigned)(img_px * (p.in1 ? p.C1 : p.C0) * 4), 0x00020000);
+    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.in0 + (size_t)it.nb * img_px * p.C0), 0, (unsigned)(img_px * p.C0 * 4), 0x00020000);
+    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? (const float*)p.in1 + (size_t)it.nb * img_px * p.C1 : (const float*)p.in0), 0,
+                                            (unsigned)(img_px * (p.in1 ? p.C1 : p.C0) * 4), 0x00020000);
+  };
+  raw_geom(cur);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (unsigned)((size_t)nch * nblocks * F4_U_BYTES), 0x00020000);
   const unsigned raw_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sR + (unsigned)cw * 1024u;
-  const unsigned u_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sU + (unsigned)cw * 1024u;
+  const unsigned u_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sU;
   const unsigned u_voff = (unsigned)lane * 16u;
 
-  auto copy_raw = [&](int kc, int slot) {
+#define FISR_F4_DMA1(RS, VOFF, SOFF, LDS)                                                                       \
+  do {                                                                                                          \
+    unsigned keep_;                                                                                             \
+    asm volatile(FISR_F4_BEGIN(keep, lds) FISR_F4_COPY(o, rs, so) FISR_F4_END(keep)                             \
+                 : [keep] "=&s"(keep_) : [rs] "s"(RS), [lds] "s"(LDS), [o] "v"(VOFF), [so] "s"(SOFF) : "memory", "scc"); \
+  } while (0)
+  // weight copy j (0..3; 4: waves 4-7 only) of chunk kc of N block nblk into U[buf]
+  auto copy_u1 = [&](int nblk, int kc, int buf, int j) __attribute__((always_inline)) {
+    const unsigned c = j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave);
+    const unsigned so = (unsigned)(((size_t)kc * nblocks + nblk) * F4_U_BYTES) + c * 1024u;
+    const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES + c * 1024u;
+    FISR_F4_DMA1(rsw, u_voff, so, lds);
+  };
+  // raw copy j (0 .. 2) of chunk kc of the raw stream's item into RAW[slot]
+  auto copy_raw1 = [&](int kc, int slot, int j) __attribute__((always_inline)) {
     const bool first = kc < nch0;
     const unsigned so = (unsigned)(first ? kc : kc - nch0) * 16u;
     const unsigned csb = (unsigned)(first ? p.C0 : p.C1) * 4u;
-    const unsigned o0 = rpix[0] < 0 ? OOB : (unsigned)rpix[0] * csb;
-    const unsigned o1 = rpix[1] < 0 ? OOB : (unsigned)rpix[1] * csb;
-    const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)F4_RAW_BYTES;
-    unsigned keep;
-#define FISR_F4_RAW(RS)                                                                                                      \
-    if (cw < 4) {                                                                                                            \
-      asm volatile(FISR_F4_BEGIN(keep, lds) FISR_F4_COPY(o0, rs, so) FISR_F4_NEXT FISR_F4_COPY(o1, rs, so) FISR_F4_END(keep) \
-                   : [keep] "=&s"(keep) : [rs] "s"(RS), [so] "s"(so), [lds] "s"(lds), [o0] "v"(o0), [o1] "v"(o1) : "memory", "scc"); \
-    } else {                                                                                                                 \
-      asm volatile(FISR_F4_BEGIN(keep, lds) FISR_F4_COPY(o0, rs, so) FISR_F4_END(keep)                                       \
-                   : [keep] "=&s"(keep) : [rs] "s"(RS), [so] "s"(so), [lds] "s"(lds), [o0] "v"(o0) : "memory", "scc");       \
-    }
-    if (first) { FISR_F4_RAW(rs0) } else { FISR_F4_RAW(rs1) }
-#undef FISR_F4_RAW
+    const int px_ = j == 0 ? rpix[0] : j == 1 ? rpix[1] : rpix[2];
+    const unsigned o = px_ < 0 ? OOB : (unsigned)px_ * csb;
+    const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)F4_RAW_BYTES + (unsigned)j * 4096u;
+    if (first) FISR_F4_DMA1(rs0, o, so, lds); else FISR_F4_DMA1(rs1, o, so, lds);
   };
-  auto copy_u = [&](int kc, int buf) {
-    const unsigned s0 = (unsigned)(((size_t)kc * nblocks + nblk) * F4_U_BYTES) + (unsigned)cw * 1024u;
-    const unsigned s1 = s0 + 6144u, s2 = s0 + 12288u, s3 = s0 + 18432u, s4 = s0 + 24576u, s5 = s0 + 30720u;
-    const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES;
-    unsigned keep;
-    asm volatile(FISR_F4_BEGIN(keep, lds) FISR_F4_COPY(o, rs, s0) FISR_F4_NEXT FISR_F4_COPY(o, rs, s1) FISR_F4_NEXT FISR_F4_COPY(o, rs, s2)
-                 FISR_F4_NEXT FISR_F4_COPY(o, rs, s3) FISR_F4_NEXT FISR_F4_COPY(o, rs, s4) FISR_F4_NEXT FISR_F4_COPY(o, rs, s5) FISR_F4_END(keep)
-                 : [keep] "=&s"(keep)
-                 : [rs] "s"(rsw), [lds] "s"(lds), [o] "v"(u_voff), [s0] "s"(s0), [s1] "s"(s1), [s2] "s"(s2), [s3] "s"(s3), [s4] "s"(s4), [s5] "s"(s5)
-                 : "memory", "scc");
+  auto copy_raw_all = [&](int kc, int slot) __attribute__((always_inline)) {
+    copy_raw1(kc, slot, 0); copy_raw1(kc, slot, 1);
+    if (cw < 2) copy_raw1(kc, slot, 2);
   };
   auto wait_keep_youngest_raw = [&]() {          // everything but the raw chunk requested last has landed
-    if (cw < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if (cw < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  // relu-on-load: applied ONCE per element, in LDS, by the wave that requested the copy (the transform lanes would apply it
+  // 2.25 times per element); read and write halves apart, a quad of MFMAs in between.  Out-of-image slots hold zeros: unchanged.
+  f32x4 rl[3];
+  auto relu_read = [&](int slot) __attribute__((always_inline)) {
+    const char* b = sR + slot * F4_RAW_BYTES + cw * 1024 + lane * 16;
+    rl[0] = *reinterpret_cast<const f32x4*>(b);
+    rl[1] = *reinterpret_cast<const f32x4*>(b + 4096);
+    if (cw < 2) rl[2] = *reinterpret_cast<const f32x4*>(b + 8192);
+  };
+  auto relu_write = [&](int slot) __attribute__((always_inline)) {
+    char* b = sR + slot * F4_RAW_BYTES + cw * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j == 2 && cw >= 2) break;
+      f32x4 f = rl[j];
+      asm("v_max_f32 %0, 0, %0" : "+v"(f.x)); asm("v_max_f32 %0, 0, %0" : "+v"(f.y));
+      asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
+      *reinterpret_cast<f32x4*>(b + j * 4096) = f;
+    }
+  };
 
-  // =========================== transform side (waves 0-1: tile half th_t = wave) ===========================
-  // lane -> (channel of the chunk, tile): 8 tiles of one tile row x 4 channels per ds_read_b32 phase
+  // =========================== transform side (waves 0-3: tile half wave & 1, transform rows 3 (wave >> 1) ..) ===========================
+  // lane -> (channel of the chunk, tile): 8 tiles of one tile row x 4 channels per ds_read_b32 phase.  The two waves of a tile
+  // half share the work by OUTPUT rows: each reads the whole 6 x 6 patch, runs the vertical pass for its three rows and the
+  // horizontal pass on them.  Everything is packed fp32 (v_pk_fma_f32 / v_pk_add_f32 on register pairs): the fp32 MFMA and the vector
+  // ALU of a SIMD do NOT overlap (probed: a v_fma wave beside an MFMA wave on one SIMD takes the SUM of their times), so every vector
+  // instruction of the K loop is paid in full on top of the 2304 MFMA cycles of a chunk.  Vertical pass: element-wise on column
+  // pairs (6 instructions per pair and wave).  Horizontal pass: the op_sel bits feed one packed instruction from the halves of
+  // different pairs, so the whole 6 -> 6 transform of a row is 6 instructions,
+  //     (a, c) = x2 * (-4, -1) + x4      (b, e) = x1 * (-4, -1) + x3      (t1, t3) = (b, e) * (1, 2) + (a, c)
+  //     (t2, t4) = (a, c) - (b, e) * (1, 2)        (t0, t5) = (x0, x1) * 4 + ((x2, x3) * -5 + (x4, x5))
+  // and leaves its outputs in the order t0 t5 t1 t3 t2 t4: that IS the order of the six positions of a row in V, U and the
+  // accumulators (F4_PERM), so nothing is shuffled.  36 packed instructions per wave and chunk (scalar: 78).
   const int t_ch = lane & 3, t_t16 = lane >> 2;
   const int t_ty = 2 * (wave & 1) + (t_t16 >> 3), t_tx = t_t16 & 7;
   const int t_roff = ((4 * t_ty) * F4_HW + t_tx) * 16 + t_ch * 4;
   const int t_voff = (wave & 1) * 1024 + (t_ch * 16 + (t_t16 ^ (t_ch << 1))) * 16;
-  auto transform = [&](int slot, int vbuf) {
+  const f32x2 K8 = {8.f, 8.f}, K4 = {4.f, 4.f}, KM4 = {-4.f, -4.f}, KM5 = {-5.f, -5.f}, K2 = {2.f, 2.f}, K41 = {-4.f, -1.f}, K12 = {1.f, 2.f};
+  auto pk_fma = [](f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; };
+  auto pk_fnma = [](f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; };
+  auto pk_add = [](f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  auto pk_sub = [](f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  f32x2 dp[6][3];                                  // the 6 x 6 patch of this lane's (tile, channel) as column pairs
+  f32x2 zp[3][3];                                  // this wave's three rows: vertical pass, then horizontal pass in place
+  auto tr_read = [&](int slot) __attribute__((always_inline)) {
     const char* rb = sR + slot * F4_RAW_BYTES + t_roff;
-    float d[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int cb = (j & 3) == 0 ? 0 : (j & 3) == 1 ? 9 : (j & 3) == 2 ? 18 : 26;     // column 4 tx + j sits at cb + tx + j / 4
-        d[r][j] = *reinterpret_cast<const float*>(rb + (r * F4_HW + cb + (j >> 2)) * 16);
+        dp[r][j >> 1][j & 1] = *reinterpret_cast<const float*>(rb + (r * F4_HW + cb + (j >> 2)) * 16);
       }
-    if constexpr (RELU_IN) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) d[r][j] = fmaxf(d[r][j], 0.f);
+  };
+  auto tr_col = [&](auto rh_tag, int c) __attribute__((always_inline)) {          // rows 3 rh .. 3 rh + 2 of B^T applied down the column pair c
+    constexpr int RH = decltype(rh_tag)::value;
+    if constexpr (RH == 0) {
+      const f32x2 a = pk_fma(dp[2][c], KM4, dp[4][c]), b = pk_fma(dp[1][c], KM4, dp[3][c]);
+      zp[0][c] = pk_fma(dp[0][c], K4, pk_fma(dp[2][c], KM5, dp[4][c]));
+      zp[1][c] = pk_add(a, b);
+      zp[2][c] = pk_sub(a, b);
+    } else {
+      const f32x2 cc = pk_sub(dp[4][c], dp[2][c]), e = pk_sub(dp[3][c], dp[1][c]);
+      zp[0][c] = pk_fma(e, K2, cc);
+      zp[1][c] = pk_fnma(e, K2, cc);
+      zp[2][c] = pk_fma(dp[1][c], K4, pk_fma(dp[3][c], KM5, dp[5][c]));
     }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) wf4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+  };
+  auto tr_row = [&](int i) __attribute__((always_inline)) {                       // -> (t0, t5), (t1, t3), (t2, t4)
+    const f32x2 p01 = zp[i][0], p23 = zp[i][1], p45 = zp[i][2];
+    f32x2 ac, be, t05, t13, t24;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(ac) : "v"(p23), "s"(K41), "v"(p45));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(be) : "v"(p01), "s"(K41), "v"(p23));
+    t13 = pk_fma(be, K12, ac);
+    t24 = pk_fnma(be, K12, ac);
+    t05 = pk_fma(p01, K4, pk_fma(p23, KM5, p45));
+    zp[i][0] = t05; zp[i][1] = t13; zp[i][2] = t24;
+  };
+  // the 18 slots 18 rh + 6 i + .. of this wave: four position quads and half of quad 4
+  auto quad_of = [](f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); };
+  auto tr_write = [&](auto rh_tag, int vbuf, int i) __attribute__((always_inline)) {     // what row i (0..2) of this wave completes
+    constexpr int RH = decltype(rh_tag)::value;
     char* vb = sV + vbuf * F4_V_BYTES + t_voff;
+    if constexpr (RH == 0) {
+      if (i == 0) *reinterpret_cast<f32x4*>(vb) = quad_of(zp[0][0], zp[0][1]);
+      if (i == 1) {
+        *reinterpret_cast<f32x4*>(vb + 2048) = quad_of(zp[0][2], zp[1][0]);
+        *reinterpret_cast<f32x4*>(vb + 2 * 2048) = quad_of(zp[1][1], zp[1][2]);
+      }
+      if (i == 2) {
+        *reinterpret_cast<f32x4*>(vb + 3 * 2048) = quad_of(zp[2][0], zp[2][1]);
+        *reinterpret_cast<f32x2*>(vb + 4 * 2048) = zp[2][2];
+      }
+    } else {
+      if (i == 0) {
+        *reinterpret_cast<f32x2*>(vb + 4 * 2048 + 8) = zp[0][0];
+        *reinterpret_cast<f32x4*>(vb + 5 * 2048) = quad_of(zp[0][1], zp[0][2]);
+      }
+      if (i == 1) *reinterpret_cast<f32x4*>(vb + 6 * 2048) = quad_of(zp[1][0], zp[1][1]);
+      if (i == 2) {
+        *reinterpret_cast<f32x4*>(vb + 7 * 2048) = quad_of(zp[1][2], zp[2][0]);
+        *reinterpret_cast<f32x4*>(vb + 8 * 2048) = quad_of(zp[2][1], zp[2][2]);
+      }
+    }
+  };
+  typedef std::integral_constant<int, 0> rh0_t;
+  typedef std::integral_constant<int, 1> rh1_t;
+  auto transform = [&](auto rh_tag, int slot, int vbuf) __attribute__((always_inline)) {       // (prologue: the whole transform at once)
+    tr_read(slot);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) wf4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    for (int c = 0; c < 3; ++c) tr_col(rh_tag, c);
 #pragma unroll
-    for (int q = 0; q < 9; ++q)          // positions 4 q .. 4 q + 3 (position = 6 i + j)
-      *reinterpret_cast<f32x4*>(vb + q * 2048) = f32x4{d[(4 * q) / 6][(4 * q) % 6], d[(4 * q + 1) / 6][(4 * q + 1) % 6],
-                                                       d[(4 * q + 2) / 6][(4 * q + 2) % 6], d[(4 * q + 3) / 6][(4 * q + 3) % 6]};
+    for (int i = 0; i < 3; ++i) { tr_row(i); tr_write(rh_tag, vbuf, i); }
   };
 
   // =========================== MFMA side (all waves) ===========================
@@ -210,122 +318,253 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p) {
   const char* const fu = sU + cq * 1024 + lane * 16;
   const char* const fv = sV + th * 1024 + ((lane & 0x30) | ((lane & 15) ^ ((lane >> 4) << 1))) * 16;
   f32x4 acc[36];
-#pragma unroll
-  for (int q = 0; q < 36; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfma_chunk = [&](int buf) {
-    const char* ub = fu + buf * F4_U_BYTES;
-    const char* vb = fv + buf * F4_V_BYTES;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ub + q * 4096);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(vb + q * 2048);
-      acc[4 * q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[4 * q], 0, 0, 0);
-      acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[4 * q + 1], 0, 0, 0);
-      acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[4 * q + 2], 0, 0, 0);
-      acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[4 * q + 3], 0, 0, 0);
-    }
-  };
+  // The fragments of a position quad are requested two quads (8 MFMAs = 256 cycles of the pipe) ahead, and the LAST quad of a
+  // chunk is multiplied behind the barrier, in the next iteration, from registers loaded before it: a wave issues in order, so
+  // without the skew every iteration opens with both waves of a SIMD waiting for an LDS round trip and the matrix pipe idle.
+  // (First iteration of an item: nothing is pending -- the accumulators of the last quad are zeroed instead -- and the other
+  // eight quads start from C = 0, an inline constant: the 144 accumulators are never zeroed by hand.  The last chunk's quad is
+  // flushed behind the loop.)
+  f32x4 ra[3], rb[3];                              // ring of three quads; slot 2 holds the pending last quad across the barrier
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4 = zero4;                             // bias of this lane's four channels (of the current item)
+  static_assert(wf4_slot(1, 1) == 8, "the bias rides in accumulator 8 (quad 2, element 0)");
+#define FISR_F4_MMA4C(Q, A, B, C0_, C1_, C2_, C3_)                                                  \
+  if (!(FISR_F4ABL & 16)) {                                                                         \
+  acc[4 * (Q)]     = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, C0_, 0, 0, 0);              \
+  acc[4 * (Q) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, C1_, 0, 0, 0);              \
+  acc[4 * (Q) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, C2_, 0, 0, 0);              \
+  acc[4 * (Q) + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, C3_, 0, 0, 0); }
+#define FISR_F4_MMA4(Q, A, B) FISR_F4_MMA4C(Q, A, B, acc[4 * (Q)], acc[4 * (Q) + 1], acc[4 * (Q) + 2], acc[4 * (Q) + 3])
+// first chunk of an item: C = 0 -- except position (1, 1) (slot 8), which starts from the BIAS: A^T has a 1 in column 1 of every
+// row, so M[1][1] enters all 16 outputs of a tile with coefficient 1 and the bias add of the epilogue costs nothing.
+#define FISR_F4_MMA4Z(Q, A, B) FISR_F4_MMA4C(Q, A, B, ((Q) == 2 ? bias4 : zero4), zero4, zero4, zero4)
 
-  // ---- prologue: raw(0), U(0), raw(1), raw(2) requested; raw(0) -> V[0] ----
-  auto clampc = [&](int kc) { return kc < nch ? kc : nch - 1; };     // behind the last chunk the copy COUNT stays fixed (counted waits)
-  if (wave >= 2) {
-    copy_raw(0, 0);
-    copy_u(0, 0);
-    copy_raw(clampc(1), 1);
-    copy_raw(clampc(2), 2);
-    wait_keep_youngest_raw();                      // raw(0), U(0), raw(1) landed
+  // ---- prologue of the workgroup's FIRST item: raw(0), U(0), raw(1), raw(2), raw(3) requested; raw(0) -> V[0] ----
+  if (wave >= 4) {
+    copy_raw_all(0, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) copy_u1(cur.nblk, 0, 0, j);
+    copy_raw_all(1, 1);
+    copy_raw_all(2, 2);
+    copy_raw_all(3, 3);
+    wait_keep_youngest_raw();                      // raw(0), U(0), raw(1), raw(2) landed
+    if constexpr (RELU_IN) { relu_read(0); relu_write(0); relu_read(1); relu_write(1); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) copy_u1(cur.nblk, 0, 0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   lds_barrier();
-  if (wave < 2) transform(0, 0);
+  if (wave < 2) transform(rh0_t{}, 0, 0);
+  else if (wave < 4) transform(rh1_t{}, 0, 0);
   lds_barrier();
   if (p.trace) t_first = __builtin_readcyclecounter();
 
-  // ---- K loop ----
-  int s1 = 1, s2 = 2, s3 = 0;                      // RAW slots of chunks k+1, k+2, k+3
-  if (wave < 2) {
-    for (int k = 0; k < nch; ++k) {
-      if (k + 1 < nch) transform(s1, (k & 1) ^ 1);
-      mfma_chunk(k & 1);
-      lds_barrier();
-      const int s_ = s1; s1 = s2; s2 = s3; s3 = s_;
-    }
-  } else {
-    for (int k = 0; k < nch; ++k) {
-      copy_u(clampc(k + 1), (k & 1) ^ 1);
-      copy_raw(clampc(k + 3), s3);
-      mfma_chunk(k & 1);
-      wait_keep_youngest_raw();                    // U(k+1), raw(k+2) landed; raw(k+3) stays in flight
-      lds_barrier();
-      const int s_ = s1; s1 = s2; s2 = s3; s3 = s_;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- K loop of one item ----
+  // RAW ring: chunk g+1 is transformed (g: the workgroup's running chunk counter), g+2 gets its relu (it landed before the
+  // previous barrier: it is older than U(g), which was waited for), g+3 may still be in flight, g+4 is requested.  Copies early
+  // in the iteration (they have the rest of it to land), one behind each quad of MFMAs; the transform between the quads that
+  // follow its LDS reads.  Behind an item's last chunk the streams continue with the next item's first ones (behind the last
+  // item: they repeat a chunk -- the copy COUNT per iteration stays fixed for the counted waits).
+  int s1 = 1, s2 = 2, s3 = 3, s4 = 0;
+  int par = 0;                                     // V / U buffer of the chunk about to be multiplied
+  // byte offsets of this lane's raw pixels in the concat source the raw stream is in (copy waves; recomputed where it changes)
+  unsigned ro[3] = {OOB, OOB, OOB};
+  bool ro_first = nch0 > 4;
+  if (wave >= 4) {
+    const unsigned csb = (unsigned)(ro_first ? p.C0 : p.C1) * 4u;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ro[j] = rpix[j] < 0 ? OOB : (unsigned)rpix[j] * csb;
   }
-  if (p.trace) t_main = __builtin_readcyclecounter();
+  typedef std::integral_constant<bool, true> first_t;
+  typedef std::integral_constant<bool, false> rest_t;
+  auto k_iter = [&](auto role_tag, auto first_tag, int k) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_tag)::value;        // 0 / 1: transform wave of rows 0-2 / 3-5; 2: copy wave
+    constexpr bool FIRST = decltype(first_tag)::value;     // first chunk of an item
+    typedef typename std::conditional<ROLE == 1, rh1_t, rh0_t>::type RH;
+    const int buf = par;
+    const char* ub = fu + buf * F4_U_BYTES;
+    const char* vb = fv + buf * F4_V_BYTES;
+    // U(k+1): of this item, of the next item (chunk 0), or a repeated chunk behind the last item
+    const bool u_here = k + 1 < nch;
+    const int ku = u_here ? k + 1 : (has_next ? 0 : nch - 1);
+    const int nblk_cur = cur.nblk, nblk_nxt = nxt.nblk;       // (values first: a conditional between the captured structs' fields is a
+    const int u_nblk = u_here || !has_next ? nblk_cur : nblk_nxt;     //  select of ADDRESSES into the closure, which then cannot be promoted to registers)
+    // raw(k+4) likewise; its geometry moves to the next item at k = nch - 4
+    const bool r_here = k + 4 < nch;
+    const int kr = r_here ? k + 4 : (has_next ? k + 4 - nch : nch - 1);
+    ra[0] = *reinterpret_cast<const f32x4*>(ub);
+    rb[0] = *reinterpret_cast<const f32x4*>(vb);
+    ra[1] = *reinterpret_cast<const f32x4*>(ub + 4096);
+    rb[1] = *reinterpret_cast<const f32x4*>(vb + 2048);
+    if (ROLE < 2 && !(FISR_F4ABL & 4)) tr_read(s1);
+    const bool rfirst = kr < nch0;
+    if constexpr (ROLE == 2) {
+      if (k == nch - 4 && has_next) { raw_geom(nxt); ro_first = !rfirst; }
+      if (rfirst != ro_first) {
+        const unsigned csb = (unsigned)(rfirst ? p.C0 : p.C1) * 4u;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ro[j] = rpix[j] < 0 ? OOB : (unsigned)rpix[j] * csb;
+        ro_first = rfirst;
+      }
+    }
+    const unsigned rso = (unsigned)(rfirst ? kr : kr - nch0) * 16u;
+    const unsigned rlds = raw_lds0 + (unsigned)s4 * (unsigned)F4_RAW_BYTES;
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[32 + r] = zero4;
+    } else {
+      FISR_F4_MMA4(8, ra[2], rb[2])
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < 7) {
+        ra[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(ub + (q + 2) * 4096);
+        rb[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(vb + (q + 2) * 2048);
+      }
+      if constexpr (FIRST) { FISR_F4_MMA4Z(q, ra[q % 3], rb[q % 3]) } else { FISR_F4_MMA4(q, ra[q % 3], rb[q % 3]) }
+      if (!(FISR_F4ABL & 1) && q < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q);
+      if constexpr (ROLE < 2) {
+        if (!(FISR_F4ABL & 4)) {
+          if (q == 1) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
+          if (q >= 2 && q < 5) { tr_row(q - 2); tr_write(RH{}, buf ^ 1, q - 2); }
+        }
+      } else {
+        if constexpr (RELU_IN) {
+          if (q == 0) relu_read(s2);
+          if (q == 1) relu_write(s2);
+        }
+        if (!(FISR_F4ABL & 2)) {
+          if (q == 5) { if (rfirst) FISR_F4_DMA1(rs0, ro[0], rso, rlds); else FISR_F4_DMA1(rs1, ro[0], rso, rlds); }
+          if (q == 6) { const unsigned l1 = rlds + 4096u; if (rfirst) FISR_F4_DMA1(rs0, ro[1], rso, l1); else FISR_F4_DMA1(rs1, ro[1], rso, l1); }
+          if (q == 7 && cw < 2) { const unsigned l2 = rlds + 8192u; if (rfirst) FISR_F4_DMA1(rs0, ro[2], rso, l2); else FISR_F4_DMA1(rs1, ro[2], rso, l2); }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ROLE < 2 || (FISR_F4ABL & 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else wait_keep_youngest_raw();                 // U(g+1) (and everything older: raw(g+3)) landed; raw(g+4) stays in flight
+    lds_barrier();
+    const int s_ = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s_;
+    par ^= 1;
+  };
+  typedef std::integral_constant<int, 0> role0_t;
+  typedef std::integral_constant<int, 1> role1_t;
+  typedef std::integral_constant<int, 2> role2_t;
+  auto k_loop = [&](auto role_tag) __attribute__((always_inline)) {
+    k_iter(role_tag, first_t{}, 0);
+    for (int k = 1; k < nch; ++k) k_iter(role_tag, rest_t{}, k);
+  };
 
-  // ---- epilogue: Y = A^T M A in registers, + bias (+ residual), relu, 16-byte stores ----
-  // lane: tile th * 16 + (lane & 15) -> tile row / column, channels c0 .. c0 + 3
-  const int e_t = th * 16 + (lane & 15);
-  const int e_ty = e_t >> 3, e_tx = e_t & 7;
-  const int c0 = nblk * F4_BN + cq * 16 + 4 * (lane >> 4);
-  const bool c_ok = c0 < p.Cout;
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + (c_ok ? c0 : 0));
-  const int cq_shift = p.d2s_shift;
-  const unsigned sub = (unsigned)c0 >> cq_shift;
-  const unsigned sA = p.d2s ? (unsigned)(4 * p.W) << cq_shift : (unsigned)p.W * (unsigned)p.Cout;
-  const unsigned sB = p.d2s ? 2u << cq_shift : (unsigned)p.Cout;
-  const unsigned vC = p.d2s ? ((((sub >> 1) * 2u * (unsigned)p.W + (sub & 1u)) << cq_shift) + ((unsigned)c0 & ((1u << cq_shift) - 1u))) : (unsigned)c0;
-  const unsigned out_bytes = p.d2s ? ((unsigned)(4 * p.H * p.W) << cq_shift) * 4u : (unsigned)(p.H * p.W) * (unsigned)p.Cout * 4u;
-  const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-      (char*)p.out + (p.d2s ? ((size_t)nb * 2 * p.H * 2 * p.W << cq_shift) * 4 : (size_t)nb * img_px * p.Cout * 4), 0, out_bytes, 0x00020000);
-  const float relu_lo = p.relu_out ? 0.f : -__builtin_huge_valf();
-  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  unsigned off[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int oy = y0 + 4 * e_ty + i;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ox = x0 + 4 * e_tx + j;
-      off[i][j] = (c_ok & (oy < p.H) & (ox < p.W)) ? ((unsigned)oy * sA + (unsigned)ox * sB + vC) * 4u : OOB;
+  int n_done = 0;
+  for (;;) {                                       // ---- work items of this workgroup ----
+    {
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      const int c0 = cur.nblk * F4_BN + cq * 16 + 4 * (l >> 4);
+      bias4 = *reinterpret_cast<const f32x4*>(p.bias + (c0 < p.Cout ? c0 : 0));
     }
-  }
-  f32x4 res[4][4];
-  if constexpr (HAS_RES) {
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((char*)p.res + (size_t)nb * img_px * p.Cout * 4, 0, out_bytes, 0x00020000);
+    if (wave < 2) k_loop(role0_t{});
+    else if (wave < 4) k_loop(role1_t{});
+    else k_loop(role2_t{});
+    FISR_F4_MMA4(8, ra[2], rb[2])                  // the last chunk's pending quad
+    if (p.trace && n_done == 0) t_main = __builtin_readcyclecounter();
+
+    // ---- epilogue: Y = A^T M A in registers, + bias (+ residual), relu, 16-byte stores.  No LDS, no barrier: V / U / RAW already
+    //      belong to the next item.  lane: tile th * 16 + (lane & 15) -> tile row / column, channels c0 .. c0 + 3
+    {
+      int l = lane;
+      asm volatile("" : "+v"(l));                  // (recomputed per item: see raw_geom)
+      const int e_t = th * 16 + (l & 15);
+      const int e_ty = e_t >> 3, e_tx = e_t & 7;
+      const int c0 = cur.nblk * F4_BN + cq * 16 + 4 * (l >> 4);
+      const bool c_ok = c0 < p.Cout;
+      const int cq_shift = p.d2s_shift;
+      const unsigned sub = (unsigned)c0 >> cq_shift;
+      const unsigned sA = p.d2s ? (unsigned)(4 * p.W) << cq_shift : (unsigned)p.W * (unsigned)p.Cout;
+      const unsigned sB = p.d2s ? 2u << cq_shift : (unsigned)p.Cout;
+      const unsigned vC = p.d2s ? ((((sub >> 1) * 2u * (unsigned)p.W + (sub & 1u)) << cq_shift) + ((unsigned)c0 & ((1u << cq_shift) - 1u))) : (unsigned)c0;
+      const unsigned out_bytes = p.d2s ? ((unsigned)(4 * p.H * p.W) << cq_shift) * 4u : (unsigned)(p.H * p.W) * (unsigned)p.Cout * 4u;
+      const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
+          (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4 : (size_t)cur.nb * img_px * p.Cout * 4), 0, out_bytes, 0x00020000);
+      const float relu_lo = p.relu_out ? 0.f : -__builtin_huge_valf();
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      unsigned off[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        const int oy = cur.y0 + 4 * e_ty + i;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) res[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[i][j], 0, 0));
-  }
-  f32x4 y[4][4];
+        for (int j = 0; j < 4; ++j) {
+          const int ox = cur.x0 + 4 * e_tx + j;
+          off[i][j] = (c_ok & (oy < p.H) & (ox < p.W)) ? ((unsigned)oy * sA + (unsigned)ox * sB + vC) * 4u : OOB;
+        }
+      }
+      // output transform, packed on the channel pairs (r0, r1), (r2, r3) of every accumulator: rows first (W = M A, 6 x 4 per pair),
+      // then columns (Y = A^T W).  The residual records are requested after the first half of the row pass -- from there on the
+      // dead halves of the accumulators make room for them -- and arrive under the rest of the transform.
+      auto at_pk = [&](f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32x2 m4, f32x2 m5, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) __attribute__((always_inline)) {
+        const f32x2 s1 = pk_add(m1, m2), d1 = pk_sub(m1, m2), s2 = pk_add(m3, m4), d2 = pk_sub(m3, m4);
+        y0 = pk_add(pk_add(m0, s1), s2);
+        y1 = pk_fma(d2, K2, d1);
+        y2 = pk_fma(s2, K4, s1);
+        y3 = pk_add(pk_fma(d2, K8, d1), m5);
+      };
+      f32x2 yp[4][4][2];                           // [row][column][channel pair]
+      f32x4 res[4][4];
+      auto half = [&](auto h_tag) __attribute__((always_inline)) {
+        constexpr int h = decltype(h_tag)::value;
+        f32x2 wp[6][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float w[6][4];
+        for (int a = 0; a < 6; ++a) {
+          f32x2 m[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
-      wf4_at(acc[a * 6 + 0][r], acc[a * 6 + 1][r], acc[a * 6 + 2][r], acc[a * 6 + 3][r], acc[a * 6 + 4][r], acc[a * 6 + 5][r],
-             w[a][0], w[a][1], w[a][2], w[a][3]);
+          for (int b = 0; b < 6; ++b) m[b] = f32x2{acc[wf4_slot(a, b)][2 * h], acc[wf4_slot(a, b)][2 * h + 1]};
+          at_pk(m[0], m[1], m[2], m[3], m[4], m[5], wp[a][0], wp[a][1], wp[a][2], wp[a][3]);
+        }
+        if constexpr (HAS_RES) {
+          if (h == 0) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((char*)p.res + (size_t)cur.nb * img_px * p.Cout * 4, 0, out_bytes, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float o0, o1, o2, o3;
-      wf4_at(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], o0, o1, o2, o3);
-      y[0][j][r] = o0; y[1][j][r] = o1; y[2][j][r] = o2; y[3][j][r] = o3;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) res[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[i][j], 0, 0));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) at_pk(wp[0][j], wp[1][j], wp[2][j], wp[3][j], wp[4][j], wp[5][j], yp[0][j][h], yp[1][j][h], yp[2][j][h], yp[3][j][h]);
+      };
+      half(std::integral_constant<int, 0>{});
+      half(std::integral_constant<int, 1>{});
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x2 lo = yp[i][j][0], hi = yp[i][j][1];
+          if constexpr (HAS_RES) { lo = pk_add(lo, f32x2{res[i][j].x, res[i][j].y}); hi = pk_add(hi, f32x2{res[i][j].z, res[i][j].w}); }
+          f32x4 o = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, %1, %0" : "+v"(o[e]) : "s"(relu_lo));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], 0, 2);   // aux 2: nontemporal
+        }
     }
+    if (p.trace && n_done == 0) t_end1 = __builtin_readcyclecounter();
+    ++n_done;
+    if (!has_next) break;
+    b_cur += gridDim.x;
+    cur = nxt;
+    has_next = b_cur + (int)gridDim.x < n_items;
+    nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 o = y[i][j] + bias;
-      if constexpr (HAS_RES) o += res[i][j];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], relu_lo);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], 0, 2);   // aux 2: nontemporal
-    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the repeated copies behind the last item still write LDS)
+#undef FISR_F4_MMA4
+#undef FISR_F4_MMA4Z
+#undef FISR_F4_MMA4C
+#undef FISR_F4_DMA1
   if (p.trace && tid == 0) {
     unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
     tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
-    tr[3] = 0; tr[4] = t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = 0;
+    tr[3] = t_end1; tr[4] = t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)n_done;
   }
 }
 
@@ -333,5 +572,77 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p) {
 #undef FISR_F4_COPY
 #undef FISR_F4_NEXT
 #undef FISR_F4_END
+
+// ---- host side: weight slabs, eligibility, launch ----
+
+// Winograd F(4x4,3x3) weights (conv3x3_wf4.h): U = G g G^T per (ci, co) with the 6x3 G of the interpolation points 0, +-1, +-2, inf,
+// computed in double and rounded once to fp32, stored as the kernel's LDS image
+// [Cin/4][CoutPad/64][slot quad 9][channel quarter 4][ci 4][channel 16][4 slots]  (slot of position (i, j): wf4_slot).
+inline void pack_weights_wf4(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
+  static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const int nb = (co + F4_BN - 1) / F4_BN, nch = cin_pad / F4_CH;
+  wp.assign((size_t)nch * nb * F4_U_BYTES, 0);
+  for (int c = 0; c < ci; ++c)
+    for (int n = 0; n < co; ++n) {
+      double g[3][3], t[6][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) g[a][b] = w[((size_t)(a * 3 + b) * ci + c) * co + n];
+      for (int i = 0; i < 6; ++i)
+        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+      const int kc = c / F4_CH, k = c % F4_CH, blk = n / F4_BN, q = (n % F4_BN) / 16, r = n % 16;
+      float* slab = reinterpret_cast<float*>(wp.data() + ((size_t)kc * nb + blk) * F4_U_BYTES);
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+          const int pos = wf4_slot(i, j);
+          slab[(((pos >> 2) * 4 + q) * 64 + k * 16 + r) * 4 + (pos & 3)] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+    }
+}
+// what conv3x3_wf4.h takes: whole 64-channel output blocks, whole 4-channel chunks per concat source, images addressed with
+// 31-bit byte offsets (the out-of-range marker of its zero padding is 2^31)
+inline bool wf4_fits(int h, int w, int c0, int c1, int co) {
+  return co % F4_BN == 0 && c0 > 0 && c0 % F4_CH == 0 && c1 % F4_CH == 0 && (c0 + c1) / F4_CH >= 4 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
+}
+// ... and where it is the faster of the two Winograd kernels (measured per map size, scripts/conv_bench.py): its 16 x 32-pixel
+// items waste more of a small map than the 8 x 32 ones of conv3x3_wino8p.h
+inline bool wf4_wins(int h, int w) { return h >= 48 && w >= 64; }
+
+// The F(4x4,3x3) Winograd kernel (conv3x3_wf4.h; fp32, FISRnet's dense layers only; a.wpk = the conv's d_wu4).
+inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
+  static bool attr_done[64] = {};
+  static int n_cu[64] = {};
+  constexpr size_t lds = wf4_lds_bytes();
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!attr_done[dev]) {
+    const void* kerns[] = {reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true>),
+                           reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, true>)};
+    for (const void* k : kerns) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    attr_done[dev] = true;
+  }
+  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && a.dil == 1;
+  if (!plain || !wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s) || a.CoutPad != a.Cout) return hipErrorInvalidValue;
+  const int items = ((a.W + F4_TW - 1) / F4_TW) * ((a.H + F4_TH - 1) / F4_TH) * a.N * (a.CoutPad / F4_BN);
+  // one workgroup per CU (the kernel needs most of a CU's LDS and half its registers), a multiple of 8 so that the items of a
+  // workgroup stay on one XCD
+  const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
+  if (a.relu_in) {
+    if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<true, true>), dim3(grid), dim3(512), lds, st, a, items);
+    else hipLaunchKernelGGL((conv3x3_wf4_kernel<true, false>), dim3(grid), dim3(512), lds, st, a, items);
+  } else {
+    if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true>), dim3(grid), dim3(512), lds, st, a, items);
+    else hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false>), dim3(grid), dim3(512), lds, st, a, items);
+  }
+  return hipGetLastError();
+}
+
 
 }  // namespace fisr

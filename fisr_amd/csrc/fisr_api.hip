@@ -326,39 +326,6 @@ void pack_weights_wino(const float* w, int ci, int co, int cin_pad, std::vector<
     }
 }
 
-// Winograd F(4x4,3x3) weights (conv3x3_wf4.h): U = G g G^T per (ci, co) with the 6x3 G of the interpolation points 0, +-1, +-2, inf,
-// computed in double and rounded once to fp32, stored as the kernel's LDS image
-// [Cin/4][CoutPad/64][position quad 9][channel quarter 4][ci 4][channel 16][4 positions].
-void pack_weights_wf4(const float* w, int ci, int co, int cin_pad, std::vector<char>& wp) {
-  static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-  const int nb = (co + F4_BN - 1) / F4_BN, nch = cin_pad / F4_CH;
-  wp.assign((size_t)nch * nb * F4_U_BYTES, 0);
-  for (int c = 0; c < ci; ++c)
-    for (int n = 0; n < co; ++n) {
-      double g[3][3], t[6][3];
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) g[a][b] = w[((size_t)(a * 3 + b) * ci + c) * co + n];
-      for (int i = 0; i < 6; ++i)
-        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
-      const int kc = c / F4_CH, k = c % F4_CH, blk = n / F4_BN, q = (n % F4_BN) / 16, r = n % 16;
-      float* slab = reinterpret_cast<float*>(wp.data() + ((size_t)kc * nb + blk) * F4_U_BYTES);
-      for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
-          const int pos = i * 6 + j;
-          slab[(((pos >> 2) * 4 + q) * 64 + k * 16 + r) * 4 + (pos & 3)] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
-        }
-    }
-}
-// what conv3x3_wf4.h takes: whole 64-channel output blocks, whole 4-channel chunks per concat source, images addressed with
-// 31-bit byte offsets (the out-of-range marker of its zero padding is 2^31)
-inline bool wf4_fits(int h, int w, int c0, int c1, int co) {
-  return co % F4_BN == 0 && c0 > 0 && c0 % F4_CH == 0 && c1 % F4_CH == 0 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
-}
-// ... and where it is the faster of the two Winograd kernels (measured per map size, scripts/conv_bench.py): its 16 x 32-pixel
-// items waste more of a small map than the 8 x 32 ones of conv3x3_wino8p.h
-inline bool wf4_wins(int h, int w) { return h >= 48 && w >= 64; }
-
 // fp16 weights for the LDS-DMA kernel (conv3x3_dma.h): [Cin/16][CoutPad/64][tap 9][row 64][32-byte record] -- a slab is the
 // kernel's LDS image: rows in the MFMA row order of pack_weights, the two 16-byte halves (channels 0-7 | 8-15 of the chunk)
 // swapped when bit 3 of the row is set.
@@ -581,35 +548,6 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
   } else if (a.relu_in) FISR_W8P_LAUNCH(true, false);
   else FISR_W8P_LAUNCH(false, false);
 #undef FISR_W8P_LAUNCH
-  return hipGetLastError();
-}
-
-// The F(4x4,3x3) Winograd kernel (conv3x3_wf4.h; fp32, FISRnet's dense layers only; a.wpk = the conv's d_wu4).
-hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
-  static bool attr_done[64] = {};
-  constexpr size_t lds = wf4_lds_bytes();
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  if (!attr_done[dev]) {
-    const void* kerns[] = {reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true>),
-                           reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, true>)};
-    for (const void* k : kerns) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    attr_done[dev] = true;
-  }
-  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && a.dil == 1;
-  if (!plain || !wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s) || a.CoutPad != a.Cout) return hipErrorInvalidValue;
-  const int items = ((a.W + F4_TW - 1) / F4_TW) * ((a.H + F4_TH - 1) / F4_TH) * a.N * (a.CoutPad / F4_BN);
-  if (a.relu_in) {
-    if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<true, true>), dim3(items), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3_wf4_kernel<true, false>), dim3(items), dim3(512), lds, st, a);
-  } else {
-    if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true>), dim3(items), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false>), dim3(items), dim3(512), lds, st, a);
-  }
   return hipGetLastError();
 }
 

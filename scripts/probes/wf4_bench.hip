@@ -1,0 +1,127 @@
+// Stand-alone micro-benchmark + self-check of the F(4x4,3x3) Winograd kernel (conv3x3_wf4.h): builds in seconds, for kernel
+// iterations.  Diagnostics only (the parity tests of record are tests/test_gpu_parity.py through the C-ABI).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ifisr_amd/csrc -Iinclude scripts/probes/wf4_bench.hip -o scripts/probes/wf4_bench
+//   wf4_bench [check]      shapes: WF4_SHAPES="n,h,w,cin,cout,flags,res;..."
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "conv3x3_wf4.h"
+using namespace fisr;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// direct fp32 reference on the GPU (one thread per output element; fp64 accumulation)
+__global__ void ref_conv(const float* in, const float* w, const float* b, const float* res, float* out, int N, int H, int W, int Ci, int Co,
+                         int relu_in, int relu_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * H * W * Co) return;
+  const int co = i % Co;
+  size_t p = i / Co;
+  const int x = p % W; p /= W;
+  const int y = p % H;
+  const int n = p / H;
+  double s = b[co];
+  for (int a = 0; a < 3; ++a)
+    for (int c = 0; c < 3; ++c) {
+      const int yy = y + a - 1, xx = x + c - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const float* ip = in + ((size_t)(n * H + yy) * W + xx) * Ci;
+      const float* wp = w + (size_t)(a * 3 + c) * Ci * Co + co;
+      for (int k = 0; k < Ci; ++k) { float v = ip[k]; if (relu_in) v = fmaxf(v, 0.f); s += (double)v * wp[(size_t)k * Co]; }
+    }
+  if (res) s += res[i];
+  if (relu_out) s = s > 0 ? s : 0;
+  out[i] = (float)s;
+}
+
+int main(int argc, char** argv) {
+  const bool check = argc > 1 && !strcmp(argv[1], "check");
+  std::string shapes = getenv("WF4_SHAPES") ? getenv("WF4_SHAPES")
+                     : check ? "1,40,100,64,64,3,1;2,24,24,64,128,1,0;1,17,45,16,64,0,0"
+                             : "12,544,992,64,64,3,1;12,544,992,64,64,0,0;12,272,496,128,128,3,1;12,136,248,256,256,3,1;12,68,124,512,512,3,1;12,136,248,512,256,2,0";
+  size_t pos = 0;
+  while (pos < shapes.size()) {
+    size_t e = shapes.find(';', pos);
+    if (e == std::string::npos) e = shapes.size();
+    int n, h, w, ci, co, fl, rs;
+    if (sscanf(shapes.substr(pos, e - pos).c_str(), "%d,%d,%d,%d,%d,%d,%d", &n, &h, &w, &ci, &co, &fl, &rs) != 7) break;
+    pos = e + 1;
+    const size_t in_e = (size_t)n * h * w * ci, out_e = (size_t)n * h * w * co;
+    std::vector<float> hw((size_t)9 * ci * co), hb(co), hin(in_e), hres(rs ? out_e : 0);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((int)(st >> 9) % 2001 - 1000) * 1e-3f; };
+    for (auto& v : hw) v = rnd() * sqrtf(2.f / (9 * ci)) * 1.7f;
+    for (auto& v : hb) v = rnd();
+    for (auto& v : hin) v = rnd() * 1.7f;
+    for (auto& v : hres) v = rnd();
+    std::vector<char> wp;
+    pack_weights_wf4(hw.data(), ci, co, ci, wp);
+    float *d_in, *d_out, *d_res = nullptr, *d_b, *d_w, *d_ref = nullptr;
+    void* d_wp;
+    CK(hipMalloc(&d_in, in_e * 4)); CK(hipMalloc(&d_out, out_e * 4)); CK(hipMalloc(&d_b, co * 4)); CK(hipMalloc(&d_wp, wp.size()));
+    CK(hipMemcpy(d_in, hin.data(), in_e * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_b, hb.data(), co * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_wp, wp.data(), wp.size(), hipMemcpyHostToDevice));
+    if (rs) { CK(hipMalloc(&d_res, out_e * 4)); CK(hipMemcpy(d_res, hres.data(), out_e * 4, hipMemcpyHostToDevice)); }
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.in0 = d_in; a.wpk = d_wp; a.bias = d_b; a.res = d_res; a.out = d_out;
+    a.C0 = ci; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = co; a.CoutPad = co;
+    a.in0_cs = ci; a.rec_cs = co; a.dil = 1;
+    a.relu_in = fl & 1; a.relu_out = (fl >> 1) & 1; a.d2s = 0;
+    const int items = ((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n * (co / F4_BN);
+    unsigned long long* d_tr;
+    CK(hipMalloc(&d_tr, (size_t)items * 64)); CK(hipMemset(d_tr, 0, (size_t)items * 64));
+    if (check) {
+      CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_ref, out_e * 4));
+      CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+      CK(launch_conv_wf4(a, nullptr));
+      hipLaunchKernelGGL(ref_conv, dim3((out_e + 255) / 256), dim3(256), 0, nullptr, d_in, d_w, d_b, d_res, d_ref, n, h, w, ci, co, fl & 1, (fl >> 1) & 1);
+      CK(hipDeviceSynchronize());
+      std::vector<float> o(out_e), r(out_e);
+      CK(hipMemcpy(o.data(), d_out, out_e * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(r.data(), d_ref, out_e * 4, hipMemcpyDeviceToHost));
+      double mx = 0, ss = 0; size_t bad = 0;
+      for (size_t i = 0; i < out_e; ++i) { double d = fabs((double)o[i] - r[i]); if (!(d <= 1e-3)) ++bad; if (d > mx) mx = d; ss += d * d; }
+      printf("check %dx%dx%d %d->%d f%d r%d: max %.3e rms %.3e bad %zu %s\n", n, h, w, ci, co, fl, rs, mx, sqrt(ss / out_e), bad, bad ? "FAIL" : "ok");
+      CK(hipFree(d_w)); CK(hipFree(d_ref));
+    } else {
+      for (int i = 0; i < 2; ++i) CK(launch_conv_wf4(a, nullptr));
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      const int iters = 5;
+      CK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < iters; ++i) CK(launch_conv_wf4(a, nullptr));
+      CK(hipEventRecord(e1, nullptr));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / iters;
+      // one traced launch: per-workgroup {start, K-loop end, end, after output transform, after prologue, ...}
+      a.trace = d_tr;
+      CK(launch_conv_wf4(a, nullptr));
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> tr((size_t)items * 8);
+      CK(hipMemcpy(tr.data(), d_tr, (size_t)items * 64, hipMemcpyDeviceToHost));
+      // persistent kernel: one row per workgroup {start, first item's K-loop end, end, first item's end, after prologue, real start, real end, items done}
+      std::vector<double> life, pro, main_, epi, clk, per_item;
+      for (int i = 0; i < items && i < 256; ++i) {
+        const unsigned long long* t = &tr[(size_t)i * 8];
+        if (t[2] <= t[0] || t[7] == 0) continue;
+        life.push_back((double)(t[2] - t[0])); pro.push_back((double)(t[4] - t[0])); main_.push_back((double)(t[1] - t[4])); epi.push_back((double)(t[3] - t[1]));
+        per_item.push_back((double)(t[2] - t[0]) / (double)t[7]);
+        if (t[6] > t[5]) clk.push_back((double)(t[2] - t[0]) / (double)(t[6] - t[5]) * 100.0);
+      }
+      auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return v[v.size() / 2]; };
+      const int nch = ci / 4;
+      printf("%2dx%dx%d %3d->%3d f%d r%d: %8.1f us %6.1f TF | items/CU %.1f cycles/item %.0f (MFMA %d) | first item: prologue %.0f K loop %.0f (%.0f per chunk) epilogue %.0f | clk %.0f MHz\n",
+             n, h, w, ci, co, fl, rs, us, 2.0 * 9 * ci * co * n * h * w / us / 1e6, items / 256.0, med(per_item), nch * 2304, med(pro), med(main_), med(main_) / nch, med(epi), med(clk));
+    }
+    CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_b)); CK(hipFree(d_wp)); CK(hipFree(d_tr));
+    if (d_res) CK(hipFree(d_res));
+  }
+  return 0;
+}

@@ -3,7 +3,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, n, h, w, ci, co, fl, rs = sys.argv[1], *map(int, sys.argv[2:9])
-prec = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
+prec = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4, "fp32w4": 8}[sys.argv[9] if len(sys.argv) > 9 else "bf16x3"]
 # needs a diagnostics build (-DFISR_DIAG: the shipped library has no trace hook): FISR_HIP_SO=build_ab/libfisr_hip_diag.so,
 # made by `python -c "from fisr_amd import lib; lib.build(diag=True)"` (or any A/B build of scripts/gpu_ablate.sh)
 os.environ.setdefault("FISR_HIP_SO", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_ab", "libfisr_hip_diag.so"))
