@@ -183,6 +183,8 @@ def _pmc_table():
 def _pmc_key(name):
     if name.startswith("conv3x3_dma"):
         return "conv3x3_dma_f16_kernel<false>"
+    if name.startswith("conv3x3_wf4"):
+        return "conv3x3_wf4_kernel<%s, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
     tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
     if name.startswith("conv3x3_wino"):
         return "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
@@ -641,7 +643,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=sorted(PEAK))
-    ap.add_argument("--others", default="fp32d,bf16x3,f16f8,mixed",
+    ap.add_argument("--others", default="fp32w,fp32d,bf16x3,f16f8,mixed",
                     help="further engines timed on rank 0 at N=1 under other_precisions ('' = none)")
     ap.add_argument("--parallelism", default="frame", choices=["frame", "tile"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")

@@ -19,7 +19,7 @@
 //     transposition (conv3x3_wino8p.h splits the positions over two waves and spends 10-14 % of a 64-channel item on that
 //     exchange and on the DPP transposes behind it).  The accumulator layout of the 16x16 MFMA gives a lane 4 consecutive channels
 //     of one tile: every output pixel is one 16-byte store, four lanes cover a 64-byte record.
-//   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (151 552 B):
+//   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (153 600 B):
 //       U[2]    36 positions x 64 channels x 4 ci       LDS-DMA of the host-made slab (the LDS image), one chunk ahead
 //       V[2]    36 positions x 32 tiles x 4 ci          B^T d B of the NEXT chunk, computed by waves 0-3 while everybody multiplies
 //       RAW[4]  18 x 34 halo pixels x 16 B              LDS-DMA from the activation tensor, four chunks ahead
@@ -54,7 +54,7 @@ constexpr int F4_V_BYTES = 36 * 32 * F4_CH * 4;        // 18432
 // Position (i, j) of the 6 x 6 transform grid lives in slot 6 i + F4_PERM[j] of V, U and the accumulators: the order in which the
 // packed horizontal pass of the input transform leaves its outputs (t0 t5 t1 t3 t2 t4).
 __host__ __device__ constexpr int wf4_slot(int i, int j) { return 6 * i + (j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 4 : j == 3 ? 3 : j == 4 ? 5 : 1); }
-constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 4 * F4_RAW_BYTES; }   // 151552
+constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 4 * F4_RAW_BYTES + 2048; }   // 153600 (+ a 2 KB sink of the residual prefetch)
 
 // FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
 // 2 no raw copies, 4 no input transform, 8 weight copies waited for one iteration later (latency vs bandwidth), 16 no MFMAs
@@ -216,6 +216,29 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       asm("v_max_f32 %0, 0, %0" : "+v"(f.x)); asm("v_max_f32 %0, 0, %0" : "+v"(f.y));
       asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
       *reinterpret_cast<f32x4*>(b + j * 4096) = f;
+    }
+  };
+
+  // Residual prefetch: the epilogue of an item adds 16 x 16 bytes per lane of the residual tensor, which nobody has touched since
+  // the previous layer: with the loads issued in the epilogue every wave of the CU sat through an HBM round trip per item
+  // (11k cycles of an 82k-cycle 64 -> 64 item).  There is no register to request them into earlier (64 per lane), so two iterations
+  // before the end of an item every wave TOUCHES its share of the tile's 128-byte lines -- one dword per line, LDS-DMA into a sink
+  // nobody reads -- and the epilogue's loads hit L2.
+  const unsigned sink_lds = (unsigned)(size_t)(wf4_lds_ptr_t)(sR + 4 * F4_RAW_BYTES) + (unsigned)wave * 256u;
+  auto prefetch_res = [&](const Item& it) __attribute__((always_inline)) {
+    const unsigned img_bytes = (unsigned)(img_px * p.Cout * 4);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((char*)p.res + (size_t)it.nb * img_px * p.Cout * 4, 0, img_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      const int idx = wave * 128 + i * 64 + l;
+      const int pix = idx >> 1, py = pix >> 5, px = pix & 31;
+      const int gy = it.y0 + py, gx = it.x0 + px;
+      const unsigned o = (gy < p.H && gx < p.W) ? ((unsigned)(gy * p.W + gx) * (unsigned)p.Cout + (unsigned)(it.nblk * F4_BN)) * 4u + (unsigned)(idx & 1) * 128u : OOB;
+      unsigned keep_;
+      asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dword %[o], %[rs], 0 offen lds\n\ts_mov_b32 m0, %[keep]"
+                   : [keep] "=&s"(keep_) : [rs] "s"(rr), [lds] "s"(sink_lds), [o] "v"(o) : "memory", "scc");
     }
   };
 
@@ -383,6 +406,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     constexpr bool FIRST = decltype(first_tag)::value;     // first chunk of an item
     typedef typename std::conditional<ROLE == 1, rh1_t, rh0_t>::type RH;
     const int buf = par;
+    if constexpr (HAS_RES) { if (k == nch - 2) prefetch_res(cur); }     // (older than this iteration's copies: landed by its end)
     const char* ub = fu + buf * F4_U_BYTES;
     const char* vb = fv + buf * F4_V_BYTES;
     // U(k+1): of this item, of the next item (chunk 0), or a repeated chunk behind the last item
@@ -604,9 +628,11 @@ inline void pack_weights_wf4(const float* w, int ci, int co, int cin_pad, std::v
 inline bool wf4_fits(int h, int w, int c0, int c1, int co) {
   return co % F4_BN == 0 && c0 > 0 && c0 % F4_CH == 0 && c1 % F4_CH == 0 && (c0 + c1) / F4_CH >= 4 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
 }
-// ... and where it is the faster of the two Winograd kernels (measured per map size, scripts/conv_bench.py): its 16 x 32-pixel
-// items waste more of a small map than the 8 x 32 ones of conv3x3_wino8p.h
-inline bool wf4_wins(int h, int w) { return h >= 48 && w >= 64; }
+// ... and where it is the faster of the two Winograd kernels (measured per map size and depth, scripts/conv_bench.py, 12 tiles:
+// 68 x 124 maps 1.2-1.35x at every channel count, 34 x 62 maps 0.72-0.77x with 64-256 channels -- its 16 x 32-pixel items waste
+// more of a small map than the 8 x 32 ones of conv3x3_wino8p.h -- but 1.04x / 1.4x on the 512-channel 34 x 62 / 17 x 31 maps,
+// where the K loop is long enough to pay for the padding)
+inline bool wf4_wins(int h, int w, int cin) { return (h >= 48 && w >= 64) || cin >= 512; }
 
 // The F(4x4,3x3) Winograd kernel (conv3x3_wf4.h; fp32, FISRnet's dense layers only; a.wpk = the conv's d_wu4).
 inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {

@@ -726,7 +726,7 @@ struct Runner {
     const double px = (double)n * h * w;
     const bool use_wino = std::is_same<T, float>::value && ctx->wino && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cw.co);
     if (use_wino) a.wpk = cw.d_wu;
-    const bool use_wf4 = std::is_same<T, float>::value && ctx->wf4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cw.co) && wf4_wins(h, w);
+    const bool use_wf4 = std::is_same<T, float>::value && ctx->wf4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cw.co) && wf4_wins(h, w, c0 + c1);
     if (use_wf4) a.wpk = cw.d_wu4;
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     const bool use_dma = std::is_same<T, _Float16>::value && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);

@@ -28,10 +28,11 @@ from . import tiling
 from . import weights as _weights
 from .lib import FisrError
 
-# "fp32" is the fp32 engine as it ships: fp32 tensors, fp32 arithmetic, Winograd F(2x2,3x3) for the 132 convs with
-# Cout % 64 == 0 (what cuDNN does for the reference's TF 1.13) -- "fp32w" names it explicitly; "fp32d" is the same
-# engine with the direct (exact fmaf-chain) MFMA kernel for every conv.
-_PREC = {"fp32": _lib.PREC_F32W, "f32": _lib.PREC_F32W, "float32": _lib.PREC_F32W, "fp32w": _lib.PREC_F32W,
+# "fp32" is the fp32 engine as it ships: fp32 tensors, fp32 arithmetic, Winograd minimal filtering for the 132 convs with
+# Cout % 64 == 0 (what cuDNN does for the reference's TF 1.13) -- F(4x4,3x3) on the maps where it is the faster kernel (r03:
+# conv3x3_wf4.h, "fp32w4" names it explicitly), F(2x2,3x3) elsewhere; "fp32w" is the all-F(2x2) engine of round 2; "fp32d" the
+# same engine with the direct (exact fmaf-chain) MFMA kernel for every conv.
+_PREC = {"fp32": _lib.PREC_F32W4, "f32": _lib.PREC_F32W4, "float32": _lib.PREC_F32W4, "fp32w": _lib.PREC_F32W,
          "fp32d": _lib.PREC_F32, "fp32w4": _lib.PREC_F32W4,      # F(4x4,3x3) Winograd for the large maps (conv3x3_wf4.h)
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
          "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8, "mixed": _lib.PREC_MIXED,
@@ -41,7 +42,7 @@ _PREC = {"fp32": _lib.PREC_F32W, "f32": _lib.PREC_F32W, "float32": _lib.PREC_F32
 # ONE default arithmetic for every entry point (FISRnet(), main.py, bench.py): the reference computes in
 # fp32 (cfg2 of BASELINE.json), so the default is the fp32 engine; the split-precision modes are opt-in.
 DEFAULT_PRECISION = "fp32"
-PRECISIONS = ("fp32", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16", "fp16r", "mixedr")     # CLI names
+PRECISIONS = ("fp32", "fp32w4", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16", "fp16r", "mixedr")     # CLI names
 
 
 def _torch():

@@ -21,7 +21,7 @@ from fisr_amd import weights  # noqa: E402
 from fisr_amd.fisrnet import FISRnet  # noqa: E402
 
 # engine -> (max |err| relative to the largest |oracle value| of the level, allowed PSNR shift in dB)
-ENGINES = {"fp32d": (3e-5, 2e-4), "fp32": (1e-4, 5e-4), "bf16x3": (5e-4, 0.004), "f16f8": (2e-3, 0.01),
+ENGINES = {"fp32d": (3e-5, 2e-4), "fp32": (1e-4, 5e-4), "fp32w4": (1e-4, 5e-4), "bf16x3": (5e-4, 0.004), "f16f8": (2e-3, 0.01),
            "mixed": (1e-2, 0.008)}     # (levels 1 and 2 of the mixed engine are plain fp16: the relative bound is fp16's)
 
 
