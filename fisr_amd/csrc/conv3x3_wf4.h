@@ -19,7 +19,7 @@
 //     transposition (conv3x3_wino8p.h splits the positions over two waves and spends 10-14 % of a 64-channel item on that
 //     exchange and on the DPP transposes behind it).  The accumulator layout of the 16x16 MFMA gives a lane 4 consecutive channels
 //     of one tile: every output pixel is one 16-byte store, four lanes cover a 64-byte record.
-//   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (153 600 B):
+//   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (151 552 B):
 //       U[2]    36 positions x 64 channels x 4 ci       LDS-DMA of the host-made slab (the LDS image), one chunk ahead
 //       V[2]    36 positions x 32 tiles x 4 ci          B^T d B of the NEXT chunk, computed by waves 0-3 while everybody multiplies
 //       RAW[4]  18 x 34 halo pixels x 16 B              LDS-DMA from the activation tensor, four chunks ahead
@@ -54,12 +54,15 @@ constexpr int F4_V_BYTES = 36 * 32 * F4_CH * 4;        // 18432
 // Position (i, j) of the 6 x 6 transform grid lives in slot 6 i + F4_PERM[j] of V, U and the accumulators: the order in which the
 // packed horizontal pass of the input transform leaves its outputs (t0 t5 t1 t3 t2 t4).
 __host__ __device__ constexpr int wf4_slot(int i, int j) { return 6 * i + (j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 4 : j == 3 ? 3 : j == 4 ? 5 : 1); }
-constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 4 * F4_RAW_BYTES + 2048; }   // 153600 (+ a 2 KB sink of the residual prefetch)
+constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 4 * F4_RAW_BYTES; }   // 151552
 
 // FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
 // 2 no raw copies, 4 no input transform, 8 weight copies waited for one iteration later (latency vs bandwidth), 16 no MFMAs
 #ifndef FISR_F4ABL
 #define FISR_F4ABL 0
+#endif
+#ifndef FISR_F4_STORE_AUX
+#define FISR_F4_STORE_AUX 0      // cache policy of the output stores (A/B hook; 2 = nontemporal: 1-2 % slower on the residual layers)
 #endif
 #define FISR_F4_BEGIN(KEEP, LDS)   "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
 #define FISR_F4_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen lds\n\t"
@@ -122,6 +125,11 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   const int nch0 = p.C0 / F4_CH, nch = (p.C0 + p.C1) / F4_CH;       // (the launcher guarantees nch >= 4)
 
   if (FISR_F4ABL & 128) { for (int i = 0; i < (int)((blockIdx.x * 7u) & 31u); ++i) __builtin_amdgcn_s_sleep(4); }     // ablation: de-phase the workgroups
+#ifdef FISR_F4_PRIO
+  if (FISR_F4_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // A/B: static priority for the younger / the older half
+  if (FISR_F4_PRIO == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
+  if (FISR_F4_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(3);
+#endif
   unsigned long long t_start = 0, t_first = 0, t_main = 0, t_end1 = 0, t_real = 0;
   if (p.trace) { t_start = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
 
@@ -219,28 +227,10 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     }
   };
 
-  // Residual prefetch: the epilogue of an item adds 16 x 16 bytes per lane of the residual tensor, which nobody has touched since
-  // the previous layer: with the loads issued in the epilogue every wave of the CU sat through an HBM round trip per item
-  // (11k cycles of an 82k-cycle 64 -> 64 item).  There is no register to request them into earlier (64 per lane), so two iterations
-  // before the end of an item every wave TOUCHES its share of the tile's 128-byte lines -- one dword per line, LDS-DMA into a sink
-  // nobody reads -- and the epilogue's loads hit L2.
-  const unsigned sink_lds = (unsigned)(size_t)(wf4_lds_ptr_t)(sR + 4 * F4_RAW_BYTES) + (unsigned)wave * 256u;
-  auto prefetch_res = [&](const Item& it) __attribute__((always_inline)) {
-    const unsigned img_bytes = (unsigned)(img_px * p.Cout * 4);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((char*)p.res + (size_t)it.nb * img_px * p.Cout * 4, 0, img_bytes, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int l = lane;
-      asm volatile("" : "+v"(l));
-      const int idx = wave * 128 + i * 64 + l;
-      const int pix = idx >> 1, py = pix >> 5, px = pix & 31;
-      const int gy = it.y0 + py, gx = it.x0 + px;
-      const unsigned o = (gy < p.H && gx < p.W) ? ((unsigned)(gy * p.W + gx) * (unsigned)p.Cout + (unsigned)(it.nblk * F4_BN)) * 4u + (unsigned)(idx & 1) * 128u : OOB;
-      unsigned keep_;
-      asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dword %[o], %[rs], 0 offen lds\n\ts_mov_b32 m0, %[keep]"
-                   : [keep] "=&s"(keep_) : [rs] "s"(rr), [lds] "s"(sink_lds), [o] "v"(o) : "memory", "scc");
-    }
-  };
+  // (Measured and dropped: touching the residual tile's 128-byte lines ahead of the epilogue -- one dword per line into a register
+  //  nobody reads, all 1024 lines two iterations before the end or 256 per iteration over the last four -- so that the epilogue's
+  //  loads would hit L2.  The epilogue of a residual layer did shrink by 4k cycles, but the K loop grew by 10-15k: a CU gets ~10
+  //  bytes per cycle out of HBM (its outstanding misses over the HBM latency) wherever the 128 KB are requested.)
 
   // =========================== transform side (waves 0-3: tile half wave & 1, transform rows 3 (wave >> 1) ..) ===========================
   // lane -> (channel of the chunk, tile): 8 tiles of one tile row x 4 channels per ds_read_b32 phase.  The two waves of a tile
@@ -406,7 +396,6 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     constexpr bool FIRST = decltype(first_tag)::value;     // first chunk of an item
     typedef typename std::conditional<ROLE == 1, rh1_t, rh0_t>::type RH;
     const int buf = par;
-    if constexpr (HAS_RES) { if (k == nch - 2) prefetch_res(cur); }     // (older than this iteration's copies: landed by its end)
     const char* ub = fu + buf * F4_U_BYTES;
     const char* vb = fv + buf * F4_V_BYTES;
     // U(k+1): of this item, of the next item (chunk 0), or a repeated chunk behind the last item
@@ -476,12 +465,19 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   typedef std::integral_constant<int, 0> role0_t;
   typedef std::integral_constant<int, 1> role1_t;
   typedef std::integral_constant<int, 2> role2_t;
+  unsigned long long t2[6] = {0, 0, 0, 0, 0, 0};   // timeline of the workgroup's SECOND item (steady state), trace runs only
+  int n_done = 0;
   auto k_loop = [&](auto role_tag) __attribute__((always_inline)) {
+    const bool tr2 = p.trace && n_done == 1;
+    if (tr2) t2[0] = __builtin_readcyclecounter();
     k_iter(role_tag, first_t{}, 0);
-    for (int k = 1; k < nch; ++k) k_iter(role_tag, rest_t{}, k);
+    if (tr2) t2[1] = __builtin_readcyclecounter();
+    k_iter(role_tag, rest_t{}, 1);
+    if (tr2) t2[2] = __builtin_readcyclecounter();
+    for (int k = 2; k < nch; ++k) k_iter(role_tag, rest_t{}, k);
+    if (tr2) t2[3] = __builtin_readcyclecounter();
   };
 
-  int n_done = 0;
   for (;;) {                                       // ---- work items of this workgroup ----
     {
       int l = lane;
@@ -512,18 +508,28 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       const unsigned out_bytes = p.d2s ? ((unsigned)(4 * p.H * p.W) << cq_shift) * 4u : (unsigned)(p.H * p.W) * (unsigned)p.Cout * 4u;
       const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
           (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4 : (size_t)cur.nb * img_px * p.Cout * 4), 0, out_bytes, 0x00020000);
-      const float relu_lo = p.relu_out ? 0.f : -__builtin_huge_valf();
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      // Record (i, j) of the lane's 4 x 4 pixels sits at byte  vbase + 4 (i sA + j sB):  one lane offset + a UNIFORM offset that rides
+      // in the scalar-offset operand of the buffer instruction -- no vector instruction per record (they are paid in full beside the
+      // MFMAs' pipe: the epilogue is bound by its vector instruction count).  Lanes outside the image get an offset behind the
+      // buffer's end (loads return zeros, stores are dropped); only a tile on the image's right / bottom edge needs that per record.
+      const int oy0 = cur.y0 + 4 * e_ty, ox0 = cur.x0 + 4 * e_tx;
+      const unsigned vbase = c_ok ? ((unsigned)oy0 * sA + (unsigned)ox0 * sB + vC) * 4u : OOB;
+      const bool interior = cur.y0 + F4_TH <= p.H && cur.x0 + F4_TW <= p.W;      // (uniform)
       unsigned off[4][4];
+      if (!interior) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int oy = cur.y0 + 4 * e_ty + i;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ox = cur.x0 + 4 * e_tx + j;
-          off[i][j] = (c_ok & (oy < p.H) & (ox < p.W)) ? ((unsigned)oy * sA + (unsigned)ox * sB + vC) * 4u : OOB;
-        }
+          for (int j = 0; j < 4; ++j) off[i][j] = ((oy0 + i < p.H) & (ox0 + j < p.W)) ? vbase : OOB;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) off[i][j] = vbase;
       }
+      const unsigned sA4 = sA * 4u, sB4 = sB * 4u;
+#define FISR_F4_SOFF(I, J) ((unsigned)(I) * sA4 + (unsigned)(J) * sB4)
       // output transform, packed on the channel pairs (r0, r1), (r2, r3) of every accumulator: rows first (W = M A, 6 x 4 per pair),
       // then columns (Y = A^T W).  The residual records are requested after the first half of the row pass -- from there on the
       // dead halves of the accumulators make room for them -- and arrive under the rest of the transform.
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         y3 = pk_add(pk_fma(d2, K8, d1), m5);
       };
       f32x2 yp[4][4][2];                           // [row][column][channel pair]
+      if (p.trace && n_done == 1) t2[4] = __builtin_readcyclecounter();
       f32x4 res[4][4];
       auto half = [&](auto h_tag) __attribute__((always_inline)) {
         constexpr int h = decltype(h_tag)::value;
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) res[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[i][j], 0, 0));
+              for (int j = 0; j < 4; ++j) res[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[i][j], FISR_F4_SOFF(i, j), 0));
           }
         }
 #pragma unroll
@@ -567,12 +574,16 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           f32x2 lo = yp[i][j][0], hi = yp[i][j][1];
           if constexpr (HAS_RES) { lo = pk_add(lo, f32x2{res[i][j].x, res[i][j].y}); hi = pk_add(hi, f32x2{res[i][j].z, res[i][j].w}); }
           f32x4 o = {lo.x, lo.y, hi.x, hi.y};
+          if (p.relu_out) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, %1, %0" : "+v"(o[e]) : "s"(relu_lo));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], 0, 2);   // aux 2: nontemporal
+            for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %0" : "+v"(o[e]));
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF(i, j), FISR_F4_STORE_AUX);
         }
     }
+    if (FISR_F4ABL & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ablation: wait for the stores here
     if (p.trace && n_done == 0) t_end1 = __builtin_readcyclecounter();
+    if (p.trace && n_done == 1) t2[5] = __builtin_readcyclecounter();
     ++n_done;
     if (!has_next) break;
     b_cur += gridDim.x;
@@ -581,6 +592,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the repeated copies behind the last item still write LDS)
+#undef FISR_F4_SOFF
 #undef FISR_F4_MMA4
 #undef FISR_F4_MMA4Z
 #undef FISR_F4_MMA4C
@@ -589,6 +601,11 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
     tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
     tr[3] = t_end1; tr[4] = t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)n_done;
+  }
+  if (p.trace && (tid & 63) == 0 && n_done > 1) {   // second row block: per WAVE {item start, after iteration 0, 1, K loop end, epilogue start of the stores.., end}
+    unsigned long long* tr = p.trace + ((size_t)gridDim.x + (size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tr[i] = t2[i];
   }
 }
 

@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
     a.relu_in = fl & 1; a.relu_out = (fl >> 1) & 1; a.d2s = 0;
     const int items = ((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n * (co / F4_BN);
     unsigned long long* d_tr;
-    CK(hipMalloc(&d_tr, (size_t)items * 64)); CK(hipMemset(d_tr, 0, (size_t)items * 64));
+    const size_t tr_rows = (size_t)items + 256 * 9;
+    CK(hipMalloc(&d_tr, tr_rows * 64)); CK(hipMemset(d_tr, 0, tr_rows * 64));
     if (check) {
       CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_ref, out_e * 4));
       CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
@@ -104,8 +105,8 @@ int main(int argc, char** argv) {
       a.trace = d_tr;
       CK(launch_conv_wf4(a, nullptr));
       CK(hipDeviceSynchronize());
-      std::vector<unsigned long long> tr((size_t)items * 8);
-      CK(hipMemcpy(tr.data(), d_tr, (size_t)items * 64, hipMemcpyDeviceToHost));
+      std::vector<unsigned long long> tr(tr_rows * 8);
+      CK(hipMemcpy(tr.data(), d_tr, tr_rows * 64, hipMemcpyDeviceToHost));
       // persistent kernel: one row per workgroup {start, first item's K-loop end, end, first item's end, after prologue, real start, real end, items done}
       std::vector<double> life, pro, main_, epi, clk, per_item;
       for (int i = 0; i < items && i < 256; ++i) {
@@ -117,6 +118,21 @@ int main(int argc, char** argv) {
       }
       auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return v[v.size() / 2]; };
       const int nch = ci / 4;
+      {   // second item of each workgroup, per wave: iteration 0, iteration 1, rest of the K loop per chunk, flush + output transform, loads/stores
+        const int grid = items < 256 ? items : 256;
+        for (int role = 0; role < 2; ++role) {
+          std::vector<double> a0, a1, ar, ot, st;
+          for (int g = 0; g < grid; ++g)
+            for (int w = role * 4; w < role * 4 + 4; ++w) {
+              const unsigned long long* t = &tr[((size_t)grid + (size_t)g * 8 + w) * 8];
+              if (t[5] <= t[0] || t[0] == 0) continue;
+              a0.push_back((double)(t[1] - t[0])); a1.push_back((double)(t[2] - t[1])); ar.push_back((double)(t[3] - t[2]) / (nch - 2));
+              ot.push_back((double)(t[4] - t[3])); st.push_back((double)(t[5] - t[4]));
+            }
+          printf("    %s waves, 2nd item: iteration 0 %.0f  iteration 1 %.0f  later iterations %.0f each  flush + setup %.0f  output stage %.0f\n",
+                 role ? "copy" : "transform", med(a0), med(a1), med(ar), med(ot), med(st));
+        }
+      }
       printf("%2dx%dx%d %3d->%3d f%d r%d: %8.1f us %6.1f TF | items/CU %.1f cycles/item %.0f (MFMA %d) | first item: prologue %.0f K loop %.0f (%.0f per chunk) epilogue %.0f | clk %.0f MHz\n",
              n, h, w, ci, co, fl, rs, us, 2.0 * 9 * ci * co * n * h * w / us / 1e6, items / 256.0, med(per_item), nch * 2304, med(pro), med(main_), med(main_) / nch, med(epi), med(clk));
     }
