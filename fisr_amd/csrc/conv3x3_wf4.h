@@ -18,7 +18,7 @@
 //     the output transform A^T M A then happens in the wave's own registers -- no exchange between waves, no LDS round trip, no
 //     transposition (conv3x3_wino8p.h splits the positions over two waves and spends 10-14 % of a 64-channel item on that
 //     exchange and on the DPP transposes behind it).  The accumulator layout of the 16x16 MFMA gives a lane 4 consecutive channels
-//     of one tile: every output pixel is one 16-byte store, four lanes cover a 64-byte record.
+//     of one tile; one lane transposition (ds_bpermute_b32) puts the four lanes of a 64-byte record next to each other.
 //   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (151 552 B):
 //       U[2]    36 positions x 64 channels x 4 ci       LDS-DMA of the host-made slab (the LDS image), one chunk ahead
 //       V[2]    36 positions x 32 tiles x 4 ci          B^T d B of the NEXT chunk, computed by waves 0-3 while everybody multiplies
@@ -491,14 +491,21 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     FISR_F4_MMA4(8, ra[2], rb[2])                  // the last chunk's pending quad
     if (p.trace && n_done == 0) t_main = __builtin_readcyclecounter();
 
-    // ---- epilogue: Y = A^T M A in registers, + bias (+ residual), relu, 16-byte stores.  No LDS, no barrier: V / U / RAW already
-    //      belong to the next item.  lane: tile th * 16 + (lane & 15) -> tile row / column, channels c0 .. c0 + 3
+    // ---- epilogue: Y = A^T M A in registers (the bias came in through accumulator (1,1)), lane transposition, (+ residual), relu,
+    //      16-byte stores.  No LDS memory, no barrier: V / U / RAW already belong to the next item.
+    //      The accumulators give lane (tile = l & 15, channel group = l >> 4) four channels of a pixel: the four lanes that make up
+    //      a 64-byte record are 16 lanes apart, and the memory pipeline merges ADJACENT lanes only -- stored like that, every lane is
+    //      its own 16-byte request (1024 per wave and item; the stores cost 11k cycles of a 72k-cycle 64 -> 64 item, the residual
+    //      loads as much again).  So the outputs are transposed across the lanes first (ds_bpermute_b32: the LDS crossbar, no LDS
+    //      memory): lane l takes tile l >> 2, channel group l & 3 -- four neighbouring lanes move one 64-byte record, and the residual
+    //      is loaded in that layout directly.
     {
       int l = lane;
       asm volatile("" : "+v"(l));                  // (recomputed per item: see raw_geom)
-      const int e_t = th * 16 + (l & 15);
+      const int bp_addr = (((l & 3) << 4) | (l >> 2)) << 2;       // byte address of the SOURCE lane of the transposition
+      const int e_t = th * 16 + (l >> 2);
       const int e_ty = e_t >> 3, e_tx = e_t & 7;
-      const int c0 = cur.nblk * F4_BN + cq * 16 + 4 * (l >> 4);
+      const int c0 = cur.nblk * F4_BN + cq * 16 + 4 * (l & 3);
       const bool c_ok = c0 < p.Cout;
       const int cq_shift = p.d2s_shift;
       const unsigned sub = (unsigned)c0 >> cq_shift;
@@ -571,14 +578,19 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x2 lo = yp[i][j][0], hi = yp[i][j][1];
-          if constexpr (HAS_RES) { lo = pk_add(lo, f32x2{res[i][j].x, res[i][j].y}); hi = pk_add(hi, f32x2{res[i][j].z, res[i][j].w}); }
-          f32x4 o = {lo.x, lo.y, hi.x, hi.y};
+          const float y0 = yp[i][j][0][0], y1 = yp[i][j][0][1], y2 = yp[i][j][1][0], y3 = yp[i][j][1][1];
+          f32x4 o;
+          o[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y0)));
+          o[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y1)));
+          o[2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y2)));
+          o[3] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y3)));
+          if constexpr (HAS_RES) o += res[i][j];
           if (p.relu_out) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %0" : "+v"(o[e]));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF(i, j), FISR_F4_STORE_AUX);
+          if (!(FISR_F4ABL & 512) || (i == 0 && j == 0))        // (ablation 512: one store per lane instead of 16)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF(i, j), FISR_F4_STORE_AUX);
         }
     }
     if (FISR_F4ABL & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ablation: wait for the stores here
