@@ -22,7 +22,7 @@
 //   * K loop over 4-channel chunks (= the K of one MFMA), ONE barrier per chunk; LDS (151 552 B):
 //       U[2]    36 positions x 64 channels x 4 ci       LDS-DMA of the host-made slab (the LDS image), one chunk ahead
 //       V[2]    36 positions x 32 tiles x 4 ci          B^T d B of the NEXT chunk, computed by waves 0-3 while everybody multiplies
-//       RAW[4]  18 x 34 halo pixels x 16 B              LDS-DMA from the activation tensor, four chunks ahead
+//       RAW[2]  18 x 34 halo pixels x 32 B              LDS-DMA from the activation tensor: PAIRS of chunks, one pair ahead
 //     Every global byte goes global -> LDS by `buffer_load_dwordx4 ... lds` from inline asm (see conv3x3_dma.h: hidden from the
 //     compiler, counted by hand; a lane whose offset lies behind the buffer's end writes ZEROS -- the zero padding is free).
 //   * Fragments are 16-byte reads of four consecutive positions (9 + 9 ds_read_b128 feed the 36 MFMAs of a chunk): U as
@@ -144,21 +144,27 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   constexpr unsigned OOB = 0x80000000u;
   const size_t img_px = (size_t)p.H * p.W;
   // the raw stream's item: pixel index of this lane's halo slots (or -1: outside the image), the image's buffer resources
-  int rpix[3] = {-1, -1, -1};
+  // raw pieces of this wave (4-7): piece cw + 4 j, j = 0..4, of the 20 1-KB pieces of a raw PAIR (two consecutive 4-channel chunks,
+  // 32 bytes per pixel).  Lanes 2 i, 2 i + 1 of a piece fetch the two chunks of ONE pixel -- 32 contiguous bytes, 32 instead of 64
+  // memory lines per instruction (that count is what a raw copy costs: 0.6k cycles per chunk with one lane per pixel) -- into the
+  // two 16-byte halves of the pixel's LDS record, half = chunk ^ f(pixel), f = bit 2 of the halo row: the record halves alternate
+  // between the two tile rows of a transform read group, which keeps its 8 tiles x 4 channels on 32 different banks.
+  int rpix[5] = {-1, -1, -1, -1, -1};              // pixel index of the lane's halo slot per piece, or -1 (outside the image)
+  unsigned rsub = 0;                               // bit j: which chunk of the pair the lane fetches in piece j
   __amdgpu_buffer_rsrc_t rs0, rs1;
   auto raw_geom = [&](const Item& it) __attribute__((always_inline)) {
+    rsub = 0;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 5; ++q) {
       int l = lane;
       asm volatile("" : "+v"(l));                  // (recomputed per item: hoisted, the halo coordinates would stay live across the K loops)
-      const int s = 64 * (cw + 4 * q) + l;
+      const int s = 32 * (cw + 4 * q) + (l >> 1);
       const int py = s / F4_HW, r = s - py * F4_HW;
       const int px = r < 9 ? 4 * r : r < 18 ? 4 * (r - 9) + 1 : r < 26 ? 4 * (r - 18) + 2 : 4 * (r - 26) + 3;
       const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
       const bool ok = s < F4_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       rpix[q] = ok ? gy * p.W + gx : -1;
-      if (FISR_F4ABL & 32) rpix[q] = ((it.y0 * p.W + it.x0) & ~15) + (s >> 2);        // ablation: 4 lanes per pixel (contiguous 64 B ... wrong data)
-      if (FISR_F4ABL & 64) rpix[q] = (it.y0 * p.W + it.x0) + s;                       // ablation: linear pixels
+      rsub |= (unsigned)((l & 1) ^ ((py >> 2) & 1)) << q;
     }
     rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.in0 + (size_t)it.nb * img_px * p.C0), 0, (unsigned)(img_px * p.C0 * 4), 0x00020000);
     rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? (const float*)p.in1 + (size_t)it.nb * img_px * p.C1 : (const float*)p.in0), 0,
@@ -183,23 +189,15 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES + c * 1024u;
     FISR_F4_DMA1(rsw, u_voff, so, lds);
   };
-  // raw copy j (0 .. 2) of chunk kc of the raw stream's item into RAW[slot]
-  auto copy_raw1 = [&](int kc, int slot, int j) __attribute__((always_inline)) {
-    const bool first = kc < nch0;
-    const unsigned so = (unsigned)(first ? kc : kc - nch0) * 16u;
+  // raw piece j (0..4) of pair pc (chunks 2 pc, 2 pc + 1 of the raw stream's item) into pair buffer pb
+  auto copy_pair1 = [&](int pc, int pb, int j) __attribute__((always_inline)) {
+    const bool first = 2 * pc < nch0;
+    const unsigned so = (unsigned)(first ? pc : pc - (nch0 >> 1)) * 32u;
     const unsigned csb = (unsigned)(first ? p.C0 : p.C1) * 4u;
-    const int px_ = j == 0 ? rpix[0] : j == 1 ? rpix[1] : rpix[2];
-    const unsigned o = px_ < 0 ? OOB : (unsigned)px_ * csb;
-    const unsigned lds = raw_lds0 + (unsigned)slot * (unsigned)F4_RAW_BYTES + (unsigned)j * 4096u;
+    const unsigned lds = raw_lds0 + (unsigned)pb * (unsigned)(2 * F4_RAW_BYTES) + (unsigned)j * 4096u;
+    const int px_ = j == 0 ? rpix[0] : j == 1 ? rpix[1] : j == 2 ? rpix[2] : j == 3 ? rpix[3] : rpix[4];
+    const unsigned o = px_ < 0 ? OOB : (unsigned)px_ * csb + ((rsub >> j) & 1u) * 16u;
     if (first) FISR_F4_DMA1(rs0, o, so, lds); else FISR_F4_DMA1(rs1, o, so, lds);
-  };
-  auto copy_raw_all = [&](int kc, int slot) __attribute__((always_inline)) {
-    copy_raw1(kc, slot, 0); copy_raw1(kc, slot, 1);
-    if (cw < 2) copy_raw1(kc, slot, 2);
-  };
-  auto wait_keep_youngest_raw = [&]() {          // everything but the raw chunk requested last has landed
-    if (cw < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -209,17 +207,16 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   // relu-on-load: applied ONCE per element, in LDS, by the wave that requested the copy (the transform lanes would apply it
   // 2.25 times per element); read and write halves apart, a quad of MFMAs in between.  Out-of-image slots hold zeros: unchanged.
   f32x4 rl[3];
-  auto relu_read = [&](int slot) __attribute__((always_inline)) {
-    const char* b = sR + slot * F4_RAW_BYTES + cw * 1024 + lane * 16;
-    rl[0] = *reinterpret_cast<const f32x4*>(b);
-    rl[1] = *reinterpret_cast<const f32x4*>(b + 4096);
-    if (cw < 2) rl[2] = *reinterpret_cast<const f32x4*>(b + 8192);
+  auto relu_read = [&](int pb, int half) __attribute__((always_inline)) {       // half 0: pieces 0-2, half 1: pieces 3-4
+    const char* b = sR + pb * (2 * F4_RAW_BYTES) + cw * 1024 + lane * 16 + half * 3 * 4096;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (half == 0 || j < 2) rl[j] = *reinterpret_cast<const f32x4*>(b + j * 4096);
   };
-  auto relu_write = [&](int slot) __attribute__((always_inline)) {
-    char* b = sR + slot * F4_RAW_BYTES + cw * 1024 + lane * 16;
+  auto relu_write = [&](int pb, int half) __attribute__((always_inline)) {
+    char* b = sR + pb * (2 * F4_RAW_BYTES) + cw * 1024 + lane * 16 + half * 3 * 4096;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      if (j == 2 && cw >= 2) break;
+      if (half == 1 && j == 2) break;
       f32x4 f = rl[j];
       asm("v_max_f32 %0, 0, %0" : "+v"(f.x)); asm("v_max_f32 %0, 0, %0" : "+v"(f.y));
       asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
@@ -244,9 +241,15 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   //     (t2, t4) = (a, c) - (b, e) * (1, 2)        (t0, t5) = (x0, x1) * 4 + ((x2, x3) * -5 + (x4, x5))
   // and leaves its outputs in the order t0 t5 t1 t3 t2 t4: that IS the order of the six positions of a row in V, U and the
   // accumulators (F4_PERM), so nothing is shuffled.  36 packed instructions per wave and chunk (scalar: 78).
-  const int t_ch = lane & 3, t_t16 = lane >> 2;
-  const int t_ty = 2 * (wave & 1) + (t_t16 >> 3), t_tx = t_t16 & 7;
-  const int t_roff = ((4 * t_ty) * F4_HW + t_tx) * 16 + t_ch * 4;
+  // lane -> (channel, tile): a ds_read_b32 phase (32 lanes) = 4 tiles of one tile row and the 4 tiles below them x 4 channels.
+  // The two tile rows read opposite halves of their pixels' 32-byte records (f = bit 2 of the halo row), so the phase covers
+  // 8 (slot mod 4, half) combinations x 4 channels = 32 banks.  A lane's patch rows 0-3 lie in halo rows of one f, rows 4-5 in
+  // the other: two base addresses, which trade places with the chunk's parity.
+  const int t_ch = lane & 3, t_t8 = (lane >> 2) & 7;
+  const int t_tx = (lane >> 5) * 4 + (t_t8 & 3), t_tyl = t_t8 >> 2;
+  const int t_ty = 2 * (wave & 1) + t_tyl, t_t16 = t_tyl * 8 + t_tx;
+  const int t_ra = ((4 * t_ty) * F4_HW + t_tx) * 32 + (t_ty & 1) * 16 + t_ch * 4;      // chunk 0 of a pair: patch rows 0-3 | chunk 1: rows 4-5
+  const int t_rb = t_ra ^ 16;                                                          // chunk 0 of a pair: patch rows 4-5 | chunk 1: rows 0-3
   const int t_voff = (wave & 1) * 1024 + (t_ch * 16 + (t_t16 ^ (t_ch << 1))) * 16;
   const f32x2 K8 = {8.f, 8.f}, K4 = {4.f, 4.f}, KM4 = {-4.f, -4.f}, KM5 = {-5.f, -5.f}, K2 = {2.f, 2.f}, K41 = {-4.f, -1.f}, K12 = {1.f, 2.f};
   auto pk_fma = [](f32x2 a, f32x2 k, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c)); return r; };
@@ -255,14 +258,15 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   auto pk_sub = [](f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; };
   f32x2 dp[6][3];                                  // the 6 x 6 patch of this lane's (tile, channel) as column pairs
   f32x2 zp[3][3];                                  // this wave's three rows: vertical pass, then horizontal pass in place
-  auto tr_read = [&](int slot) __attribute__((always_inline)) {
-    const char* rb = sR + slot * F4_RAW_BYTES + t_roff;
+  auto tr_read = [&](int pb, int sub) __attribute__((always_inline)) {       // chunk `sub` of the pair in buffer pb
+    const char* r03 = sR + pb * (2 * F4_RAW_BYTES) + (sub ? t_rb : t_ra);
+    const char* r45 = sR + pb * (2 * F4_RAW_BYTES) + (sub ? t_ra : t_rb);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int cb = (j & 3) == 0 ? 0 : (j & 3) == 1 ? 9 : (j & 3) == 2 ? 18 : 26;     // column 4 tx + j sits at cb + tx + j / 4
-        dp[r][j >> 1][j & 1] = *reinterpret_cast<const float*>(rb + (r * F4_HW + cb + (j >> 2)) * 16);
+        dp[r][j >> 1][j & 1] = *reinterpret_cast<const float*>((r < 4 ? r03 : r45) + (r * F4_HW + cb + (j >> 2)) * 32);
       }
   };
   auto tr_col = [&](auto rh_tag, int c) __attribute__((always_inline)) {          // rows 3 rh .. 3 rh + 2 of B^T applied down the column pair c
@@ -318,8 +322,8 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   };
   typedef std::integral_constant<int, 0> rh0_t;
   typedef std::integral_constant<int, 1> rh1_t;
-  auto transform = [&](auto rh_tag, int slot, int vbuf) __attribute__((always_inline)) {       // (prologue: the whole transform at once)
-    tr_read(slot);
+  auto transform = [&](auto rh_tag, int pb, int sub, int vbuf) __attribute__((always_inline)) {       // (prologue: the whole transform at once)
+    tr_read(pb, sub);
 #pragma unroll
     for (int c = 0; c < 3; ++c) tr_col(rh_tag, c);
 #pragma unroll
@@ -354,46 +358,43 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 
   // ---- prologue of the workgroup's FIRST item: raw(0), U(0), raw(1), raw(2), raw(3) requested; raw(0) -> V[0] ----
   if (wave >= 4) {
-    copy_raw_all(0, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) copy_pair1(0, 0, j);
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_u1(cur.nblk, 0, 0, j);
-    copy_raw_all(1, 1);
-    copy_raw_all(2, 2);
-    copy_raw_all(3, 3);
-    wait_keep_youngest_raw();                      // raw(0), U(0), raw(1), raw(2) landed
-    if constexpr (RELU_IN) { relu_read(0); relu_write(0); relu_read(1); relu_write(1); }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) copy_pair1(1, 1, j);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // pair 0, U(0) landed; pair 1 in flight
+    if constexpr (RELU_IN) { relu_read(0, 0); relu_write(0, 0); relu_read(0, 1); relu_write(0, 1); }
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) copy_u1(cur.nblk, 0, 0, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   lds_barrier();
-  if (wave < 2) transform(rh0_t{}, 0, 0);
-  else if (wave < 4) transform(rh1_t{}, 0, 0);
+  if (wave < 2) transform(rh0_t{}, 0, 0, 0);
+  else if (wave < 4) transform(rh1_t{}, 0, 0, 0);
   lds_barrier();
   if (p.trace) t_first = __builtin_readcyclecounter();
 
   // ---- K loop of one item ----
-  // RAW ring: chunk g+1 is transformed (g: the workgroup's running chunk counter), g+2 gets its relu (it landed before the
-  // previous barrier: it is older than U(g), which was waited for), g+3 may still be in flight, g+4 is requested.  Copies early
-  // in the iteration (they have the rest of it to land), one behind each quad of MFMAs; the transform between the quads that
-  // follow its LDS reads.  Behind an item's last chunk the streams continue with the next item's first ones (behind the last
-  // item: they repeat a chunk -- the copy COUNT per iteration stays fixed for the counted waits).
-  int s1 = 1, s2 = 2, s3 = 3, s4 = 0;
+  // g: the workgroup's running chunk counter (items have an even number of chunks, so its parity is k's).  Iteration g multiplies
+  // chunk g and transforms chunk g+1 out of its raw pair.  Raw pairs: two buffers; pair m+1 is requested in the odd iteration
+  // 2m-1 (pair m-1 was read for the last time in 2m-2), waited for and relu'd late in the even iteration 2m, read from 2m+1 on:
+  // it has 1.6 iterations to come from HBM.  Weight copies early in the iteration (they have the rest of it to land), one behind
+  // each quad of MFMAs; the transform between the quads that follow its LDS reads.  Behind an item's last chunk the streams
+  // continue with the next item's first ones (behind the last item they repeat a chunk: the copy COUNT per iteration stays fixed
+  // for the counted waits).
   int par = 0;                                     // V / U buffer of the chunk about to be multiplied
-  // byte offsets of this lane's raw pixels in the concat source the raw stream is in (copy waves; recomputed where it changes)
-  unsigned ro[3] = {OOB, OOB, OOB};
-  bool ro_first = nch0 > 4;
-  if (wave >= 4) {
-    const unsigned csb = (unsigned)(ro_first ? p.C0 : p.C1) * 4u;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) ro[j] = rpix[j] < 0 ? OOB : (unsigned)rpix[j] * csb;
-  }
+  int pbt = 0;                                     // raw pair buffer that holds chunk g+1
   typedef std::integral_constant<bool, true> first_t;
   typedef std::integral_constant<bool, false> rest_t;
-  auto k_iter = [&](auto role_tag, auto first_tag, int k) __attribute__((always_inline)) {
+  typedef std::integral_constant<bool, true> odd_t;
+  typedef std::integral_constant<bool, false> even_t;
+  auto k_iter = [&](auto role_tag, auto first_tag, auto odd_tag, int k) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_tag)::value;        // 0 / 1: transform wave of rows 0-2 / 3-5; 2: copy wave
     constexpr bool FIRST = decltype(first_tag)::value;     // first chunk of an item
+    constexpr bool ODD = decltype(odd_tag)::value;         // k odd
     typedef typename std::conditional<ROLE == 1, rh1_t, rh0_t>::type RH;
     const int buf = par;
     const char* ub = fu + buf * F4_U_BYTES;
@@ -403,26 +404,18 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     const int ku = u_here ? k + 1 : (has_next ? 0 : nch - 1);
     const int nblk_cur = cur.nblk, nblk_nxt = nxt.nblk;       // (values first: a conditional between the captured structs' fields is a
     const int u_nblk = u_here || !has_next ? nblk_cur : nblk_nxt;     //  select of ADDRESSES into the closure, which then cannot be promoted to registers)
-    // raw(k+4) likewise; its geometry moves to the next item at k = nch - 4
-    const bool r_here = k + 4 < nch;
-    const int kr = r_here ? k + 4 : (has_next ? k + 4 - nch : nch - 1);
     ra[0] = *reinterpret_cast<const f32x4*>(ub);
     rb[0] = *reinterpret_cast<const f32x4*>(vb);
     ra[1] = *reinterpret_cast<const f32x4*>(ub + 4096);
     rb[1] = *reinterpret_cast<const f32x4*>(vb + 2048);
-    if (ROLE < 2 && !(FISR_F4ABL & 4)) tr_read(s1);
-    const bool rfirst = kr < nch0;
-    if constexpr (ROLE == 2) {
-      if (k == nch - 4 && has_next) { raw_geom(nxt); ro_first = !rfirst; }
-      if (rfirst != ro_first) {
-        const unsigned csb = (unsigned)(rfirst ? p.C0 : p.C1) * 4u;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ro[j] = rpix[j] < 0 ? OOB : (unsigned)rpix[j] * csb;
-        ro_first = rfirst;
-      }
+    if (ROLE < 2 && !(FISR_F4ABL & 4)) tr_read(pbt, ODD ? 0 : 1);
+    // odd iterations request the raw pair (k + 3) / 2: of this item, of the next one (its geometry from k = nch - 3 on), or a repeat
+    int pc = 0;
+    if constexpr (ROLE == 2 && ODD) {
+      const int pp = (k + 3) >> 1, np = nch >> 1;
+      pc = pp < np ? pp : (has_next ? pp - np : np - 1);
+      if (k == nch - 3 && has_next) raw_geom(nxt);
     }
-    const unsigned rso = (unsigned)(rfirst ? kr : kr - nch0) * 16u;
-    const unsigned rlds = raw_lds0 + (unsigned)s4 * (unsigned)F4_RAW_BYTES;
     if constexpr (FIRST) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[32 + r] = zero4;
@@ -443,23 +436,23 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           if (q == 1) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
           if (q >= 2 && q < 5) { tr_row(q - 2); tr_write(RH{}, buf ^ 1, q - 2); }
         }
-      } else {
-        if constexpr (RELU_IN) {
-          if (q == 0) relu_read(s2);
-          if (q == 1) relu_write(s2);
-        }
-        if (!(FISR_F4ABL & 2)) {
-          if (q == 5) { if (rfirst) FISR_F4_DMA1(rs0, ro[0], rso, rlds); else FISR_F4_DMA1(rs1, ro[0], rso, rlds); }
-          if (q == 6) { const unsigned l1 = rlds + 4096u; if (rfirst) FISR_F4_DMA1(rs0, ro[1], rso, l1); else FISR_F4_DMA1(rs1, ro[1], rso, l1); }
-          if (q == 7 && cw < 2) { const unsigned l2 = rlds + 8192u; if (rfirst) FISR_F4_DMA1(rs0, ro[2], rso, l2); else FISR_F4_DMA1(rs1, ro[2], rso, l2); }
-        }
+      } else if constexpr (ODD) {
+        if (q == 5) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
+        if (q == 6) { copy_pair1(pc, pbt ^ 1, 2); copy_pair1(pc, pbt ^ 1, 3); }
+        if (q == 7) copy_pair1(pc, pbt ^ 1, 4);
+      } else if constexpr (RELU_IN) {
+        // the pair requested an iteration ago is older than this iteration's five weight copies
+        if (q == 4) { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); relu_read(pbt ^ 1, 0); }
+        if (q == 5) relu_write(pbt ^ 1, 0);
+        if (q == 6) relu_read(pbt ^ 1, 1);
+        if (q == 7) relu_write(pbt ^ 1, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ROLE < 2 || (FISR_F4ABL & 3)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else wait_keep_youngest_raw();                 // U(g+1) (and everything older: raw(g+3)) landed; raw(g+4) stays in flight
+    if (ROLE == 2 && ODD) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // U(g+1) (and the raw pair of the iteration before) landed
     lds_barrier();
-    const int s_ = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s_;
+    if (!ODD) pbt ^= 1;
     par ^= 1;
   };
   typedef std::integral_constant<int, 0> role0_t;
@@ -470,11 +463,11 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   auto k_loop = [&](auto role_tag) __attribute__((always_inline)) {
     const bool tr2 = p.trace && n_done == 1;
     if (tr2) t2[0] = __builtin_readcyclecounter();
-    k_iter(role_tag, first_t{}, 0);
+    k_iter(role_tag, first_t{}, even_t{}, 0);
     if (tr2) t2[1] = __builtin_readcyclecounter();
-    k_iter(role_tag, rest_t{}, 1);
+    k_iter(role_tag, rest_t{}, odd_t{}, 1);
     if (tr2) t2[2] = __builtin_readcyclecounter();
-    for (int k = 2; k < nch; ++k) k_iter(role_tag, rest_t{}, k);
+    for (int k = 2; k < nch; k += 2) { k_iter(role_tag, rest_t{}, even_t{}, k); k_iter(role_tag, rest_t{}, odd_t{}, k + 1); }
     if (tr2) t2[3] = __builtin_readcyclecounter();
   };
 
@@ -652,10 +645,10 @@ inline void pack_weights_wf4(const float* w, int ci, int co, int cin_pad, std::v
         }
     }
 }
-// what conv3x3_wf4.h takes: whole 64-channel output blocks, whole 4-channel chunks per concat source, images addressed with
+// what conv3x3_wf4.h takes: whole 64-channel output blocks, whole 8-channel raw pairs per concat source, images addressed with
 // 31-bit byte offsets (the out-of-range marker of its zero padding is 2^31)
 inline bool wf4_fits(int h, int w, int c0, int c1, int co) {
-  return co % F4_BN == 0 && c0 > 0 && c0 % F4_CH == 0 && c1 % F4_CH == 0 && (c0 + c1) / F4_CH >= 4 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
+  return co % F4_BN == 0 && c0 > 0 && c0 % (2 * F4_CH) == 0 && c1 % (2 * F4_CH) == 0 && (c0 + c1) / F4_CH >= 4 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
 }
 // ... and where it is the faster of the two Winograd kernels (measured per map size and depth, scripts/conv_bench.py, 12 tiles:
 // 68 x 124 maps 1.2-1.35x at every channel count, 34 x 62 maps 0.72-0.77x with 64-256 channels -- its 16 x 32-pixel items waste
