@@ -9,8 +9,9 @@
 // QUARTER of the direct work (the kernel needs the pipe busy 0.45 of the time to match conv3x3_wino8p.h at 0.70).  Everything is
 // fp32: transforms are fp32 fma chains, products accumulate on v_mfma_f32_16x16x4_f32, U = G g G^T is computed on the host in
 // double and rounded once.  The price is the conditioning of the F(4,3) transforms (interpolation points 0, +-1, +-2, inf): about
-// ten times F(2x2)'s rounding error per convolution (the whole network: ~2e-5 instead of 1.5e-6 against the fp64 oracle -- what
-// the bf16x3 engine has, 7e-5 dB) -- which is why this is its own engine (FISR_PREC_F32W4) and not a silent change of FISR_PREC_F32W.
+// ten times F(2x2)'s rounding error per convolution (2e-5 instead of 2e-6 on O(1) outputs).  Through the network it does not add
+// up -- 1.5e-6 against the fp64 oracle on the full tile, 1.1-1.6e-6 on the undamped and the harsh weight sets, the F(2x2)
+// engine's figures -- but it is its own engine id (FISR_PREC_F32W4) all the same, FISR_PREC_F32W stays what it was.
 //
 // GEMM view, per transform position p = 0..35:  M_p[co][tile] = sum_ci U_p[co][ci] * V_p[ci][tile].
 // Work item = 16 x 32 output pixels (4 x 8 tiles of 4 x 4) x 64 output channels; 512 threads = 8 waves = two per SIMD.
@@ -29,8 +30,13 @@
 //     [position quad][channel quarter][k][16 channels][4], V as [position quad][tile half][slot(k, tile)][4] with
 //     slot = 16 k + (tile ^ 2 k): the transform lanes (2 tiles x 4 channels per ds_write_b128 phase) and the MFMA lanes (the
 //     lane groups of a ds_read_b128 phase: 8 tiles of one k and the 8 other tiles of the next) both hit every bank once.
-//   * The raw halo rows hold their columns grouped by column mod 4, so the 8 tiles x 4 channels of a ds_read_b32 phase read 32
-//     consecutive dwords.
+//   * A raw record is 32 bytes = a PAIR of chunks of one pixel, fetched by two neighbouring lanes as 32 contiguous bytes (a copy
+//     instruction then touches 32 memory lines, not 64: that count is what a raw copy costs).  The halo rows hold their columns
+//     grouped by column mod 4 and the two halves of a record trade places with bit 2 of the halo row, so a ds_read_b32 phase of the
+//     transform -- 4 tiles of one tile row, the 4 below them, 4 channels -- reads 32 different banks.
+//   * The fp32 MFMA and the vector ALU of a SIMD do not overlap (probed), so every vector instruction is paid on top of the MFMAs:
+//     the transforms are packed fp32 (op_sel: 6 instructions per 6 -> 6 row), the bias rides in accumulator (1,1), the relu of
+//     relu-on-load layers is applied once per element in LDS, record offsets ride in the scalar operand of the buffer instructions.
 #pragma once
 #include <algorithm>
 #include <type_traits>
@@ -44,29 +50,47 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int F4_TH = 16, F4_TW = 32;                  // output pixels of a work item
 constexpr int F4_HH = F4_TH + 2, F4_HW = F4_TW + 2;    // halo tile 18 x 34
-constexpr int F4_HALO = F4_HH * F4_HW;                 // 612 pixels (16 bytes each per chunk)
+constexpr int F4_HALO = F4_HH * F4_HW;                 // 612 pixels (16 bytes each per chunk, 32 per raw pair)
 constexpr int F4_CH = 4;                               // channels per K chunk
 constexpr int F4_BN = 64;                              // output channels per work item
-constexpr int F4_RAW_COPIES = 10;                      // 1 KB LDS-DMA copies per raw chunk (640 slots, 612 used)
+constexpr int F4_RAW_COPIES = 10;                      // 1 KB LDS-DMA copies per raw chunk (640 slots, 612 used); a raw PAIR is two of these
 constexpr int F4_RAW_BYTES = F4_RAW_COPIES * 1024;     // 10240
 constexpr int F4_U_BYTES = 36 * F4_BN * F4_CH * 4;     // 36864: one weight slab = 36 copies
 constexpr int F4_V_BYTES = 36 * 32 * F4_CH * 4;        // 18432
 // Position (i, j) of the 6 x 6 transform grid lives in slot 6 i + F4_PERM[j] of V, U and the accumulators: the order in which the
 // packed horizontal pass of the input transform leaves its outputs (t0 t5 t1 t3 t2 t4).
 __host__ __device__ constexpr int wf4_slot(int i, int j) { return 6 * i + (j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 4 : j == 3 ? 3 : j == 4 ? 5 : 1); }
-constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 4 * F4_RAW_BYTES; }   // 151552
+constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 2 * (2 * F4_RAW_BYTES); }   // 151552
 
 // FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
-// 2 no raw copies, 4 no input transform, 8 weight copies waited for one iteration later (latency vs bandwidth), 16 no MFMAs
+// 4 no input transform, 16 no MFMAs, 128 workgroups de-phased at start, 256 wait for the stores behind the epilogue, 512 one store
+// per lane instead of 16 (earlier versions: 2 no raw copies, 32 / 64 raw access patterns)
 #ifndef FISR_F4ABL
 #define FISR_F4ABL 0
+#endif
+// per-workgroup / per-wave timestamps (p.trace): compiled in for scripts/probes/wf4_bench.hip only (-DFISR_F4_TRACE=1)
+#ifndef FISR_F4_TRACE
+#define FISR_F4_TRACE 0
 #endif
 #ifndef FISR_F4_STORE_AUX
 #define FISR_F4_STORE_AUX 0      // cache policy of the output stores (A/B hook; 2 = nontemporal: 1-2 % slower on the residual layers)
 #endif
 #define FISR_F4_BEGIN(KEEP, LDS)   "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
+// schedule hooks (A/B): quad behind which the transform's vertical pass / first row runs, first quad of the weight copies
+#ifndef FISR_F4_COLQ
+#define FISR_F4_COLQ 1
+#endif
+#ifndef FISR_F4_ROWQ
+#define FISR_F4_ROWQ 2
+#endif
+#ifndef FISR_F4_UQ
+#define FISR_F4_UQ 0
+#endif
+#ifndef FISR_F4_U_AUX
+#define FISR_F4_U_AUX ""         // cache-policy bits of the weight copies (A/B hook: " nt", " sc1", " sc0 sc1")
+#endif
 #define FISR_F4_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen lds\n\t"
-#define FISR_F4_NEXT               "s_add_u32 m0, m0, 0x1800\n\ts_nop 0\n\t"
+#define FISR_F4_COPYU(OFF, RS, SO) "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen" FISR_F4_U_AUX " lds\n\t"
 #define FISR_F4_END(KEEP)          "s_mov_b32 m0, %[" #KEEP "]"
 
 // B^T of F(4,3), in place on six values (rows of [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1])
@@ -131,11 +155,11 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   if (FISR_F4_PRIO == 3 && wave >= 4) __builtin_amdgcn_s_setprio(3);
 #endif
   unsigned long long t_start = 0, t_first = 0, t_main = 0, t_end1 = 0, t_real = 0;
-  if (p.trace) { t_start = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
+  if (FISR_F4_TRACE && p.trace) { t_start = __builtin_readcyclecounter(); t_real = __builtin_amdgcn_s_memrealtime(); }
 
   // =========================== copies (LDS-DMA, 1 KB per wave instruction) ===========================
   // weight copy c (0..35) is linear: wave w issues copies w, w + 8, w + 16, w + 24 and, waves 4-7, copy 28 + w.
-  // raw copy c (0..9) moves halo slots 64 c .. 64 c + 63; wave 4 + cw issues copies cw, cw + 4 and (cw < 2) cw + 8.
+  // raw copy c (0..19) of a raw pair moves halo slots 32 c .. 32 c + 31 (two lanes per slot); wave 4 + cw issues copies cw, cw + 4, .., cw + 16.
   // (Measured and dropped: all weight copies on waves 0-3 and the raw copies alone on waves 4-7, so that the wait for the weights
   // -- vmcnt is ONE in-order counter per wave -- does not also wait for the older raw copies: no gain, the transform waves carry
   // the longer instruction stream already.)
@@ -175,6 +199,9 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   const unsigned raw_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sR + (unsigned)cw * 1024u;
   const unsigned u_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sU;
   const unsigned u_voff = (unsigned)lane * 16u;
+  // the workgroups of an XCD multiply the same slab at the same time: each walks its 36 pieces from another starting point, so
+  // that they do not all ask the same L2 channel for the same lines at once (1-2 % on the 256 / 512-channel layers)
+  const unsigned u_rot = ((blockIdx.x >> 3) * 7u) % 36u;
 
 #define FISR_F4_DMA1(RS, VOFF, SOFF, LDS)                                                                       \
   do {                                                                                                          \
@@ -184,10 +211,15 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   } while (0)
   // weight copy j (0..3; 4: waves 4-7 only) of chunk kc of N block nblk into U[buf]
   auto copy_u1 = [&](int nblk, int kc, int buf, int j) __attribute__((always_inline)) {
-    const unsigned c = j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave);
+    unsigned c = (j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave)) + u_rot;
+    c = c >= 36u ? c - 36u : c;
     const unsigned so = (unsigned)(((size_t)kc * nblocks + nblk) * F4_U_BYTES) + c * 1024u;
     const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES + c * 1024u;
-    FISR_F4_DMA1(rsw, u_voff, so, lds);
+    {
+      unsigned keep_;
+      asm volatile(FISR_F4_BEGIN(keep, lds) FISR_F4_COPYU(o, rs, so) FISR_F4_END(keep)
+                   : [keep] "=&s"(keep_) : [rs] "s"(rsw), [lds] "s"(lds), [o] "v"(u_voff), [so] "s"(so) : "memory", "scc");
+    }
   };
   // raw piece j (0..4) of pair pc (chunks 2 pc, 2 pc + 1 of the raw stream's item) into pair buffer pb
   auto copy_pair1 = [&](int pc, int pb, int j) __attribute__((always_inline)) {
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   if (wave < 2) transform(rh0_t{}, 0, 0, 0);
   else if (wave < 4) transform(rh1_t{}, 0, 0, 0);
   lds_barrier();
-  if (p.trace) t_first = __builtin_readcyclecounter();
+  if (FISR_F4_TRACE && p.trace) t_first = __builtin_readcyclecounter();
 
   // ---- K loop of one item ----
   // g: the workgroup's running chunk counter (items have an even number of chunks, so its parity is k's).  Iteration g multiplies
@@ -430,11 +462,11 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         rb[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(vb + (q + 2) * 2048);
       }
       if constexpr (FIRST) { FISR_F4_MMA4Z(q, ra[q % 3], rb[q % 3]) } else { FISR_F4_MMA4(q, ra[q % 3], rb[q % 3]) }
-      if (!(FISR_F4ABL & 1) && q < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q);
+      if (!(FISR_F4ABL & 1) && q >= FISR_F4_UQ && q - FISR_F4_UQ < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q - FISR_F4_UQ);
       if constexpr (ROLE < 2) {
         if (!(FISR_F4ABL & 4)) {
-          if (q == 1) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
-          if (q >= 2 && q < 5) { tr_row(q - 2); tr_write(RH{}, buf ^ 1, q - 2); }
+          if (q == FISR_F4_COLQ) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
+          if (q >= FISR_F4_ROWQ && q < FISR_F4_ROWQ + 3) { tr_row(q - FISR_F4_ROWQ); tr_write(RH{}, buf ^ 1, q - FISR_F4_ROWQ); }
         }
       } else if constexpr (ODD) {
         if (q == 5) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
@@ -461,7 +493,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   unsigned long long t2[6] = {0, 0, 0, 0, 0, 0};   // timeline of the workgroup's SECOND item (steady state), trace runs only
   int n_done = 0;
   auto k_loop = [&](auto role_tag) __attribute__((always_inline)) {
-    const bool tr2 = p.trace && n_done == 1;
+    const bool tr2 = FISR_F4_TRACE && p.trace && n_done == 1;
     if (tr2) t2[0] = __builtin_readcyclecounter();
     k_iter(role_tag, first_t{}, even_t{}, 0);
     if (tr2) t2[1] = __builtin_readcyclecounter();
@@ -482,7 +514,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     else if (wave < 4) k_loop(role1_t{});
     else k_loop(role2_t{});
     FISR_F4_MMA4(8, ra[2], rb[2])                  // the last chunk's pending quad
-    if (p.trace && n_done == 0) t_main = __builtin_readcyclecounter();
+    if (FISR_F4_TRACE && p.trace && n_done == 0) t_main = __builtin_readcyclecounter();
 
     // ---- epilogue: Y = A^T M A in registers (the bias came in through accumulator (1,1)), lane transposition, (+ residual), relu,
     //      16-byte stores.  No LDS memory, no barrier: V / U / RAW already belong to the next item.
@@ -541,7 +573,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         y3 = pk_add(pk_fma(d2, K8, d1), m5);
       };
       f32x2 yp[4][4][2];                           // [row][column][channel pair]
-      if (p.trace && n_done == 1) t2[4] = __builtin_readcyclecounter();
+      if (FISR_F4_TRACE && p.trace && n_done == 1) t2[4] = __builtin_readcyclecounter();
       f32x4 res[4][4];
       auto half = [&](auto h_tag) __attribute__((always_inline)) {
         constexpr int h = decltype(h_tag)::value;
@@ -587,8 +619,8 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         }
     }
     if (FISR_F4ABL & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ablation: wait for the stores here
-    if (p.trace && n_done == 0) t_end1 = __builtin_readcyclecounter();
-    if (p.trace && n_done == 1) t2[5] = __builtin_readcyclecounter();
+    if (FISR_F4_TRACE && p.trace && n_done == 0) t_end1 = __builtin_readcyclecounter();
+    if (FISR_F4_TRACE && p.trace && n_done == 1) t2[5] = __builtin_readcyclecounter();
     ++n_done;
     if (!has_next) break;
     b_cur += gridDim.x;
@@ -602,12 +634,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 #undef FISR_F4_MMA4Z
 #undef FISR_F4_MMA4C
 #undef FISR_F4_DMA1
-  if (p.trace && tid == 0) {
+  if (FISR_F4_TRACE && p.trace && tid == 0) {
     unsigned long long* tr = p.trace + (size_t)blockIdx.x * 8;
     tr[0] = t_start; tr[1] = t_main; tr[2] = __builtin_readcyclecounter();
     tr[3] = t_end1; tr[4] = t_first; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)n_done;
   }
-  if (p.trace && (tid & 63) == 0 && n_done > 1) {   // second row block: per WAVE {item start, after iteration 0, 1, K loop end, epilogue start of the stores.., end}
+  if (FISR_F4_TRACE && p.trace && (tid & 63) == 0 && n_done > 1) {   // second row block: per WAVE {item start, after iteration 0, 1, K loop end, epilogue start of the stores.., end}
     unsigned long long* tr = p.trace + ((size_t)gridDim.x + (size_t)blockIdx.x * 8 + wave) * 8;
 #pragma unroll
     for (int i = 0; i < 6; ++i) tr[i] = t2[i];
@@ -616,7 +648,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 
 #undef FISR_F4_BEGIN
 #undef FISR_F4_COPY
-#undef FISR_F4_NEXT
+#undef FISR_F4_COPYU
 #undef FISR_F4_END
 
 // ---- host side: weight slabs, eligibility, launch ----

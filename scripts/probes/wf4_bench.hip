@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#define FISR_F4_TRACE 1
 #include "conv3x3_wf4.h"
 using namespace fisr;
 
