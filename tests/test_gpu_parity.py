@@ -42,7 +42,7 @@ def net32(dev, syn_weights):
 
 @pytest.fixture(scope="module")
 def net32w(dev, syn_weights):
-    n = FISRnet(device="cuda:0", precision="fp32")       # the shipped fp32 engine: Winograd F(2x2,3x3) where eligible
+    n = FISRnet(device="cuda:0", precision="fp32")       # the shipped fp32 engine: Winograd F(4x4,3x3) on maps >= 48x64, F(2x2,3x3) below
     n.set_weights(syn_weights)
     yield n
     n.close()
@@ -519,8 +519,30 @@ def test_forward_fp32_cfg1_96x96_windows(net32, gold_dir):
         _report(l3.cpu().numpy()[0], g["l3"][s].astype(np.float64), F32_FWD_TOL + 1e-6, f"window {s}")
 
 
+def test_fp32_engine_runs_the_kernels_it_claims(dev, syn_weights):
+    """Which kernel a conv runs on is decided per map (wf4_wins): on a 96 x 160 input the fp32 engine must run BOTH Winograd kernels
+    -- F(4x4) on the 96 x 160 / 48 x 80 maps, F(2x2) below --, 'fp32w' only the F(2x2) one, 'fp32d' neither; and the three engines
+    agree to fp32 rounding."""
+    x = np.random.default_rng(3).random((1, 96, 160, 29)).astype(np.float32)
+    x[..., 9:17] = (x[..., 9:17] - 0.5) * 0.4
+    outs = {}
+    for prec in ("fp32", "fp32w", "fp32d"):
+        net = FISRnet(device="cuda:0", precision=prec)
+        net.set_weights(syn_weights)
+        net.profile(1)
+        outs[prec] = net.model(torch.from_numpy(x).cuda(), want_all=False)[2].cpu().numpy()
+        torch.cuda.synchronize()
+        names = {p["name"].split("<")[0] for p in net.profile_read() if p["launches"]}
+        net.profile(0)
+        net.close()
+        assert ("conv3x3_wf4" in names) == (prec == "fp32"), (prec, names)
+        assert ("conv3x3_wino8p" in names) == (prec != "fp32d"), (prec, names)
+    assert np.abs(outs["fp32"] - outs["fp32d"]).max() < 2e-5
+    assert np.abs(outs["fp32w"] - outs["fp32d"]).max() < 2e-5
+
+
 def test_forward_fp32_winograd_vs_goldens(net32w, gold_dir, syn_blob):
-    """The fp32 engine with Winograd F(2x2,3x3) convolutions (FISR_PREC_F32W) against the same fp64-oracle goldens
+    """The shipped fp32 engine (Winograd F(4x4,3x3) / F(2x2,3x3) convolutions, FISR_PREC_F32W4) against the same fp64-oracle goldens
     as the direct fp32 engine and at the same bound (2e-4 on O(1) outputs after 138 convs; measured ~1e-5), all
     three levels; the three cfg1 windows with the PSNR protocol; one full 544x992 tile on the sparse grid; random
     shapes incl. the minimal 32x32 (level-1 maps of 8x8 .. 1x1: tiles mostly padding)."""
