@@ -423,6 +423,9 @@ struct ConvArgs {
   int dil;              // Winograd kernel only: dilation (1 otherwise)
   // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
   unsigned long long* trace;
+  // conv3x3_wf4.h only: when not NULL, the 2x2 max pooling of the output ([N,H/2,W/2,Cout], ops.py:54) as a second store of the
+  // epilogue -- a Winograd tile holds whole pooling windows (H, W even; not with depth_to_space)
+  void* pool_out = nullptr;
 };
 
 template <typename T, int NT> constexpr size_t conv_lds_bytes() {

@@ -110,7 +110,9 @@ __device__ __forceinline__ void wf4_at(float m0, float m1, float m2, float m3, f
   y3 = fmaf(8.f, d2, d1) + m5;
 }
 
-template <bool RELU_IN, bool HAS_RES>
+// POOL: p.pool_out gets the 2x2 max pooling of the output as a second store of the epilogue (its own instantiation: the sixteen
+// registers of the pooled pixels cost the other layers 1.5-3 % in spills around the output stage).
+template <bool RELU_IN, bool HAS_RES, bool POOL = false>
 __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sU = smem;
@@ -221,14 +223,22 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
                    : [keep] "=&s"(keep_) : [rs] "s"(rsw), [lds] "s"(lds), [o] "v"(u_voff), [so] "s"(so) : "memory", "scc");
     }
   };
+  // byte offsets of this lane's raw pixels (its half of the pair included) in the concat source the raw stream is in: recomputed
+  // where the source or the item changes, not per copy (every vector instruction of the K loop is paid in full)
+  unsigned ro[5] = {OOB, OOB, OOB, OOB, OOB};
+  bool ro_first = true;
+  auto raw_offsets = [&](bool first) __attribute__((always_inline)) {
+    const unsigned csb = (unsigned)(first ? p.C0 : p.C1) * 4u;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) ro[j] = rpix[j] < 0 ? OOB : (unsigned)rpix[j] * csb + ((rsub >> j) & 1u) * 16u;
+    ro_first = first;
+  };
   // raw piece j (0..4) of pair pc (chunks 2 pc, 2 pc + 1 of the raw stream's item) into pair buffer pb
   auto copy_pair1 = [&](int pc, int pb, int j) __attribute__((always_inline)) {
     const bool first = 2 * pc < nch0;
     const unsigned so = (unsigned)(first ? pc : pc - (nch0 >> 1)) * 32u;
-    const unsigned csb = (unsigned)(first ? p.C0 : p.C1) * 4u;
     const unsigned lds = raw_lds0 + (unsigned)pb * (unsigned)(2 * F4_RAW_BYTES) + (unsigned)j * 4096u;
-    const int px_ = j == 0 ? rpix[0] : j == 1 ? rpix[1] : j == 2 ? rpix[2] : j == 3 ? rpix[3] : rpix[4];
-    const unsigned o = px_ < 0 ? OOB : (unsigned)px_ * csb + ((rsub >> j) & 1u) * 16u;
+    const unsigned o = j == 0 ? ro[0] : j == 1 ? ro[1] : j == 2 ? ro[2] : j == 3 ? ro[3] : ro[4];
     if (first) FISR_F4_DMA1(rs0, o, so, lds); else FISR_F4_DMA1(rs1, o, so, lds);
   };
   auto lds_barrier = [&]() {
@@ -390,10 +400,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 
   // ---- prologue of the workgroup's FIRST item: raw(0), U(0), raw(1), raw(2), raw(3) requested; raw(0) -> V[0] ----
   if (wave >= 4) {
+    raw_offsets(true);
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_pair1(0, 0, j);
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_u1(cur.nblk, 0, 0, j);
+    if (2 >= nch0) raw_offsets(false);
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_pair1(1, 1, j);
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // pair 0, U(0) landed; pair 1 in flight
@@ -446,7 +458,10 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     if constexpr (ROLE == 2 && ODD) {
       const int pp = (k + 3) >> 1, np = nch >> 1;
       pc = pp < np ? pp : (has_next ? pp - np : np - 1);
-      if (k == nch - 3 && has_next) raw_geom(nxt);
+      const bool rfirst = 2 * pc < nch0;
+      bool redo = rfirst != ro_first;
+      if (k == nch - 3 && has_next) { raw_geom(nxt); redo = true; }
+      if (redo) raw_offsets(rfirst);
     }
     if constexpr (FIRST) {
 #pragma unroll
@@ -599,6 +614,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       };
       half(std::integral_constant<int, 0>{});
       half(std::integral_constant<int, 1>{});
+      f32x4 pm[2][2];                              // 2x2 max pooling of the lane's 4 x 4 pixels (p.pool_out)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -616,7 +632,28 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           }
           if (!(FISR_F4ABL & 512) || (i == 0 && j == 0))        // (ablation 512: one store per lane instead of 16)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF(i, j), FISR_F4_STORE_AUX);
+          if constexpr (POOL) {
+            if ((i & 1) == 0 && (j & 1) == 0) pm[i >> 1][j >> 1] = o;
+            else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pm[i >> 1][j >> 1][e] = fmaxf(pm[i >> 1][j >> 1][e], o[e]);
+            }
+          }
         }
+      if constexpr (POOL) {       // ops.py:54 max_pool 2x2 / 2 of what was just stored: [N, H/2, W/2, Cout]
+        const unsigned ph = (unsigned)p.H >> 1, pw = (unsigned)p.W >> 1;
+        const unsigned pool_bytes = ph * pw * (unsigned)p.Cout * 4u;
+        const __amdgpu_buffer_rsrc_t ps_ = __builtin_amdgcn_make_buffer_rsrc((char*)p.pool_out + (size_t)cur.nb * pool_bytes, 0, pool_bytes, 0x00020000);
+        const unsigned pbase = c_ok ? (((unsigned)oy0 >> 1) * pw + ((unsigned)ox0 >> 1)) * (unsigned)p.Cout * 4u + (unsigned)c0 * 4u : OOB;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj) {
+            const unsigned o_ = (interior || ((oy0 + 2 * bi < p.H) & (ox0 + 2 * bj < p.W))) ? pbase : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pm[bi][bj]), ps_, o_,
+                                                   ((unsigned)bi * pw + (unsigned)bj) * (unsigned)p.Cout * 4u, FISR_F4_STORE_AUX);
+          }
+      }
     }
     if (FISR_F4ABL & 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ablation: wait for the stores here
     if (FISR_F4_TRACE && p.trace && n_done == 0) t_end1 = __builtin_readcyclecounter();
@@ -698,7 +735,8 @@ inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   if (!attr_done[dev]) {
     const void* kerns[] = {reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true>),
-                           reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, true>)};
+                           reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, false>), reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, true>),
+                           reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true, true>)};
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
@@ -710,11 +748,15 @@ inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
   }
   const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && a.dil == 1;
   if (!plain || !wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s) || a.CoutPad != a.Cout) return hipErrorInvalidValue;
+  // (fused pooling: instantiated for what FISRnet needs it for, the last conv of an encoder level -- residual, no relu-on-load)
+  if (a.pool_out && (a.d2s || (a.H & 1) || (a.W & 1) || a.relu_in || !a.res)) return hipErrorInvalidValue;
   const int items = ((a.W + F4_TW - 1) / F4_TW) * ((a.H + F4_TH - 1) / F4_TH) * a.N * (a.CoutPad / F4_BN);
   // one workgroup per CU (the kernel needs most of a CU's LDS and half its registers), a multiple of 8 so that the items of a
   // workgroup stay on one XCD
   const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
-  if (a.relu_in) {
+  if (a.pool_out) {
+    hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true, true>), dim3(grid), dim3(512), lds, st, a, items);
+  } else if (a.relu_in) {
     if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<true, true>), dim3(grid), dim3(512), lds, st, a, items);
     else hipLaunchKernelGGL((conv3x3_wf4_kernel<true, false>), dim3(grid), dim3(512), lds, st, a, items);
   } else {

@@ -697,9 +697,16 @@ struct Runner {
   }
 
   // ops.py:7-11 (+ fused neighbours, see conv3x3.h)
+  // (pool_out: the 2x2 max pooling of the output as a second store of the conv -- only when pool_fuses() says this conv runs on the
+  //  F(4x4) Winograd kernel)
+  bool pool_fuses(const std::string& name, int c, int h, int w) {
+    auto it = ctx->convs.find(name);
+    return std::is_same<T, float>::value && ctx->wf4 && it != ctx->convs.end() && it->second.d_wu4 && wf4_fits(h, w, c, 0, it->second.co) &&
+           wf4_wins(h, w, c) && !(h & 1) && !(w & 1);
+  }
   void conv(const std::string& name, const T* in0, int c0, const T* in1, int c1, const T* res, void* out,
             int n, int h, int w, int flags, bool out_f32 = false, int cstride = 0, int coff = 0,
-            int split = 1 << 30, int gap = 0) {
+            int split = 1 << 30, int gap = 0, void* pool_out = nullptr) {
     if (rc) return;
     auto it = ctx->convs.find(name);
     if (it == ctx->convs.end()) { rc = fail(ctx, FISR_EMISSING, "unknown conv " + name); return; }
@@ -728,12 +735,16 @@ struct Runner {
     if (use_wino) a.wpk = cw.d_wu;
     const bool use_wf4 = std::is_same<T, float>::value && ctx->wf4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cw.co) && wf4_wins(h, w, c0 + c1);
     if (use_wf4) a.wpk = cw.d_wu4;
+    if (pool_out) {
+      if (!use_wf4) { rc = fail(ctx, FISR_ESTATE, name + ": fused pooling asked of a conv that does not run on the F(4x4) kernel"); return; }
+      a.pool_out = pool_out;
+    }
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     const bool use_dma = std::is_same<T, _Float16>::value && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
     if (use_dma) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
     char cls[96];
     if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
-    else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
+    else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
@@ -751,9 +762,9 @@ struct Runner {
   }
 
   // ops.py:39-44 res_block, in place on X with scratch A.
-  void rb(const std::string& name, T* X, T* A, int c, int n, int h, int w, bool relu_out) {
+  void rb(const std::string& name, T* X, T* A, int c, int n, int h, int w, bool relu_out, void* pool_out = nullptr) {
     conv(name + "/conv/0", X, c, nullptr, 0, nullptr, A, n, h, w, FISR_CONV_RELU_IN | FISR_CONV_RELU_OUT);
-    conv(name + "/conv/1", A, c, nullptr, 0, X, X, n, h, w, relu_out ? FISR_CONV_RELU_OUT : 0);
+    conv(name + "/conv/1", A, c, nullptr, 0, X, X, n, h, w, relu_out ? FISR_CONV_RELU_OUT : 0, false, 0, 0, 1 << 30, 0, pool_out);
   }
 
   void pool(const T* in, T* out, int n, int h, int w, int c) {  // ops.py:54
@@ -794,10 +805,12 @@ struct Runner {
     T* A = talloc(px * c);
     conv(e + "/conv/0", cur, cc, nullptr, 0, nullptr, X, n, h, w, 0);
     rb(e + "/res_block/0", X, A, c, n, h, w, false);
-    rb(e + "/res_block/1", X, A, c, n, h, w, true);  // n = relu(res_block(...)); skip = n
-    *skip = X;
     T* Pl = talloc(px / 4 * c);
-    pool(X, Pl, n, h, w, c);
+    // ops.py:54: the pooled map is a second store of the level's last conv where that conv runs on the F(4x4) kernel (r03)
+    const bool fused = pool_fuses(e + "/res_block/1/conv/1", c, h, w);
+    rb(e + "/res_block/1", X, A, c, n, h, w, true, fused ? Pl : nullptr);  // n = relu(res_block(...)); skip = n
+    *skip = X;
+    if (!fused) pool(X, Pl, n, h, w, c);
     return Pl;
   }
   // Bottleneck_res ops.py:59-63
