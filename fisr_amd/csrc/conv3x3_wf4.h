@@ -37,6 +37,8 @@
 //   * The fp32 MFMA and the vector ALU of a SIMD do not overlap (probed), so every vector instruction is paid on top of the MFMAs:
 //     the transforms are packed fp32 (op_sel: 6 instructions per 6 -> 6 row), the bias rides in accumulator (1,1), the relu of
 //     relu-on-load layers is applied once per element in LDS, record offsets ride in the scalar operand of the buffer instructions.
+//   * Persistent (one workgroup per CU walks its work items, copy and transform streams run on into the next item); the 2x2 max
+//     pooling behind an encoder level (ops.py:54) is a second store of that level's last convolution (POOL instantiation).
 #pragma once
 #include <algorithm>
 #include <type_traits>

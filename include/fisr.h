@@ -73,9 +73,11 @@ enum {
   FISR_PREC_MIXEDR = 7, /* engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
   FISR_PREC_F32W4 = 8  /* fp32 activations/weights and arithmetic like FISR_PREC_F32W, with Winograd F(4x4,3x3) (conv3x3_wf4.h: 36
                           multiplies per 4x4 outputs on v_mfma_f32_16x16x4_f32, a quarter of the direct algorithm's) for the
-                          convolutions with Cout % 64 == 0 on maps of at least 48 x 64 pixels (op level: on every map); smaller maps
-                          and the rest as in FISR_PREC_F32W.  The F(4,3) transforms are worse conditioned: ~1e-5 instead of ~1e-6
-                          per convolution against float64 -- the accuracy class of FISR_PREC_BF16X3, still fp32 tensors. */
+                          convolutions with Cout % 64 == 0 on maps of at least 48 x 64 pixels and on 512-channel maps (op level: on
+                          every map); smaller maps and the rest as in FISR_PREC_F32W; the 2x2 max pooling behind an encoder level
+                          is a second store of that level's last convolution.  The F(4,3) transforms are worse conditioned: ~2e-5
+                          instead of ~2e-6 per convolution against float64 -- through the network it does not add up (1.5e-6 on the
+                          full tile, the F(2x2) engine's figure).  What fisrnet.py's "fp32" selects since round 3. */
 };
 
 /* flags of fisr_op_conv3x3 */
