@@ -974,6 +974,17 @@ def test_winograd_vs_direct_random_large_shapes():
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_winograd_f4_vs_direct_random_large_shapes():
+    """The same campaign for the F(4x4) kernel (persistent items, raw pairs across the concat boundary, lane-transposed stores on
+    ragged tiles, in-place residual, d2s); 200 cases passed when the kernel was written."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = os.environ.get("FISR_WINO_CAMPAIGN", "16")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "wino_campaign.py"), cases, "11", "f4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,flags", [(1, 8, 32, 64, 6, 0), (2, 13, 45, 64, 3, 1), (1, 37, 70, 32, 6, 3), (3, 5, 9, 64, 5, 0),
                                                    (1, 64, 96, 64, 6, 1), (1, 16, 33, 128, 2, 2)])
 def test_fp32_heads_on_the_vector_alu_vs_oracle(n, h, w, cin, cout, flags):
