@@ -185,8 +185,10 @@ def _pmc_key(name):
         return "conv3x3_dma_f16_kernel<false>"
     if name.startswith("conv3x3_wf4"):
         if "res+pool" in name:
-            return "conv3x3_wf4_kernel<false, true, true>"
-        return "conv3x3_wf4_kernel<%s, %s, false>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
+            return "conv3x3_wf4_kernel<false, true, true, false>"
+        if "up2" in name:
+            return "conv3x3_wf4_kernel<false, false, false, true>"
+        return "conv3x3_wf4_kernel<%s, %s, false, false>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
     tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
     if name.startswith("conv3x3_wino"):
         return "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")

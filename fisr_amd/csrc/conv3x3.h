@@ -426,6 +426,7 @@ struct ConvArgs {
   // conv3x3_wf4.h only: when not NULL, the 2x2 max pooling of the output ([N,H/2,W/2,Cout], ops.py:54) as a second store of the
   // epilogue -- a Winograd tile holds whole pooling windows (H, W even; not with depth_to_space)
   void* pool_out = nullptr;
+  int ups = 0;              // conv3x3_wf4.h: in0 is [N, H/2, W/2, C0] and enters through the legacy x2 bilinear (ops.py:69) on its way into LDS
 };
 
 template <typename T, int NT> constexpr size_t conv_lds_bytes() {

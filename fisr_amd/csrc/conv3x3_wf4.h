@@ -63,6 +63,10 @@ constexpr int F4_V_BYTES = 36 * 32 * F4_CH * 4;        // 18432
 // packed horizontal pass of the input transform leaves its outputs (t0 t5 t1 t3 t2 t4).
 __host__ __device__ constexpr int wf4_slot(int i, int j) { return 6 * i + (j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 4 : j == 3 ? 3 : j == 4 ? 5 : 1); }
 constexpr size_t wf4_lds_bytes() { return (size_t)2 * F4_U_BYTES + 2 * F4_V_BYTES + 2 * (2 * F4_RAW_BYTES); }   // 151552
+// UPS (fused x2 bilinear): two staging buffers for the HALF-resolution halo of a raw pair -- 10 x 18 pixels (192 slots) in two
+// 16-byte planes, one per chunk of the pair -- behind the raw buffers: 163840 bytes, all of a CU's LDS
+constexpr int F4_L_ROWS = 10, F4_L_COLS = 18, F4_L_PLANE = 3072, F4_L_BYTES = 2 * F4_L_PLANE;
+constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; }
 
 // FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
 // 4 no input transform, 16 no MFMAs, 128 workgroups de-phased at start, 256 wait for the stores behind the epilogue, 512 one store
@@ -114,12 +118,19 @@ __device__ __forceinline__ void wf4_at(float m0, float m1, float m2, float m3, f
 
 // POOL: p.pool_out gets the 2x2 max pooling of the output as a second store of the epilogue (its own instantiation: the sixteen
 // registers of the pooled pixels cost the other layers 1.5-3 % in spills around the output stage).
-template <bool RELU_IN, bool HAS_RES, bool POOL = false>
+// UPS: p.in0 is the HALF-resolution map [N, H/2, W/2, C0] and the convolution runs on its x2 bilinear enlargement (ops.py:69,
+// tf.image.resize_images(BILINEAR), the TF-1.13 legacy kernel of glue_kernels.h upsample2) without that tensor ever existing: the
+// copy waves fetch the 10 x 18 half-resolution pixels under a halo tile (a quarter of the bytes and a third of the requests of the
+// full-resolution halo) into a staging buffer and blend them into the raw pair buffer where the relu-on-load pass of the other
+// instantiations sits -- one 2 x 2 output quad per lane, out[2i+1] = x[i] + (x[i+1] - x[i]) / 2, out[2i+2] = x[i+1], the same
+// operations in the same order as the stand-alone kernel (fma(d, 0.5, a) rounds like a + d * 0.5: the product is exact).
+template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false>
 __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sU = smem;
   char* const sV = smem + 2 * F4_U_BYTES;
   char* const sR = smem + 2 * F4_U_BYTES + 2 * F4_V_BYTES;
+  char* const sL = smem + wf4_lds_bytes();         // (UPS only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -198,7 +209,30 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? (const float*)p.in1 + (size_t)it.nb * img_px * p.C1 : (const float*)p.in0), 0,
                                             (unsigned)(img_px * (p.in1 ? p.C1 : p.C0) * 4), 0x00020000);
   };
-  raw_geom(cur);
+  // UPS: the lane's staging slots instead.  Wave-piece wp = cw (piece 0) and, waves 4-5, 4 + cw (piece 1) of the six 1-KB pieces
+  // of a staged pair: plane wp / 3 (= chunk of the pair), slots 64 (wp % 3) + lane; slot -> half-resolution pixel
+  // (y0 / 2 - 1 + slot / 18, x0 / 2 - 1 + slot % 18), clamped into the map (the bilinear's edge rule; what lies outside the
+  // ENLARGED map is zeroed when the quads are written).
+  unsigned lro[2] = {OOB, OOB};
+  auto ups_geom = [&](const Item& it) __attribute__((always_inline)) {
+    const int hl = p.H >> 1, wl = p.W >> 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      const int wp = j == 0 ? cw : 4 + cw;
+      const int plane = wp >= 3 ? 1 : 0;
+      const int s = (wp - 3 * plane) * 64 + l;
+      const int ly = s / F4_L_COLS, lx = s - ly * F4_L_COLS;
+      const int sy = min(max((it.y0 >> 1) - 1 + ly, 0), hl - 1), sx = min(max((it.x0 >> 1) - 1 + lx, 0), wl - 1);
+      lro[j] = s < F4_L_ROWS * F4_L_COLS ? (unsigned)(sy * wl + sx) * (unsigned)(p.C0 * 4) + (unsigned)plane * 16u : OOB;
+    }
+    // (no size check in this resource -- every offset is clamped into the map, the unused slots carry the out-of-range marker 2^31:
+    //  a size derived from p.C0 * 4 is computed on the vector ALU beside the offsets above, which turns the whole resource into
+    //  vector registers that the copies' "s" operands cannot take)
+    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.in0 + (size_t)it.nb * ((size_t)hl * wl) * p.C0), 0, 0x7fffffffu, 0x00020000);
+  };
+  if constexpr (UPS) ups_geom(cur); else raw_geom(cur);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpk, 0, (unsigned)((size_t)nch * nblocks * F4_U_BYTES), 0x00020000);
   const unsigned raw_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sR + (unsigned)cw * 1024u;
   const unsigned u_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sU;
@@ -266,6 +300,69 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       asm("v_max_f32 %0, 0, %0" : "+v"(f.z)); asm("v_max_f32 %0, 0, %0" : "+v"(f.w));
       *reinterpret_cast<f32x4*>(b + j * 4096) = f;
     }
+  };
+
+  // UPS: staged piece j (0; 1: waves 4-5 only) of pair pc into staging buffer lb
+  const unsigned l_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sL;
+  auto copy_l1 = [&](int pc, int lb, int j) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)pc * 32u;
+    const unsigned lds = l_lds0 + (unsigned)lb * (unsigned)F4_L_BYTES + (unsigned)(j == 0 ? cw : 4 + cw) * 1024u;
+    const unsigned o = j == 0 ? lro[0] : lro[1];
+    FISR_F4_DMA1(rs0, o, so, lds);
+  };
+  // UPS: quad q = 64 cw + lane of the 9 x 17 quads of a halo tile (waves 4-6; the lanes behind quad 152 repeat it): staging
+  // pixels (qy, qx) .. (qy + 1, qx + 1) -> halo pixels (2 qy + a, 2 qx + b); one 16-byte plane entry per pixel and chunk in, the
+  // chunk's half of four raw records out (record slot and half as the raw copies of the other instantiations lay them out).
+  int e_la = 0, e_r0 = 0, e_r1 = 0;
+  if constexpr (UPS) {
+    const int q = min(cw * 64 + lane, 152), qy = q / 17, qx = q - qy * 17;
+    e_la = (qy * F4_L_COLS + qx) * 16;
+    const int f16 = ((qy >> 1) & 1) * 16;
+    e_r0 = (2 * qy * F4_HW + ((qx & 1) ? 18 : 0) + (qx >> 1)) * 32 + f16;
+    e_r1 = (2 * qy * F4_HW + ((qx & 1) ? 26 : 9) + (qx >> 1)) * 32 + f16;
+  }
+  f32x4 e_tl, e_tr, e_bl, e_br;
+  auto ex_read = [&](int lb, int c) __attribute__((always_inline)) {
+    const char* b = sL + lb * F4_L_BYTES + c * F4_L_PLANE + e_la;
+    e_tl = *reinterpret_cast<const f32x4*>(b);
+    e_tr = *reinterpret_cast<const f32x4*>(b + 16);
+    e_bl = *reinterpret_cast<const f32x4*>(b + F4_L_COLS * 16);
+    e_br = *reinterpret_cast<const f32x4*>(b + F4_L_COLS * 16 + 16);
+  };
+  // (ey0, ex0: origin of the item the pair belongs to)
+  auto ex_write = [&](int pb, int c, int ey0, int ex0) __attribute__((always_inline)) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    // a * 0.5 + c: the inline constant sits in the low half of its 64-bit operand, op_sel_hi = 0 hands it to both halves
+    auto fma2 = [](f2_t a, f2_t c2) { f2_t r; asm("v_pk_fma_f32 %0, %1, 0.5, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c2)); return r; };
+    auto sub2 = [](f2_t a, f2_t b2) { f2_t r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b2)); return r; };
+    f32x4 oD, oC, oB;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f2_t tl = {e_tl[2 * h], e_tl[2 * h + 1]}, tr = {e_tr[2 * h], e_tr[2 * h + 1]};
+      const f2_t bl = {e_bl[2 * h], e_bl[2 * h + 1]}, br = {e_br[2 * h], e_br[2 * h + 1]};
+      const f2_t A = fma2(sub2(tr, tl), tl);        // odd row, odd column: top
+      const f2_t B = fma2(sub2(br, bl), bl);        //                      bottom = even row, odd column
+      const f2_t C = fma2(sub2(br, tr), tr);        // odd row, even column
+      const f2_t D = fma2(sub2(B, A), A);
+      oD[2 * h] = D.x; oD[2 * h + 1] = D.y; oC[2 * h] = C.x; oC[2 * h + 1] = C.y; oB[2 * h] = B.x; oB[2 * h + 1] = B.y;
+    }
+    f32x4 oE = e_br;                                    // even row, even column
+    const bool interior = ey0 > 0 && ex0 > 0 && ey0 + F4_TH + 1 <= p.H && ex0 + F4_TW + 1 <= p.W;     // (uniform) the whole halo inside the map
+    if (!interior) {
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      const int q = min(cw * 64 + l, 152), qy = q / 17, qx = q - qy * 17;
+      const int gy = ey0 - 1 + 2 * qy, gx = ex0 - 1 + 2 * qx;
+      const bool ya = gy >= 0 && gy < p.H, yb = gy + 1 < p.H, xa = gx >= 0 && gx < p.W, xb = gx + 1 < p.W;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      oD = ya && xa ? oD : z; oC = ya && xb ? oC : z; oB = yb && xa ? oB : z; oE = yb && xb ? oE : z;
+    }
+    char* r = sR + pb * (2 * F4_RAW_BYTES);
+    const int a0 = e_r0 ^ (c * 16), a1 = e_r1 ^ (c * 16);
+    *reinterpret_cast<f32x4*>(r + a0) = oD;
+    *reinterpret_cast<f32x4*>(r + a1) = oC;
+    *reinterpret_cast<f32x4*>(r + a0 + F4_HW * 32) = oB;
+    *reinterpret_cast<f32x4*>(r + a1 + F4_HW * 32) = oE;
   };
 
   // (Measured and dropped: touching the residual tile's 128-byte lines ahead of the epilogue -- one dword per line into a register
@@ -401,7 +498,15 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 #define FISR_F4_MMA4Z(Q, A, B) FISR_F4_MMA4C(Q, A, B, ((Q) == 2 ? bias4 : zero4), zero4, zero4, zero4)
 
   // ---- prologue of the workgroup's FIRST item: raw(0), U(0), raw(1), raw(2), raw(3) requested; raw(0) -> V[0] ----
-  if (wave >= 4) {
+  if (UPS && wave >= 4) {        // UPS: staged pairs 0 and 1, U(0); everything landed before the barrier (the quads read other waves' pieces)
+    copy_l1(0, 0, 0);
+    if (cw < 2) copy_l1(0, 0, 1);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) copy_u1(cur.nblk, 0, 0, j);
+    copy_l1(1, 1, 0);
+    if (cw < 2) copy_l1(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (wave >= 4) {
     raw_offsets(true);
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_pair1(0, 0, j);
@@ -418,6 +523,10 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   lds_barrier();
+  if constexpr (UPS) {
+    if (wave >= 4 && cw < 3) { ex_read(0, 0); ex_write(0, 0, cur.y0, cur.x0); ex_read(0, 1); ex_write(0, 1, cur.y0, cur.x0); }
+    lds_barrier();
+  }
   if (wave < 2) transform(rh0_t{}, 0, 0, 0);
   else if (wave < 4) transform(rh1_t{}, 0, 0, 0);
   lds_barrier();
@@ -457,7 +566,17 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     if (ROLE < 2 && !(FISR_F4ABL & 4)) tr_read(pbt, ODD ? 0 : 1);
     // odd iterations request the raw pair (k + 3) / 2: of this item, of the next one (its geometry from k = nch - 3 on), or a repeat
     int pc = 0;
-    if constexpr (ROLE == 2 && ODD) {
+    int ey0 = 0, ex0 = 0;
+    if constexpr (ROLE == 2 && UPS && !ODD) {
+      // UPS: even iterations blend the pair (k + 2) / 2 out of staging buffer pbt ^ 1 and request the pair (k + 4) / 2 into the other
+      const int pp = (k + 4) >> 1, np = nch >> 1;
+      pc = pp < np ? pp : (has_next ? pp - np : np - 1);
+      if (k == nch - 4 && has_next) ups_geom(nxt);
+      const int cy0 = cur.y0, cx0 = cur.x0, ny0 = nxt.y0, nx0 = nxt.x0;
+      const bool of_next = k + 2 >= nch;
+      ey0 = of_next ? ny0 : cy0; ex0 = of_next ? nx0 : cx0;
+    }
+    if constexpr (ROLE == 2 && ODD && !UPS) {
       const int pp = (k + 3) >> 1, np = nch >> 1;
       pc = pp < np ? pp : (has_next ? pp - np : np - 1);
       const bool rfirst = 2 * pc < nch0;
@@ -485,6 +604,16 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           if (q == FISR_F4_COLQ) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
           if (q >= FISR_F4_ROWQ && q < FISR_F4_ROWQ + 3) { tr_row(q - FISR_F4_ROWQ); tr_write(RH{}, buf ^ 1, q - FISR_F4_ROWQ); }
         }
+      } else if constexpr (UPS) {
+        if constexpr (!ODD) {
+          if (cw < 3) {
+            if (q == 4) ex_read(pbt ^ 1, 0);
+            if (q == 5) ex_write(pbt ^ 1, 0, ey0, ex0);
+            if (q == 6) ex_read(pbt ^ 1, 1);
+            if (q == 7) ex_write(pbt ^ 1, 1, ey0, ex0);
+          }
+          if (q == 5) { copy_l1(pc, pbt, 0); if (cw < 2) copy_l1(pc, pbt, 1); }     // (behind this iteration's five weight copies)
+        }
       } else if constexpr (ODD) {
         if (q == 5) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
         if (q == 6) { copy_pair1(pc, pbt ^ 1, 2); copy_pair1(pc, pbt ^ 1, 3); }
@@ -498,7 +627,9 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ROLE == 2 && ODD) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
+    if (ROLE == 2 && UPS && !ODD) {                                           // U(g+1) landed; the staged pair stays in flight
+      if (cw < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else if (ROLE == 2 && ODD && !UPS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // U(g+1) (and the raw pair of the iteration before) landed
     lds_barrier();
     if (!ODD) pbt ^= 1;
@@ -743,6 +874,9 @@ inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
+    hipError_t eu = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)wf4_lds_bytes_ups());
+    if (eu != hipSuccess) return eu;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
     n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -752,11 +886,15 @@ inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
   if (!plain || !wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s) || a.CoutPad != a.Cout) return hipErrorInvalidValue;
   // (fused pooling: instantiated for what FISRnet needs it for, the last conv of an encoder level -- residual, no relu-on-load)
   if (a.pool_out && (a.d2s || (a.H & 1) || (a.W & 1) || a.relu_in || !a.res)) return hipErrorInvalidValue;
+  // (fused x2 bilinear: the decoder's resize convolution -- one source, no relu-on-load, no residual)
+  if (a.ups && ((a.H & 1) || (a.W & 1) || a.C1 || a.relu_in || a.res || a.pool_out)) return hipErrorInvalidValue;
   const int items = ((a.W + F4_TW - 1) / F4_TW) * ((a.H + F4_TH - 1) / F4_TH) * a.N * (a.CoutPad / F4_BN);
   // one workgroup per CU (the kernel needs most of a CU's LDS and half its registers), a multiple of 8 so that the items of a
   // workgroup stay on one XCD
   const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
-  if (a.pool_out) {
+  if (a.ups) {
+    hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false, false, true>), dim3(grid), dim3(512), wf4_lds_bytes_ups(), st, a, items);
+  } else if (a.pool_out) {
     hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true, true>), dim3(grid), dim3(512), lds, st, a, items);
   } else if (a.relu_in) {
     if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<true, true>), dim3(grid), dim3(512), lds, st, a, items);

@@ -704,9 +704,12 @@ struct Runner {
     return std::is_same<T, float>::value && ctx->wf4 && it != ctx->convs.end() && it->second.d_wu4 && wf4_fits(h, w, c, 0, it->second.co) &&
            wf4_wins(h, w, c) && !(h & 1) && !(w & 1);
   }
+  // (ups: in0 is the half-resolution map and the x2 bilinear of ops.py:69 happens on the conv's way into LDS -- only when up_fuses()
+  //  says this conv runs on the F(4x4) Winograd kernel; h, w are the ENLARGED map's)
+  bool up_fuses(const std::string& name, int c, int h, int w) { return pool_fuses(name, c, h, w); }      // (the same conditions)
   void conv(const std::string& name, const T* in0, int c0, const T* in1, int c1, const T* res, void* out,
             int n, int h, int w, int flags, bool out_f32 = false, int cstride = 0, int coff = 0,
-            int split = 1 << 30, int gap = 0, void* pool_out = nullptr) {
+            int split = 1 << 30, int gap = 0, void* pool_out = nullptr, bool ups = false) {
     if (rc) return;
     auto it = ctx->convs.find(name);
     if (it == ctx->convs.end()) { rc = fail(ctx, FISR_EMISSING, "unknown conv " + name); return; }
@@ -739,12 +742,16 @@ struct Runner {
       if (!use_wf4) { rc = fail(ctx, FISR_ESTATE, name + ": fused pooling asked of a conv that does not run on the F(4x4) kernel"); return; }
       a.pool_out = pool_out;
     }
+    if (ups) {
+      if (!use_wf4) { rc = fail(ctx, FISR_ESTATE, name + ": fused up-sampling asked of a conv that does not run on the F(4x4) kernel"); return; }
+      a.ups = 1;
+    }
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     const bool use_dma = std::is_same<T, _Float16>::value && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
     if (use_dma) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
     char cls[96];
     if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
-    else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
+    else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : ups ? "up2" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
@@ -755,7 +762,7 @@ struct Runner {
       cname = name.substr(name.find("level_")) + shp;
     }
     ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
-                 px * (double)(c0 + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
+                 px * (double)((ups ? c0 * 0.25 : c0) + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
     check(use_dma ? launch_conv_dma(a, st)
                   : use_wf4 ? launch_conv_wf4(a, st)
                   : use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
@@ -826,12 +833,14 @@ struct Runner {
   T* dec_level(const std::string& P, int l, const T* cur, int cc, const T* skip, int n, int h, int w) {
     const int c = widths()[l];
     const std::string d = P + "/dec/level_" + std::to_string(l);
-    T* U = talloc((size_t)n * h * w * 4 * cc);
-    up(cur, U, n, h, w, cc);
+    // tf.image.resize_images + Conv2d: on the F(4x4) kernel the enlarged map never exists (conv3x3_wf4.h, UPS)
+    const bool fused = up_fuses(d + "/resize", cc, 2 * h, 2 * w);
+    T* U = fused ? nullptr : talloc((size_t)n * h * w * 4 * cc);
+    if (!fused) up(cur, U, n, h, w, cc);
     h *= 2; w *= 2;
     const size_t px = (size_t)n * h * w;
     T* D = talloc(px * c);
-    conv(d + "/resize", U, cc, nullptr, 0, nullptr, D, n, h, w, FISR_CONV_RELU_OUT);
+    conv(d + "/resize", fused ? cur : U, cc, nullptr, 0, nullptr, D, n, h, w, FISR_CONV_RELU_OUT, false, 0, 0, 1 << 30, 0, nullptr, fused);
     T* X = talloc(px * c);
     T* A = talloc(px * c);
     conv(d + "/conv/0", D, c, skip, c, nullptr, X, n, h, w, 0);  // concat([n, skip])
@@ -1278,6 +1287,9 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   if (((c0 % cc || c1 % cc) && !dma_op) || (c1 && !in1)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: channels must be multiples of the chunk");
   if ((flags & FISR_CONV_D2S) && (cout % 4 || !is_pow2(cout / 4) || cout / 4 < CONV_REC))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: d2s needs cout/4 to be a power of two >= 16 (whole 16-channel records)");
+  if ((flags & FISR_CONV_UP2_IN) && (precision != FISR_PREC_F32W4 || out_f32 || !wf4_fits(h, w, c0, c1, cout) || (h & 1) || (w & 1) || c1 || res ||
+                                     (flags & (FISR_CONV_RELU_IN | FISR_CONV_D2S))))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: FISR_CONV_UP2_IN is fused on the F(4x4) kernel only (FISR_PREC_F32W4, even h / w, one source, no residual, relu-on-load or d2s)");
   DeviceGuard guard(device_of(out));
   HIP_OK(nullptr, guard.err);
   ConvW cw;
@@ -1298,6 +1310,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
+  a.ups = (flags & FISR_CONV_UP2_IN) != 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
   // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)

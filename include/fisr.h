@@ -84,7 +84,12 @@ enum {
 enum {
   FISR_CONV_RELU_IN = 1,  /* conv(relu(x))           ops.py:41-42 */
   FISR_CONV_RELU_OUT = 2, /* relu(conv(x) [+ res])   ops.py:52,62,70,75 */
-  FISR_CONV_D2S = 4       /* tf.depth_to_space(y, 2) fused into the store, FISRnet.py:99 */
+  FISR_CONV_D2S = 4,      /* tf.depth_to_space(y, 2) fused into the store, FISRnet.py:99 */
+  FISR_CONV_UP2_IN = 8    /* conv(resize_images(x, 2x, BILINEAR)), ops.py:69-70 (Dec_level_res): in0 is the HALF-resolution map
+                             [n, h/2, w/2, c0] and is enlarged on its way into the kernel.  fisr_op_conv3x3 takes it where the
+                             F(4x4) Winograd kernel does the work (FISR_PREC_F32W4; h, w even; cout % 64 == 0; c0 % 8 == 0; no
+                             in1 / res / RELU_IN / D2S) and returns FISR_EINVAL elsewhere: compose fisr_op_upsample2 +
+                             fisr_op_conv3x3 there, as the engines do */
 };
 
 const char* fisr_version(void);

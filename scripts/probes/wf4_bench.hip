@@ -38,6 +38,24 @@ __global__ void ref_conv(const float* in, const float* w, const float* b, const 
   out[i] = (float)s;
 }
 
+// the legacy x2 bilinear (glue_kernels.h upsample2), one thread per output element
+__global__ void ref_up2(const float* in, float* out, int N, int H, int W, int C) {
+#pragma clang fp contract(off)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * 4 * H * W * C) return;
+  const int c = i % C;
+  size_t p = i / C;
+  const int ox = p % (2 * W); p /= 2 * W;
+  const int oy = p % (2 * H);
+  const int n = p / (2 * H);
+  const int y0 = oy >> 1, x0 = ox >> 1, y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ty = (oy & 1) ? 0.5f : 0.f, tx = (ox & 1) ? 0.5f : 0.f;
+  auto at = [&](int y, int x) { return in[((size_t)(n * H + y) * W + x) * C + c]; };
+  const float top = at(y0, x0) + (at(y0, x1) - at(y0, x0)) * tx;
+  const float bot = at(y1, x0) + (at(y1, x1) - at(y1, x0)) * tx;
+  out[i] = top + (bot - top) * ty;
+}
+
 int main(int argc, char** argv) {
   const bool check = argc > 1 && !strcmp(argv[1], "check");
   std::string shapes = getenv("WF4_SHAPES") ? getenv("WF4_SHAPES")
@@ -50,7 +68,8 @@ int main(int argc, char** argv) {
     int n, h, w, ci, co, fl, rs;
     if (sscanf(shapes.substr(pos, e - pos).c_str(), "%d,%d,%d,%d,%d,%d,%d", &n, &h, &w, &ci, &co, &fl, &rs) != 7) break;
     pos = e + 1;
-    const size_t in_e = (size_t)n * h * w * ci, out_e = (size_t)n * h * w * co;
+    const bool ups = fl & 8;            // flags bit 3: the input is the half-resolution map (fused x2 bilinear)
+    const size_t in_e = (size_t)n * h * w * ci / (ups ? 4 : 1), out_e = (size_t)n * h * w * co;
     std::vector<float> hw((size_t)9 * ci * co), hb(co), hin(in_e), hres(rs ? out_e : 0);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((int)(st >> 9) % 2001 - 1000) * 1e-3f; };
@@ -72,7 +91,7 @@ int main(int argc, char** argv) {
     a.in0 = d_in; a.wpk = d_wp; a.bias = d_b; a.res = d_res; a.out = d_out;
     a.C0 = ci; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = co; a.CoutPad = co;
     a.in0_cs = ci; a.rec_cs = co; a.dil = 1;
-    a.relu_in = fl & 1; a.relu_out = (fl >> 1) & 1; a.d2s = 0;
+    a.relu_in = fl & 1; a.relu_out = (fl >> 1) & 1; a.d2s = 0; a.ups = ups;
     const int items = ((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n * (co / F4_BN);
     unsigned long long* d_tr;
     const size_t tr_rows = (size_t)items + 256 * 9;
@@ -81,7 +100,12 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_ref, out_e * 4));
       CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
       CK(launch_conv_wf4(a, nullptr));
-      hipLaunchKernelGGL(ref_conv, dim3((out_e + 255) / 256), dim3(256), 0, nullptr, d_in, d_w, d_b, d_res, d_ref, n, h, w, ci, co, fl & 1, (fl >> 1) & 1);
+      float* d_full = d_in;
+      if (ups) {
+        CK(hipMalloc(&d_full, in_e * 4 * 4));
+        hipLaunchKernelGGL(ref_up2, dim3((in_e * 4 + 255) / 256), dim3(256), 0, nullptr, d_in, d_full, n, h / 2, w / 2, ci);
+      }
+      hipLaunchKernelGGL(ref_conv, dim3((out_e + 255) / 256), dim3(256), 0, nullptr, d_full, d_w, d_b, d_res, d_ref, n, h, w, ci, co, fl & 1, (fl >> 1) & 1);
       CK(hipDeviceSynchronize());
       std::vector<float> o(out_e), r(out_e);
       CK(hipMemcpy(o.data(), d_out, out_e * 4, hipMemcpyDeviceToHost));
@@ -90,6 +114,7 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < out_e; ++i) { double d = fabs((double)o[i] - r[i]); if (!(d <= 1e-3)) ++bad; if (d > mx) mx = d; ss += d * d; }
       printf("check %dx%dx%d %d->%d f%d r%d: max %.3e rms %.3e bad %zu %s\n", n, h, w, ci, co, fl, rs, mx, sqrt(ss / out_e), bad, bad ? "FAIL" : "ok");
       CK(hipFree(d_w)); CK(hipFree(d_ref));
+      if (ups) CK(hipFree(d_full));
     } else {
       for (int i = 0; i < 2; ++i) CK(launch_conv_wf4(a, nullptr));
       hipEvent_t e0, e1;

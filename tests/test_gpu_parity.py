@@ -283,6 +283,54 @@ def test_conv3x3_fp32_winograd_f4_vs_oracle(dev, shape):
         assert got.min() >= 0
 
 
+@pytest.mark.parametrize("shape", [
+    (1, 16, 32, 16, 64, 0),        # one work item, every halo pixel on a border
+    (1, 32, 64, 32, 64, 2),        # 2 x 2 items: every corner / edge combination
+    (2, 40, 100, 64, 64, 2),       # ragged right / bottom tiles
+    (1, 18, 46, 16, 64, 0),        # a tile row of two pixel rows, a tile column of fourteen
+    (1, 48, 96, 128, 128, 2),      # interior item (no border handling), two output blocks
+    (1, 34, 62, 512, 256, 2),      # the level-1 decoder's deepest resize conv
+])
+def test_conv3x3_fp32_winograd_f4_fused_bilinear_vs_oracle(dev, shape):
+    """FISR_CONV_UP2_IN (Dec_level_res, ops.py:69-70): conv(resize_images(x, 2x, BILINEAR)) with the enlargement fused into the
+    F(4x4) kernel's copy stage, against the oracle's resize_bilinear_x2 + fp64 conv -- and against the library's own two-launch
+    composition (fisr_op_upsample2 + the same kernel), which it must match BIT FOR BIT: the blend is the same operations in the
+    same order, only where they happen differs."""
+    n, h, w, c0, cout, flags = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31) + 11)
+    x = rng.standard_normal((n, h // 2, w // 2, c0)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, c0, cout)) * np.sqrt(2.0 / (9 * c0))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    L = flib.lib()
+    dx = torch.from_numpy(x).cuda()
+    out = torch.empty((n, h, w, cout), device="cuda")
+    flib.check(L.fisr_op_conv3x3(ctypes.c_void_p(dx.data_ptr()), c0, None, 0, _fp(wt), _fp(b), cout, None, ctypes.c_void_p(out.data_ptr()),
+                                 n, h, w, flags | flib.CONV_UP2_IN, 8, 0, _stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    big = O.resize_bilinear_x2(x)
+    assert big.shape == (n, h, w, c0)
+    exp = ref_conv(big.astype(np.float32), wt, b, None, None, flags)
+    _report(got, exp, 40 * F32_OP_TOL, f"fused bilinear + winograd F(4x4) conv {shape}")
+    up = torch.empty((n, h, w, c0), device="cuda")
+    flib.check(L.fisr_op_upsample2(ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(up.data_ptr()), n, h // 2, w // 2, c0, 0, _stream()))
+    two = hip_conv(up.cpu().numpy(), wt, b, None, None, flags, prec="fp32w4")
+    assert np.array_equal(got, two), f"fused != upsample2 + conv: max {np.abs(got - two).max():.3e}"
+
+
+def test_conv3x3_fused_bilinear_is_refused_where_it_is_not_implemented(dev):
+    """FISR_CONV_UP2_IN outside the F(4x4) kernel's reach: FISR_EINVAL with a message, never a silent full-resolution read."""
+    L = flib.lib()
+    x = torch.zeros((1, 8, 16, 16), device="cuda")
+    out = torch.empty((1, 16, 32, 64), device="cuda")
+    wt = np.zeros((3, 3, 16, 64), np.float32)
+    b = np.zeros(64, np.float32)
+    for prec, flags, hh in ((0, 0, 16), (7, 0, 16), (8, flib.CONV_RELU_IN, 16), (8, 0, 15)):
+        rc = L.fisr_op_conv3x3(ctypes.c_void_p(x.data_ptr()), 16, None, 0, _fp(wt), _fp(b), 64, None, ctypes.c_void_p(out.data_ptr()),
+                               1, hh, 32, flags | flib.CONV_UP2_IN, prec, 0, _stream())
+        assert rc == -1, (prec, flags, hh, rc)            # FISR_EINVAL
+
+
 def test_conv3x3_fp32_winograd_f4_residual_in_place(dev):
     """res_block's conv/1 writes onto its residual (ops.py:43): every element is read and written by the same lane."""
     L = flib.lib()
