@@ -1,7 +1,7 @@
 // Stand-alone micro-benchmark + self-check of the F(4x4,3x3) Winograd kernel (conv3x3_wf4.h): builds in seconds, for kernel
 // iterations.  Diagnostics only (the parity tests of record are tests/test_gpu_parity.py through the C-ABI).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ifisr_amd/csrc -Iinclude scripts/probes/wf4_bench.hip -o scripts/probes/wf4_bench
-//   wf4_bench [check]      shapes: WF4_SHAPES="n,h,w,cin,cout,flags,res;..."
+//   wf4_bench [check]      shapes: WF4_SHAPES="n,h,w,cin,cout,flags,res;..."   flags: 1 relu-on-load, 2 relu, 8 fused x2 bilinear (h, w: the enlarged map)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
