@@ -174,6 +174,18 @@ def test_one_default_precision_everywhere():
     assert 'ap.add_argument("--precision", default="fp32"' in src
 
 
+def test_python_mirror_of_the_header_enums():
+    """fisr_amd/lib.py repeats include/fisr.h's precision and conv-flag values (ctypes has no header): they must not drift."""
+    import re
+    from fisr_amd import lib as flib
+    header = open(os.path.join(ROOT, "include", "fisr.h")).read()
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(FISR_(?:PREC|CONV)_[A-Z0-9_]+)\s*=\s*(\d+)", header)}
+    assert len(enums) >= 13, enums
+    for name, value in enums.items():
+        mirror = name[len("FISR_"):]
+        assert getattr(flib, mirror) == value, (name, value, getattr(flib, mirror, None))
+
+
 def test_xavier_initialiser_and_lr_schedule():
     """ops.py:8-9: xavier_initializer(uniform=False) = truncated normal, stddev sqrt(1.3 * 2 / (fan_in + fan_out)), zero
     biases; FISRnet.py:227-245: tf.train.piecewise_constant switches one step AFTER a boundary."""
