@@ -92,6 +92,10 @@ constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; 
 #ifndef FISR_F4_UQ
 #define FISR_F4_UQ 0
 #endif
+// the plain residual instantiation issues ALL 36 weight copies of a chunk from the copy waves (A/B hook: 0 = the 4 + 5 split of the others)
+#ifndef FISR_F4_UALL
+#define FISR_F4_UALL 1
+#endif
 #ifndef FISR_F4_U_AUX
 #define FISR_F4_U_AUX ""         // cache-policy bits of the weight copies (A/B hook: " nt", " sc1", " sc0 sc1")
 #endif
@@ -248,8 +252,14 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
                  : [keep] "=&s"(keep_) : [rs] "s"(RS), [lds] "s"(LDS), [o] "v"(VOFF), [so] "s"(SOFF) : "memory", "scc"); \
   } while (0)
   // weight copy j (0..3; 4: waves 4-7 only) of chunk kc of N block nblk into U[buf]
+  // (UALL: all 36 on waves 4-7, copy cw + 4 j, j = 0..8: the transform waves then have no memory instruction and no vmcnt wait in
+  //  the K loop at all, and the instantiation stops spilling.  Only where the copy waves have nothing else to do -- the plain
+  //  residual layers: 3.4 % faster inside the network (same box, two rounds: 50.4 -> 48.7 ms per 66 launches).  With the relu pass
+  //  on the copy waves it costs 2.4 % (87.8 -> 89.9 ms per 94 launches), with the blend of the fused bilinear 3-4 %, with the
+  //  pooling epilogue 1 %, plain without residual nothing; splits that left the transform waves 2-5 copies each: +-1 %.)
+  constexpr bool UALL = FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL && !UPS;
   auto copy_u1 = [&](int nblk, int kc, int buf, int j) __attribute__((always_inline)) {
-    unsigned c = (j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave)) + u_rot;
+    unsigned c = (UALL ? (unsigned)(cw + 4 * j) : j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave)) + u_rot;
     c = c >= 36u ? c - 36u : c;
     const unsigned so = (unsigned)(((size_t)kc * nblocks + nblk) * F4_U_BYTES) + c * 1024u;
     const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES + c * 1024u;
@@ -368,7 +378,10 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   // (Measured and dropped: touching the residual tile's 128-byte lines ahead of the epilogue -- one dword per line into a register
   //  nobody reads, all 1024 lines two iterations before the end or 256 per iteration over the last four -- so that the epilogue's
   //  loads would hit L2.  The epilogue of a residual layer did shrink by 4k cycles, but the K loop grew by 10-15k: a CU gets ~10
-  //  bytes per cycle out of HBM (its outstanding misses over the HBM latency) wherever the 128 KB are requested.)
+  //  bytes per cycle out of HBM (its outstanding misses over the HBM latency) wherever the 128 KB are requested.  Third attempt,
+  //  with the suspicion that the in-order vmcnt waits of the issuing waves were to blame: the touches as LDS-DMA copies into a dump
+  //  area from transform waves that have NO other memory instruction (see UALL), in one burst 4 or 6 iterations before the end or a
+  //  quarter per iteration from 8 or 12 before: epilogue -6k cycles, K loop +4..8k -- no wait involved, it is the CU's memory path.)
 
   // =========================== transform side (waves 0-3: tile half wave & 1, transform rows 3 (wave >> 1) ..) ===========================
   // lane -> (channel of the chunk, tile): 8 tiles of one tile row x 4 channels per ds_read_b32 phase.  The two waves of a tile
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     copy_l1(0, 0, 0);
     if (cw < 2) copy_l1(0, 0, 1);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) copy_u1(cur.nblk, 0, 0, j);
+    for (int j = 0; j < (UALL ? 9 : 5); ++j) copy_u1(cur.nblk, 0, 0, j);
     copy_l1(1, 1, 0);
     if (cw < 2) copy_l1(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -511,13 +524,13 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_pair1(0, 0, j);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) copy_u1(cur.nblk, 0, 0, j);
+    for (int j = 0; j < (UALL ? 9 : 5); ++j) copy_u1(cur.nblk, 0, 0, j);
     if (2 >= nch0) raw_offsets(false);
 #pragma unroll
     for (int j = 0; j < 5; ++j) copy_pair1(1, 1, j);
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // pair 0, U(0) landed; pair 1 in flight
     if constexpr (RELU_IN) { relu_read(0, 0); relu_write(0, 0); relu_read(0, 1); relu_write(0, 1); }
-  } else {
+  } else if (!UALL) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) copy_u1(cur.nblk, 0, 0, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -598,7 +611,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         rb[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(vb + (q + 2) * 2048);
       }
       if constexpr (FIRST) { FISR_F4_MMA4Z(q, ra[q % 3], rb[q % 3]) } else { FISR_F4_MMA4(q, ra[q % 3], rb[q % 3]) }
-      if (!(FISR_F4ABL & 1) && q >= FISR_F4_UQ && q - FISR_F4_UQ < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q - FISR_F4_UQ);
+      if constexpr (UALL) {
+        if (ROLE == 2 && !(FISR_F4ABL & 1)) {
+          if (q < 4) { copy_u1(u_nblk, ku, buf ^ 1, 2 * q); copy_u1(u_nblk, ku, buf ^ 1, 2 * q + 1); }
+          if (q == 4) copy_u1(u_nblk, ku, buf ^ 1, 8);
+        }
+      } else if (!(FISR_F4ABL & 1) && q >= FISR_F4_UQ && q - FISR_F4_UQ < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q - FISR_F4_UQ);
       if constexpr (ROLE < 2) {
         if (!(FISR_F4ABL & 4)) {
           if (q == FISR_F4_COLQ) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
@@ -620,7 +638,10 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         if (q == 7) copy_pair1(pc, pbt ^ 1, 4);
       } else if constexpr (RELU_IN) {
         // the pair requested an iteration ago is older than this iteration's five weight copies
-        if (q == 4) { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); relu_read(pbt ^ 1, 0); }
+        if (q == 4) {
+          if constexpr (UALL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          relu_read(pbt ^ 1, 0);
+        }
         if (q == 5) relu_write(pbt ^ 1, 0);
         if (q == 6) relu_read(pbt ^ 1, 1);
         if (q == 7) relu_write(pbt ^ 1, 1);
@@ -630,6 +651,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     if (ROLE == 2 && UPS && !ODD) {                                           // U(g+1) landed; the staged pair stays in flight
       if (cw < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     } else if (ROLE == 2 && ODD && !UPS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
+    else if (ROLE < 2 && UALL) { }                                           // (nothing of this wave's to wait for)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // U(g+1) (and the raw pair of the iteration before) landed
     lds_barrier();
     if (!ODD) pbt ^= 1;
