@@ -168,6 +168,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   const int nch0 = p.C0 / F4_CH, nch = (p.C0 + p.C1) / F4_CH;       // (the launcher guarantees nch >= 4)
 
   if (FISR_F4ABL & 128) { for (int i = 0; i < (int)((blockIdx.x * 7u) & 31u); ++i) __builtin_amdgcn_s_sleep(4); }     // ablation: de-phase the workgroups
+  // Static priority 1 for the copy waves where they carry the most beside their MFMAs -- the bilinear blend (3.3 % faster inside the
+  // network, same box, two rounds) and all 36 weight copies of the plain residual instantiation (0.8 %); on the relu-on-load and
+  // plain instantiations the same costs 3.7 % / 4.7 %, and priority for the transform waves changes nothing anywhere.
+#ifndef FISR_F4_PRIO
+  if ((UPS || (FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL)) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef FISR_F4_PRIO
   if (FISR_F4_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // A/B: static priority for the younger / the older half
   if (FISR_F4_PRIO == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
