@@ -69,7 +69,7 @@ constexpr int F4_L_ROWS = 10, F4_L_COLS = 18, F4_L_PLANE = 3072, F4_L_BYTES = 2 
 constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; }
 
 // FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
-// 4 no input transform, 16 no MFMAs, 128 workgroups de-phased at start, 256 wait for the stores behind the epilogue, 512 one store
+// 4 no input transform, 16 no MFMAs, 128 workgroups de-phased at start, 256 wait for the stores behind the epilogue, 1024 no barrier, 2048 no vmcnt wait at the end of an iteration, 512 one store
 // per lane instead of 16 (earlier versions: 2 no raw copies, 32 / 64 raw access patterns)
 #ifndef FISR_F4ABL
 #define FISR_F4ABL 0
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     it.x0 = tx * F4_TW;
     it.y0 = (t % tiles_y) * F4_TH;
     it.nb = t / tiles_y;
+    if (FISR_F4ABL & 4096) { it.x0 = (tx & 1) * F4_TW; it.y0 = 0; it.nb = 0; }      // (ablation 4096: every item works on two tiles of image 0 -- no DRAM traffic)
     return it;
   };
   int b_cur = blockIdx.x;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(FISR_F4ABL & 1024)) __builtin_amdgcn_s_barrier();       // (ablation 1024: no barrier -- what the rendezvous of the 8 waves costs)
     asm volatile("" ::: "memory");
   };
   // relu-on-load: applied ONCE per element, in LDS, by the wave that requested the copy (the transform lanes would apply it
@@ -654,7 +655,8 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ROLE == 2 && UPS && !ODD) {                                           // U(g+1) landed; the staged pair stays in flight
+    if (FISR_F4ABL & 2048) { }                                                // (ablation 2048: no wait for the copies at the end of an iteration)
+    else if (ROLE == 2 && UPS && !ODD) {                                           // U(g+1) landed; the staged pair stays in flight
       if (cw < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     } else if (ROLE == 2 && ODD && !UPS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
     else if (ROLE < 2 && UALL) { }                                           // (nothing of this wave's to wait for)

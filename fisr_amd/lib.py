@@ -83,7 +83,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, define
     if not diag and not out and not force and not needs_build():
         return SO_PATH
     os.makedirs(os.path.dirname(target), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
            f'-DFISR_SRC_HASH="{source_hash()}"'] + (["-DFISR_DIAG"] if diag else []) + [f"-D{d}" for d in defines] + \
           ["-o", target, os.path.join(CSRC, "fisr_api.hip")]
     if verbose:

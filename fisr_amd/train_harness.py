@@ -150,6 +150,7 @@ def run_train(args):
     start_time = time.time()
     keymap = (("data15", "data"), ("label21", "label"), ("flow16", "flow"), ("warp24", "warp"), ("flow_ss2", "flow_ss2"), ("warp_ss2", "warp_ss2"))
     last = float("nan")
+    written_prev = []        # files of the checkpoint THIS run wrote last (tf.train.Saver._last_checkpoints: restore() never registers the loaded one)
     for epoch in range(start_epoch, args.epoch):
         rows = []
         rand_idx = np.random.permutation(n - nv)
@@ -222,12 +223,15 @@ def run_train(args):
                 tf_bundle.write_bundle(os.path.join(ckpt_dir, name), Wn)
             with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
                 f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
-            # Saver(max_to_keep=1) (FISRnet.py:585): the previous step's files go once the state file names the new ones
-            for fn in os.listdir(ckpt_dir):
-                stem = fn.split(".")[0]
-                if stem.startswith("FISRnet-") and stem != name and fn != "checkpoint":
+            # Saver(max_to_keep=1) (FISRnet.py:585): the previous checkpoint SAVED BY THIS RUN goes once the state file names the new
+            # one.  A checkpoint the run was restored from (a pretrained / inference-only bundle the user put here) was never
+            # registered with the Saver and stays, exactly as under the reference.
+            written_now = [fn for fn in os.listdir(ckpt_dir) if fn.split(".")[0] == name]
+            for fn in written_prev:
+                if fn not in written_now:
                     try:
                         os.remove(os.path.join(ckpt_dir, fn))
                     except OSError:
                         pass
+            written_prev = written_now
     return last

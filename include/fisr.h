@@ -25,6 +25,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the FISR_API entries below are its whole dynamic surface
+ * (tests/test_host.py asserts that `nm -D` shows exactly these). */
+#ifndef FISR_API
+#define FISR_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -92,41 +98,41 @@ enum {
                              fisr_op_conv3x3 there, as the engines do */
 };
 
-const char* fisr_version(void);
+FISR_API const char* fisr_version(void);
 
 /* ---- context: owns the (re-packed) weights; replaces the tf.Session + variables ---- */
-int fisr_create(fisr_ctx** out, int device_id);
-void fisr_destroy(fisr_ctx* ctx);
+FISR_API int fisr_create(fisr_ctx** out, int device_id);
+FISR_API void fisr_destroy(fisr_ctx* ctx);
 /* ctx may be NULL: returns the last error of the calling thread. */
-const char* fisr_last_error(const fisr_ctx* ctx);
+FISR_API const char* fisr_last_error(const fisr_ctx* ctx);
 
 /* Weight seam (replaces saver.restore, FISRnet.py:1108).  `tf_var_name` is the
  * reference's variable name, e.g. "FISRnet/level_3/dec/level_0/resize/w"; `host` is the
  * float32 tensor in TF layout (HWIO for .../w, [Cout] for .../b); copied.  Names outside
  * the 276 FISRnet variables (Adam slots, global step) are ignored with return 1. */
-int fisr_set_weight(fisr_ctx* ctx, const char* tf_var_name, const float* host,
+FISR_API int fisr_set_weight(fisr_ctx* ctx, const char* tf_var_name, const float* host,
                     const int64_t* shape, int rank);
 /* Re-pack for the MFMA kernels and upload.  Fails with FISR_EMISSING (naming the first
  * absent variable) unless all 276 tensors were set. */
-int fisr_finalize_weights(fisr_ctx* ctx, int precision);
-int fisr_num_variables_set(const fisr_ctx* ctx);
+FISR_API int fisr_finalize_weights(fisr_ctx* ctx, int precision);
+FISR_API int fisr_num_variables_set(const fisr_ctx* ctx);
 
 /* Graph seam.  in: [n,h,w,29] float32; h % 32 == 0 and w % 32 == 0 (FISRnet.py:820-824).
  * out_l3 [n,2h,2w,9] float32 (required); out_l2 [n,h,w,9], out_l1 [n,h/2,w/2,9] optional
  * (NULL to skip the copy-out).  workspace: caller-owned device scratch of at least
  * fisr_workspace_bytes(ctx,n,h,w). */
-size_t fisr_workspace_bytes(const fisr_ctx* ctx, int n, int h, int w);
-int fisr_forward(fisr_ctx* ctx, const float* in_nhwc29, int n, int h, int w,
+FISR_API size_t fisr_workspace_bytes(const fisr_ctx* ctx, int n, int h, int w);
+FISR_API int fisr_forward(fisr_ctx* ctx, const float* in_nhwc29, int n, int h, int w,
                  float* out_l3, float* out_l2, float* out_l1,
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Per-kernel timing (HIP events on `stream` around every launch of the next forwards).
  * Off by default; bench.py uses it for the roofline figure of the dominant kernel. */
-int fisr_profile_enable(fisr_ctx* ctx, int on);
-int fisr_profile_reset(fisr_ctx* ctx);
+FISR_API int fisr_profile_enable(fisr_ctx* ctx, int on);
+FISR_API int fisr_profile_reset(fisr_ctx* ctx);
 /* Fills up to `cap` entries; returns the number of kernel classes.  name[i] points into
  * ctx-owned storage.  flops = algorithmic 2*9*Cin*Cout*pixels summed over launches. */
-int fisr_profile_read(fisr_ctx* ctx, int cap, const char** name, double* total_ms,
+FISR_API int fisr_profile_read(fisr_ctx* ctx, int cap, const char** name, double* total_ms,
                       int64_t* launches, double* flops, double* bytes);
 
 /* ---- glue kernels (HBM-bound) ---- */
@@ -135,42 +141,42 @@ int fisr_profile_read(fisr_ctx* ctx, int cap, const char** name, double* total_m
  * OTHER frame of the pair), flow [h,w,2] float32 pixels, flow_scale 0.5 (:122,126),
  * quantized!=0 reproduces cv2.remap's 1/32-px fixed-point coordinates.
  * dst_yuv [h,w,3] float32 0..255 (what the reference stores in the .mat file). */
-int fisr_warp(const float* src_yuv, const float* flow, float flow_scale, int h, int w,
+FISR_API int fisr_warp(const float* src_yuv, const float* flow, float flow_scale, int h, int w,
               int quantized, float* dst_yuv, void* stream);
 
 /* Input assembly for window s (FISRnet.py:828-843): frames_u8 [3][h0,w0,3] uint8 YUV
  * given as three device pointers, flow4 [4][h0,w0,2] float32 px and warp4 [4][h0,w0,3]
  * float32 0..255 given as four pointers each; crops to h x w (top-left), normalises
  * (/255 clip01; /96/2 clip+-1; /255 clip01) and writes [1,h,w,29] float32. */
-int fisr_pack_input(const uint8_t* const* frames3, const float* const* flow4,
+FISR_API int fisr_pack_input(const uint8_t* const* frames3, const float* const* flow4,
                     const float* const* warp4, int h0, int w0, int h, int w,
                     float* out_nhwc29, void* stream);
 
 /* Output post-processing (FISRnet.py:883,903-909): pred [h,w,9] float32 -> clip[0,1],
  * yuv_u8 [h,w,9] = uint8(x*255) (truncation), rgb_u8 [3][h,w,3] = YUV2RGB_matlab(yuv)
  * truncated (either may be NULL). */
-int fisr_unpack_output(const float* pred_hw9, int h, int w, uint8_t* yuv_u8, uint8_t* rgb_u8,
+FISR_API int fisr_unpack_output(const float* pred_hw9, int h, int w, uint8_t* yuv_u8, uint8_t* rgb_u8,
                        void* stream);
 
 /* Copy the trimmed interior of a tile prediction into the full frame
  * (trim_patch_boundary utils.py:138-159 + the stitch at FISRnet.py:879-880).
  * tile [th,tw,9] -> full[fh,fw,9] at (dst_y,dst_x), taking rows/cols from (src_y,src_x),
  * size (ch,cw). */
-int fisr_stitch(const float* tile, int th, int tw, int src_y, int src_x, int ch, int cw,
+FISR_API int fisr_stitch(const float* tile, int th, int tw, int src_y, int src_x, int ch, int cw,
                 float* full, int fh, int fw, int dst_y, int dst_x, void* stream);
 
 /* Sum of squared error of a prediction against uint8 ground truth, in double, as the
  * reference's PSNR sees it (utils.py:23-26 over FISRnet.py:828-831,883):
  * sum((gt_u8/255.0 - clip(pred,0,1))^2).  The result is written to *out_host after the
  * stream is synchronised. */
-int fisr_sse_vs_u8(const float* pred, const uint8_t* gt_u8, size_t count, double* out_host,
+FISR_API int fisr_sse_vs_u8(const float* pred, const uint8_t* gt_u8, size_t count, double* out_host,
                    void* stream);
 
 /* SSIM the way the reference's SSIM_PIL.compare_ssim computes it on two uint8 images
  * (FISRnet.py:890-891): non-overlapping 7x7 tiles per channel, C1=(0.01*255)^2, C2=(0.03*255)^2,
  * unbiased variance, mean over tiles and the 3 channels.  a, b: [h,w,cstride] uint8, the frame's
  * three channels start at channel `coff`.  Result in *out_host after synchronising the stream. */
-int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, int coff,
+FISR_API int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, int coff,
                  double* out_host, void* stream);
 
 /* ---- op-level entry points (parity tests of the individual kernels) ---- */
@@ -183,16 +189,16 @@ int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, 
  * One output image (h * w * cout elements of the activation type) must stay below 4 GB: the kernels address it with
  * 32-bit byte offsets (FISR_EHIP otherwise; the 2x2 tiles of a 1080p frame are 0.55 GB at most).
  * Synchronous (packs and uploads the weights on every call). */
-int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host,
+FISR_API int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host,
                     const float* b_host, int cout, const void* res, void* out, int n, int h,
                     int w, int flags, int precision, int out_f32, void* stream);
-int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
-int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
+FISR_API int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
+FISR_API int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
 
 /* Micro-benchmark of one conv shape (diagnostics; not on the product path): runs `iters`
  * launches of the conv kernel on self-allocated buffers and returns the mean microseconds per
  * launch in *out_us. */
-int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res,
+FISR_API int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res,
                     int iters, double* out_us);
 
 /* ---- multi-GPU exchange: thin RCCL wrappers (north_star: "2K->4K tiles shard across the 8 GPUs of one
@@ -203,16 +209,16 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
 typedef struct fisr_comm fisr_comm;
 #define FISR_COMM_ID_BYTES 128
 /* Rank 0 creates the id (host buffer of FISR_COMM_ID_BYTES) and hands it to the other ranks out of band. */
-int fisr_comm_unique_id(void* id_out);
-int fisr_comm_init(fisr_comm** out, const void* id, int nranks, int rank, int device_id);
-int fisr_comm_rank(const fisr_comm* comm);
-int fisr_comm_size(const fisr_comm* comm);
+FISR_API int fisr_comm_unique_id(void* id_out);
+FISR_API int fisr_comm_init(fisr_comm** out, const void* id, int nranks, int rank, int device_id);
+FISR_API int fisr_comm_rank(const fisr_comm* comm);
+FISR_API int fisr_comm_size(const fisr_comm* comm);
 /* recv[r * bytes_per_rank ...] = send of rank r (device buffers; asynchronous on stream): the gather of
  * halo strips before a tile-parallel forward and of output tiles after it. */
-int fisr_comm_allgather(fisr_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+FISR_API int fisr_comm_allgather(fisr_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 /* Exchange `bytes` with one neighbour (send and receive fused in one group; peer may be the own rank). */
-int fisr_comm_sendrecv(fisr_comm* comm, const void* send, void* recv, size_t bytes, int peer, void* stream);
-void fisr_comm_destroy(fisr_comm* comm);
+FISR_API int fisr_comm_sendrecv(fisr_comm* comm, const void* send, void* recv, size_t bytes, int peer, void* stream);
+FISR_API void fisr_comm_destroy(fisr_comm* comm);
 
 /* ---- on-GPU optical flow (cfg5 of BASELINE.json): PWC-Net-large as
  * `FISR_for_video_Compute_Flow` runs it before FISRnet (main.py:207-211;
@@ -221,42 +227,42 @@ void fisr_comm_destroy(fisr_comm* comm);
  * ('pwcnet/featpyr/conv1a/kernel' [3,3,3,16] HWIO, '.../bias', 'pwcnet/predict_flow/conv6_0/kernel', 'pwcnet/ctxt/dc_conv21/kernel',
  * 'pwcnet/upsample/up_feat3/kernel' [4,4,2,Cin], ...): what `pwcnet.ckpt-595000` (script :31) holds. ---- */
 typedef struct fisr_pwc fisr_pwc;
-int fisr_pwc_create(fisr_pwc** out, int device_id);
-void fisr_pwc_destroy(fisr_pwc* ctx);
-const char* fisr_pwc_last_error(const fisr_pwc* ctx);
+FISR_API int fisr_pwc_create(fisr_pwc** out, int device_id);
+FISR_API void fisr_pwc_destroy(fisr_pwc* ctx);
+FISR_API const char* fisr_pwc_last_error(const fisr_pwc* ctx);
 /* the 182 variables the inference graph needs: count, then name/shape of variable i (returns the rank) */
-int fisr_pwc_num_variables(void);
-int fisr_pwc_variable(int i, const char** name, int64_t* shape4);
+FISR_API int fisr_pwc_num_variables(void);
+FISR_API int fisr_pwc_variable(int i, const char** name, int64_t* shape4);
 /* host float32 tensor in TF layout; unknown names (optimizer slots, ...) are ignored with return 1 */
-int fisr_pwc_set_weight(fisr_pwc* ctx, const char* tf_var_name, const float* host, const int64_t* shape, int rank);
-int fisr_pwc_finalize(fisr_pwc* ctx);   /* FISR_EMISSING names the first absent variable; = ..._precision(ctx, FISR_PREC_F32W) */
+FISR_API int fisr_pwc_set_weight(fisr_pwc* ctx, const char* tf_var_name, const float* host, const int64_t* shape, int rank);
+FISR_API int fisr_pwc_finalize(fisr_pwc* ctx);   /* FISR_EMISSING names the first absent variable; = ..._precision(ctx, FISR_PREC_F32W) */
 /* precision FISR_PREC_F32W: float32 tensors and arithmetic (dense layers on the Winograd kernel).  FISR_PREC_F16 (cfg5 of
  * BASELINE.json, "bf16"-class 16-bit arithmetic): fp16 feature tensors, fp32 accumulation, float32 flows (flow heads, refinement
  * sums, what is handed to the next level and to the caller); dense layers on the LDS-DMA kernel. */
-int fisr_pwc_finalize_precision(fisr_pwc* ctx, int precision);
+FISR_API int fisr_pwc_finalize_precision(fisr_pwc* ctx, int precision);
 /* The script's whole loop (:104-141) in one call: nframes YUV uint8 frames [h,w,3] (device pointers) -> flows
  * [nframes-1, 2, h, w, 2] float32 LR pixels (pair fr: [0] = fr -> fr+1, [1] = fr+1 -> fr; the layout of the script's 5-D .flo).
  * Every frame is pre-processed and its feature pyramid extracted once, the 2 (nframes-1) directions go through the decoder as
  * batches of up to 8. */
-size_t fisr_pwc_flow_stack_workspace_bytes(const fisr_pwc* ctx, int nframes, int h, int w);
-int fisr_pwc_flow_stack(fisr_pwc* ctx, const uint8_t* const* yuv_frames, int nframes, int h, int w, float* flows, void* workspace,
+FISR_API size_t fisr_pwc_flow_stack_workspace_bytes(const fisr_pwc* ctx, int nframes, int h, int w);
+FISR_API int fisr_pwc_flow_stack(fisr_pwc* ctx, const uint8_t* const* yuv_frames, int nframes, int h, int w, float* flows, void* workspace,
                         size_t workspace_bytes, void* stream);
 /* One iteration of the script's loop (:118-140): two YUV uint8 frames [h,w,3] (device) -> YUV->RGB, x2 scikit-image
  * up-resize, uint8 truncation, /255, pad to 64 (adapt_x, model_pwcnet.py:371-411), the network in both directions,
  * x4 bilinear * 4 (:1587-1590), crop, anti-aliased scikit-image down-resize, / 2 -> flow_ab, flow_ba [h,w,2] float32
  * LR pixels (device): pred[fr, 0] and pred[fr, 1] of the script's 5-D .flo. */
-size_t fisr_pwc_flow_workspace_bytes(const fisr_pwc* ctx, int h, int w);
-int fisr_pwc_flow_pair(fisr_pwc* ctx, const uint8_t* yuv_a, const uint8_t* yuv_b, int h, int w, float* flow_ab,
+FISR_API size_t fisr_pwc_flow_workspace_bytes(const fisr_pwc* ctx, int h, int w);
+FISR_API int fisr_pwc_flow_pair(fisr_pwc* ctx, const uint8_t* yuv_a, const uint8_t* yuv_b, int h, int w, float* flow_ab,
                        float* flow_ba, void* workspace, size_t workspace_bytes, void* stream);
 /* The network alone (model_pwcnet.py:1525-1593) on a prepared pair: im [2,H,W,4] device float32 (image a, image b;
  * RGB/255 and a zero 4th channel; H, W multiples of 64).  flow_pred [2,H,W,2] (a->b, b->a; nullable); pyr: 10 nullable
  * device pointers, refined flows of levels 6..2 [H/2^l, W/2^l, 2] for a->b then b->a (nullable). */
-size_t fisr_pwc_nn_workspace_bytes(const fisr_pwc* ctx, int H, int W);
-int fisr_pwc_nn(fisr_pwc* ctx, const float* im, int H, int W, float* flow_pred, float* const* pyr, void* workspace,
+FISR_API size_t fisr_pwc_nn_workspace_bytes(const fisr_pwc* ctx, int H, int W);
+FISR_API int fisr_pwc_nn(fisr_pwc* ctx, const float* im, int H, int W, float* flow_pred, float* const* pyr, void* workspace,
                 size_t workspace_bytes, void* stream);
 /* the two pre/post-processing kernels on their own (parity tests): yuv [h,w,3] -> out [PH,PW,4]; flow2 [FH,FW,2] -> out [h,w,2] */
-int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream);
-int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream);
+FISR_API int fisr_pwc_prep(const uint8_t* yuv, int h, int w, float* out, int PH, int PW, void* stream);
+FISR_API int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int w, void* stream);
 /* Op-level entries: one layer of the flow network exactly as the network launches it (parity tests at the sizes the
  * bench runs).  precision: FISR_PREC_F32W (float32 tensors) or FISR_PREC_F16 (fp16 feature tensors; `add` and any out_f32 /
  * in_f32 tensor stay float32 -- the flows).
@@ -270,13 +276,13 @@ int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, int h, int
  * fisr_pwc_op_deconv = tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196), w_host [4,4,2,ci];
  * fisr_pwc_op_costvol = core_costvol.cost_volume + leaky relu (:1277), 81 channels; fisr_pwc_op_warp = core_warp.dense_image_warp
  * (:1178) at (x + scale*u, y + scale*v). */
-int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
+FISR_API int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
                      const int* chmap, void* out, int out_f32, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h,
                      int w, int stride, int dil, float slope, int route, int precision, void* stream);
-int fisr_pwc_op_deconv(const void* in, int in_f32, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci,
+FISR_API int fisr_pwc_op_deconv(const void* in, int in_f32, int in_cs, int in_co, int cin4, const float* w_host, const float* b_host, int ci,
                        const int* chmap, void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream);
-int fisr_pwc_op_costvol(const void* c1, const void* c2, int c, void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream);
-int fisr_pwc_op_warp(const void* img, int c, const void* flow, int f_cs, int f_co, float scale, void* out, int n, int h, int w, int precision,
+FISR_API int fisr_pwc_op_costvol(const void* c1, const void* c2, int c, void* out, int out_cs, int out_co, int n, int h, int w, int precision, void* stream);
+FISR_API int fisr_pwc_op_warp(const void* img, int c, const void* flow, int f_cs, int f_co, float scale, void* out, int n, int h, int w, int precision,
                      void* stream);
 
 /* ---- training graph: the ops the reference gets from TensorFlow's autodiff and optimizer ----
@@ -289,10 +295,10 @@ int fisr_pwc_op_warp(const void* img, int c, const void* flow, int f_cs, int f_c
  * _s2d = the gradient of tf.depth_to_space (FISRnet.py:99); _copy_channels = the gradients of tf.concat / tf.split /
  * tf.slice; _loss = FISRnet.py:316-484 for one level (values and gradients); _adam = tf.train.AdamOptimizer
  * (FISRnet.py:490-491). */
-size_t fisr_train_packed_bytes(int ci, int co, int transpose);
-int fisr_train_pack(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
-size_t fisr_train_wino_bytes(int ci, int co, int transpose);      /* 0: not eligible for the Winograd kernel */
-int fisr_train_pack_wino(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
+FISR_API size_t fisr_train_packed_bytes(int ci, int co, int transpose);
+FISR_API int fisr_train_pack(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
+FISR_API size_t fisr_train_wino_bytes(int ci, int co, int transpose);      /* 0: not eligible for the Winograd kernel */
+FISR_API int fisr_train_pack_wino(const float* d_w_hwio, int ci, int co, int transpose, void* d_packed, void* stream);
 /* every layout of n convs in ONE launch (what a training step does after Adam): d_descs is a DEVICE array of n descriptors;
  * a null destination skips that layout */
 typedef struct fisr_train_pack_desc {
@@ -301,28 +307,28 @@ typedef struct fisr_train_pack_desc {
   void* pkw; void* pkw_t;    /* fisr_train_pack_wino, transpose = 0 / 1 */
   int ci, co;
 } fisr_train_pack_desc;
-int fisr_train_pack_all(const fisr_train_pack_desc* d_descs, int n, void* stream);
+FISR_API int fisr_train_pack_all(const fisr_train_pack_desc* d_descs, int n, void* stream);
 /* d_packed_wino (nullable): the slabs of fisr_train_pack_wino; the call then runs the Winograd kernel and d_packed may be
  * NULL.  d_bias must be readable up to the N block's padding (cout rounded up to 64; 16 for the heads).
  * fisr_train_wgrad picks its kernel by shape: the Winograd-domain weight gradient where a 4x32 / 8x16 / 16x8 / 8x8-pixel
  * tile covers the map to >= 75 %, the direct pixel-axis GEMM otherwise, a vector-ALU kernel for co <= 8 (the heads). */
-int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed /* nullable, see above */,
+FISR_API int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const void* d_packed /* nullable, see above */,
                        const float* d_bias, int cout, const float* res, float* out, int n, int h, int w, int flags,
                        int out_cstride, int out_coff, int out_split, int out_gap, const void* d_packed_wino /* nullable */,
                        void* stream);
-int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw,
+FISR_API int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw,
                      float* db /* nullable */, int ci, int co, int n, int h, int w, void* stream);
-int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream);
-int fisr_train_relu_bwd(const float* g_in, const float* ref, float* g_out, size_t count, void* stream);
-int fisr_train_axpy(const float* x, float a, float* y, size_t count, void* stream);
-int fisr_train_maxpool2_bwd(const float* x, const float* dpool, float* dx, int n, int h, int w, int c, void* stream);
-int fisr_train_upsample2_bwd(const float* dy, float* dx, int n, int h, int w, int c, void* stream);
-int fisr_train_s2d(const float* g, float* out, int n, int h, int w, int c, void* stream);
-int fisr_train_copy_channels(const float* src, int scs, int sco, float* dst, int dcs, int dco, int nc, size_t npix,
+FISR_API int fisr_train_bgrad(const float* g, int cg, size_t npix, float* db, int co, void* stream);
+FISR_API int fisr_train_relu_bwd(const float* g_in, const float* ref, float* g_out, size_t count, void* stream);
+FISR_API int fisr_train_axpy(const float* x, float a, float* y, size_t count, void* stream);
+FISR_API int fisr_train_maxpool2_bwd(const float* x, const float* dpool, float* dx, int n, int h, int w, int c, void* stream);
+FISR_API int fisr_train_upsample2_bwd(const float* dy, float* dx, int n, int h, int w, int c, void* stream);
+FISR_API int fisr_train_s2d(const float* g, float* out, int n, int h, int w, int c, void* stream);
+FISR_API int fisr_train_copy_channels(const float* src, int scs, int sco, float* dst, int dcs, int dco, int nc, size_t npix,
                              int add, void* stream);
-int fisr_train_loss(const float* const* pred4, const float* gt, float* const* grad4, float* sums, size_t npix,
+FISR_API int fisr_train_loss(const float* const* pred4, const float* gt, float* const* grad4, float* sums, size_t npix,
                     const float* k7, void* stream);
-int fisr_train_adam(float* w, const float* g, float* m, float* v, size_t count, float lr_t, float b1, float b2,
+FISR_API int fisr_train_adam(float* w, const float* g, float* m, float* v, size_t count, float lr_t, float b1, float b2,
                     float eps, void* stream);
 
 #ifdef __cplusplus

@@ -9,7 +9,9 @@
 #include <cstring>
 #include <string>
 #define FISR_F4_TRACE 1
+#define FISR_F4X_TRACE 1
 #include "conv3x3_wf4.h"
+#include "diag/conv3x3_wf4x.h"
 using namespace fisr;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -56,7 +58,12 @@ __global__ void ref_up2(const float* in, float* out, int N, int H, int W, int C)
   out[i] = top + (bot - top) * ty;
 }
 
+// WF4X=1: the one-wave-per-SIMD kernel (conv3x3_wf4x.h)
+static bool g_x = false;
+static hipError_t launch_any(const ConvArgs& a, hipStream_t st) { return g_x ? launch_conv_wf4x(a, st) : launch_conv_wf4(a, st); }
+
 int main(int argc, char** argv) {
+  g_x = getenv("WF4X") && atoi(getenv("WF4X")) != 0;
   const bool check = argc > 1 && !strcmp(argv[1], "check");
   std::string shapes = getenv("WF4_SHAPES") ? getenv("WF4_SHAPES")
                      : check ? "1,40,100,64,64,3,1;2,24,24,64,128,1,0;1,17,45,16,64,0,0"
@@ -99,7 +106,7 @@ int main(int argc, char** argv) {
     if (check) {
       CK(hipMalloc(&d_w, hw.size() * 4)); CK(hipMalloc(&d_ref, out_e * 4));
       CK(hipMemcpy(d_w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-      CK(launch_conv_wf4(a, nullptr));
+      CK(launch_any(a, nullptr));
       float* d_full = d_in;
       if (ups) {
         CK(hipMalloc(&d_full, in_e * 4 * 4));
@@ -113,15 +120,28 @@ int main(int argc, char** argv) {
       double mx = 0, ss = 0; size_t bad = 0;
       for (size_t i = 0; i < out_e; ++i) { double d = fabs((double)o[i] - r[i]); if (!(d <= 1e-3)) ++bad; if (d > mx) mx = d; ss += d * d; }
       printf("check %dx%dx%d %d->%d f%d r%d: max %.3e rms %.3e bad %zu %s\n", n, h, w, ci, co, fl, rs, mx, sqrt(ss / out_e), bad, bad ? "FAIL" : "ok");
+      if (bad) {      // which channels / rows / columns are wrong
+        std::vector<size_t> bc(co, 0), by(h, 0), bx(w, 0);
+        int shown = 0;
+        for (size_t i = 0; i < out_e; ++i) {
+          if (fabs((double)o[i] - r[i]) <= 1e-3) continue;
+          const int c = i % co; size_t pp = i / co; const int x = pp % w; pp /= w; const int y = pp % h;
+          ++bc[c]; ++by[y]; ++bx[x];
+          if (shown++ < 6) printf("    [n %zu y %d x %d c %d] got %g ref %g\n", pp / h, y, x, c, o[i], r[i]);
+        }
+        printf("    bad channels:"); for (int c = 0; c < co; ++c) if (bc[c]) printf(" %d:%zu", c, bc[c]); printf("\n");
+        printf("    bad rows:"); for (int y = 0; y < h && y < 40; ++y) if (by[y]) printf(" %d:%zu", y, by[y]); printf("\n");
+        printf("    bad cols:"); for (int x = 0; x < w && x < 70; ++x) if (bx[x]) printf(" %d:%zu", x, bx[x]); printf("\n");
+      }
       CK(hipFree(d_w)); CK(hipFree(d_ref));
       if (ups) CK(hipFree(d_full));
     } else {
-      for (int i = 0; i < 2; ++i) CK(launch_conv_wf4(a, nullptr));
+      for (int i = 0; i < 2; ++i) CK(launch_any(a, nullptr));
       hipEvent_t e0, e1;
       CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 5;
       CK(hipEventRecord(e0, nullptr));
-      for (int i = 0; i < iters; ++i) CK(launch_conv_wf4(a, nullptr));
+      for (int i = 0; i < iters; ++i) CK(launch_any(a, nullptr));
       CK(hipEventRecord(e1, nullptr));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -129,7 +149,7 @@ int main(int argc, char** argv) {
       const double us = ms * 1e3 / iters;
       // one traced launch: per-workgroup {start, K-loop end, end, after output transform, after prologue, ...}
       a.trace = d_tr;
-      CK(launch_conv_wf4(a, nullptr));
+      CK(launch_any(a, nullptr));
       CK(hipDeviceSynchronize());
       std::vector<unsigned long long> tr(tr_rows * 8);
       CK(hipMemcpy(tr.data(), d_tr, tr_rows * 64, hipMemcpyDeviceToHost));

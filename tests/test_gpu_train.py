@@ -272,6 +272,10 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     # resuming for one more epoch continues from step 4 with that state
     assert main.main(argv[:4] + ["--epoch", "3"] + argv[6:]) == 0
     assert weights.find_checkpoint(d + "/ck", "FISRnet_exp1")[2] == 6
+    # ... and the checkpoint the run was RESTORED from stays (tf.train.Saver only prunes what it saved itself: restore() does not
+    # register the loaded files -- a user's pretrained bundle must survive a fine-tuning epoch)
+    left = sorted(f for f in os.listdir(os.path.join(d, "ck", "FISRnet_exp1")) if f != "checkpoint")
+    assert left == sorted(f"FISRnet-{s_}{e}" for s_ in (4, 6) for e in (".data-00000-of-00001", ".index", ".npz")), left
     net = FISRnet(device="cuda:0", precision="fp32")
     net.set_weights(W)
     x = torch.rand(1, 32, 32, 29, device="cuda:0")

@@ -3,6 +3,7 @@ loads and exports every symbol include/fisr.h declares (no compute without a GPU
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -82,6 +83,11 @@ def test_library_builds_loads_and_exports_header_symbols():
         assert hasattr(L, name), f"{name} declared in include/fisr.h but not exported"
     assert sorted(lib.EXPORTS) == declared
     assert b"gfx950" in L.fisr_version()
+    # the dynamic surface of the binary IS the header: -fvisibility=hidden + FISR_API, no C++ kernel stubs beside the C entries
+    assert len(re.findall(r"^FISR_API ", header, re.M)) == len(declared)
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in nm.splitlines() if l.split()[-2] in "TWBDRV")
+    assert exported == declared, sorted(set(exported) ^ set(declared))
 
 
 def test_product_never_imports_oracle():
