@@ -11,8 +11,9 @@ inner loops of `FISRnet.test` / `FISR_for_video` (reference FISRnet.py:798-910),
 = 7 unique 2048x3840 frames.  Flows and warped frames are pre-made inputs as in cfg2.
 
 The headline (`value`, `dtype`) is the fp32 engine -- cfg2 says fp32, the reference computes in fp32: fp32 tensors,
-fp32 arithmetic, Winograd F(2x2,3x3) minimal filtering for the 3x3 convolutions (as cuDNN does under the
-reference's TensorFlow); `fp32d` under `other_precisions` is the same engine with the direct exact-fp32 kernel.
+fp32 arithmetic, Winograd minimal filtering for the 3x3 convolutions (as cuDNN does under the reference's
+TensorFlow): F(4x4,3x3) on every map >= 48x64 and on the 512-channel maps, F(2x2,3x3) on the rest; under
+`other_precisions`, `fp32w` is the all-F(2x2) engine and `fp32d` the same engine with the direct exact-fp32 kernel.
 The split-precision engines (bf16x3, f16f8: fp32-grade results on the 16-bit / fp8 matrix pipes, far
 inside the reference tolerance of +-0.02 dB) are timed in the same run under `other_precisions`, each
 with its own roofline, its full-size comparison against the fp32 engine of this run and a check of one
@@ -30,7 +31,11 @@ Timing is barrier + synchronize on both sides, max over ranks.
 
 One JSON line is printed by rank 0.  `roofline` is measured in a second, instrumented pass (HIP events on
 the launch stream around every kernel, inside libfisr_hip.so; HIP events on the same stream around the glue
-calls); `cpu_baseline` times the C oracle (oracle/fisr_oracle.c, OpenMP, fp32) and `cpu_baseline_onednn`
+calls).  The counter-derived fields (`traffic`, `pmc_mfma_busy_frac`, `pmc_gb_per_launch`) are NOT measured by this
+process: they are read from profiles/pmc_traffic.json, the summary of a `rocprofv3 --pmc` run of this same command
+(scripts/gpu_profile.sh), every one carries `source` = that file + the library it was run on, and a field is
+dropped (null + `..._dropped`) when that library is not the running one or when the kernel's launches per step
+differ between the two runs; `cpu_baseline` times the C oracle (oracle/fisr_oracle.c, OpenMP, fp32) and `cpu_baseline_onednn`
 the torch-CPU/oneDNN twin (oracle/torch_cpu.py) on ONE full 544x992 tile on rank 0 at N=1.
 """
 import argparse
@@ -169,6 +174,82 @@ class Workload:
         return 3 * sum(t.in_h * t.in_w for t in self.tiles) * FLOP_PER_LR_PX
 
 
+PMC_SRC = None          # how the counter-derived fields of this line are labelled (set by _pmc_table)
+
+
+def _src_of(library):
+    """'... src <16 hex digits> ...' -> the hex digits"""
+    import re
+    m = re.search(r"src ([0-9a-f]{16})", library or "")
+    return m.group(1) if m else None
+
+
+def _pmc_table_checked(running_library):
+    """profiles/pmc_traffic.json, or {} when it was measured on another library (its `_meta.library` names the build): a counter
+    of another kernel build under this build's name would read as measured."""
+    global PMC_SRC
+    pmc = _pmc_table()
+    meta = pmc.pop("_meta", None) or {}
+    have, want = _src_of(meta.get("library")), _src_of(running_library)
+    if not pmc:
+        PMC_SRC = {"file": "profiles/pmc_traffic.json", "status": "absent"}
+        return {}, meta
+    if have is None or have != want:
+        PMC_SRC = {"file": "profiles/pmc_traffic.json", "status": "dropped: measured on library src %s, running src %s" % (have, want)}
+        return {}, meta
+    PMC_SRC = {"file": "profiles/pmc_traffic.json", "status": "same library", "library_src": have,
+               "how": "rocprofv3 --pmc, separate passes (FETCH_SIZE x 2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE), scripts/gpu_profile.sh"}
+    return pmc, meta
+
+
+def _pmc_same_population(entry, meta, launches_per_step):
+    """the PMC run averaged `dispatches` launches over `steps_per_pass` steps: the same kernel NAME with another launch population
+    (r03: the two maxpool2 launches the fp32 engine has left vs the 18 of the other engines) is not this kernel's traffic"""
+    steps = meta.get("steps_per_pass") or 0
+    if not steps or not entry.get("dispatches"):
+        return False
+    return abs(entry["dispatches"] / steps - launches_per_step) <= 0.1 * max(launches_per_step, 1)
+
+
+def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, rank, weight_bytes):
+    """Bytes this rank's step holds on its device, by item, and whether they fit (cfg2 workload; `gather_world` > 1: rank 0 also
+    holds the receive buffer of the frame gather).  The activation arena is what fisr_workspace_bytes says for the largest
+    forward batch of the plan -- the library's own figure, not an estimate."""
+    from fisr_amd import tiling
+    H0, W0 = 1080, 1920
+    h, w = tiling.crop_hw(H0, W0, patch)
+    tiles = tiling.plan_tiles(h, w, patch)
+    if parallelism == "tile":
+        t = tiles[topo.tile]
+        n_fwd, th, tw = 3, t.in_h, t.in_w                       # the rank's own tile of the 3 windows
+    else:
+        per = {"stack": 3 * len(tiles), "window": len(tiles), "tile": 1}[batch]
+        th, tw = max(t.in_h for t in tiles), max(t.in_w for t in tiles)
+        n_fwd = per
+    arena = int(net._L.fisr_workspace_bytes(net._ctx, n_fwd, th, tw))
+    out_f32 = 3 * (2 * h) * (2 * w) * 9 * 4
+    out_u8 = 3 * (2 * h) * (2 * w) * 9
+    items = {
+        "weights_packed_measured": int(weight_bytes),
+        "activation_arena": arena,
+        "forward_batch": [n_fwd, th, tw],
+        "inputs_frames_flows_warps": 5 * H0 * W0 * 3 + 8 * H0 * W0 * 2 * 4 + 8 * H0 * W0 * 3 * 4,
+        "packed_input_3_windows": 3 * h * w * 29 * 4,
+        "tile_batch_in_out": n_fwd * th * tw * 29 * 4 + n_fwd * 4 * th * tw * 9 * 4,
+        "stitched_output_f32": out_f32, "output_yuv_rgb_u8": 3 * out_u8,
+        "gather_send_buffers": 2 * out_u8 if gather_world > 1 else 0,
+        "gather_receive_buffer": gather_world * out_u8 if gather_world > 1 and rank == 0 else 0,
+    }
+    total = sum(v for k, v in items.items() if isinstance(v, int))
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    free_b += int(weight_bytes)                               # (the weights are already resident)
+    sharing = int(os.environ.get("FISR_BENCH_ONE_DEVICE", "0") == "1") and int(os.environ.get("WORLD_SIZE", "1")) or 1
+    budget = total_b // max(sharing, 1)                        # (test mode: all ranks share device 0)
+    return {"rank": rank, "device": str(dev), "bytes": items, "total_bytes": total, "device_total_bytes": int(total_b),
+            "device_free_bytes_now": int(free_b), "ranks_sharing_device": sharing,
+            "fits": bool(total * 1.05 <= budget)}              # 5 % for the allocator's rounding
+
+
 def _pmc_table():
     """HBM bytes per launch of every kernel, from the rocprofv3 PMC passes of this same command
     (scripts/gpu_profile.sh -> profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
@@ -240,7 +321,29 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     convs = [p for p in prof if p["name"].startswith("conv3x3") and p["launches"]]
     if not convs:
         return None
-    pmc = _pmc_table()
+    from fisr_amd import lib as _fl
+    pmc, pmc_meta = _pmc_table_checked(_fl.lib().fisr_version().decode())
+    lps = {p["name"]: p["launches"] / max(reps, 1) for p in prof}          # launches per step of this run, per kernel
+    dropped = []
+
+    def pmc_entry(key, name):
+        """the PMC table's entry for kernel `name` (table key prefix `key`), or None (and a note) when its launch population differs"""
+        hits = [v for k, v in pmc.items() if k.startswith(key)]
+        if not hits:
+            return None
+        e = max(hits, key=lambda v: v.get("dispatches", 0))
+        if not _pmc_same_population(e, pmc_meta, lps.get(name, 0)):
+            dropped.append("%s: %.1f launches per step in the PMC run, %.1f here" % (name, e.get("dispatches", 0) / max(pmc_meta.get("steps_per_pass") or 1, 1), lps.get(name, 0)))
+            return None
+        return e
+
+    def conv_field(name, field, scale=1.0):
+        try:
+            e = pmc_entry(_pmc_key(name), name)
+        except (KeyError, IndexError, ValueError):
+            e = None
+        return None if e is None or field not in e else round(e[field] * scale, 4)
+
     dom = max(convs, key=lambda p: p["ms"])
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     peak = PEAK[precision]
@@ -255,10 +358,10 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
                "algorithmic_gb_per_launch": round(alg_bytes / launches / 1e9, 4),
                "algorithmic_gbps": round(alg_bytes / (ms * 1e-3) / 1e9, 1)}
         rec["frac_of_hbm_peak"] = round(rec["algorithmic_gbps"] / HBM_PEAK_GBPS, 4)
-        hit = [v for k, v in pmc.items() if k.startswith(pmc_key)]
-        if hit:
-            b = max(hit, key=lambda v: v.get("dispatches", 0))["hbm_bytes_per_launch"]
-            rec["pmc_gb_per_launch"] = round(b / 1e9, 4)
+        e = pmc_entry(pmc_key, name) if name in lps else ([v for k, v in pmc.items() if k.startswith(pmc_key)] or [None])[0]
+        if e and "hbm_bytes_per_launch" in e:
+            rec["pmc_gb_per_launch"] = round(e["hbm_bytes_per_launch"] / 1e9, 4)
+            rec["pmc_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / max(alg_bytes / launches, 1.0), 3)
         hbm[name] = rec
 
     for p in prof:
@@ -279,15 +382,16 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     # algorithmic rate itself (which exceeds the fp32 peak for the Winograd kernel: it skips 20 of 36 multiplies) is kept
     # as `algorithmic_tflops` / `algorithmic_over_peak`.
     epa = executed_per_algorithmic(dom["name"])
-    busy = _pmc_field(pmc, dom["name"], "mfma_busy_frac")
+    busy = conv_field(dom["name"], "mfma_busy_frac")
     rl = {"bound": "mfma", "kernel": dom["name"], "achieved": round(epa * ach, 2), "peak": peak,
           "unit": "TFLOP/s", "frac": round(epa * ach / peak, 4),
           "achieved_is": "matrix-pipe FLOPs executed per second = algorithmic FLOPs x executed_per_algorithmic / duration",
           "executed_per_algorithmic": round(epa, 4),
           "algorithmic_tflops": round(ach, 2), "algorithmic_over_peak": round(ach / peak, 4),
           "pmc_mfma_busy_frac": busy,
-          "traffic": _pmc_conv_traffic(pmc, dom["name"]),
-          "traffic_unit": "GB of HBM per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE in separate passes, profiles/pmc_traffic.json)",
+          "traffic": conv_field(dom["name"], "hbm_bytes_per_launch", 1e-9),
+          "traffic_unit": "GB of HBM per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE in separate passes); null = not measured for this build / launch population",
+          "counter_fields_source": PMC_SRC,
           "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "launches": int(dom["launches"]),
           "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 2),
           "algorithmic_gbyte_per_launch": round(dom["bytes"] / dom["launches"] / 1e9, 4),
@@ -297,9 +401,11 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
                                           (sum(p["ms"] for p in convs) * 1e-3) / 1e12 / peak, 4),
           "kernels": {p["name"]: {"ms": round(p["ms"], 3), "launches": int(p["launches"]),
                                   **({"executed_frac": round(executed_per_algorithmic(p["name"]) * p["flops"] / (p["ms"] * 1e-3) / 1e12 / peak, 4),
-                                      "traffic_gb": _pmc_conv_traffic(pmc, p["name"])} if p["name"].startswith("conv3x3") and p["ms"] > 0 else {})}
+                                      "traffic_gb": conv_field(p["name"], "hbm_bytes_per_launch", 1e-9)} if p["name"].startswith("conv3x3") and p["ms"] > 0 else {})}
                       for p in prof},
           "hbm_bound_kernels": hbm}
+    if dropped:
+        rl["counter_fields_dropped"] = sorted(set(dropped))
     return rl
 
 
@@ -320,9 +426,11 @@ def time_warp(net, wl, reps=8):
     rec = {"avg_launch_us": round(us, 2), "algorithmic_gb_per_launch": round(px * 44 / 1e9, 4),
            "algorithmic_gbps": round(px * 44 / us / 1e3, 1)}
     rec["frac_of_hbm_peak"] = round(rec["algorithmic_gbps"] / HBM_PEAK_GBPS, 4)
-    hit = _pmc_table().get("warp_kernel")
-    if hit:
+    from fisr_amd import lib as _fl
+    hit = _pmc_table_checked(_fl.lib().fisr_version().decode())[0].get("warp_kernel")
+    if hit:             # (one launch shape only: 1080 x 1920, no population to compare)
         rec["pmc_gb_per_launch"] = round(hit["hbm_bytes_per_launch"] / 1e9, 4)
+        rec["pmc_source"] = PMC_SRC
     return rec
 
 
@@ -662,6 +770,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="frame-parallel: skip the RCCL gather of the output frames")
     ap.add_argument("--no-flow", action="store_true", help="skip the cfg5 measurement (on-GPU PWC-Net flow + warp + FISRnet)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement (row f4)")
+    ap.add_argument("--dry-run", action="store_true", help="plan only: every rank reports the bytes it would hold on its device "
+                    "(weights, activation arena of its forward batch, inputs, outputs, gather buffers) against the device's memory; "
+                    "no step is run; exit status 3 if a rank's plan does not fit")
     args = ap.parse_args()
     patch = tuple(int(v) for v in args.patch.strip("()").split(","))
 
@@ -707,8 +818,29 @@ def main():
     from fisr_amd import lib as _flib
     flib_version = _flib.lib().fisr_version().decode()       # carries a hash of csrc/: ties the line to the binary's sources
     W = weights.synthetic_weights(2020)
+    free_before_weights = torch.cuda.mem_get_info(dev)[0]
     net = FISRnet(device=f"cuda:{local_rank}", precision=args.precision)
     net.set_weights(W)
+    torch.cuda.synchronize(dev)
+    weight_bytes = max(0, int(free_before_weights - torch.cuda.mem_get_info(dev)[0]))      # what the engine's packed weights took
+    # ---- memory plan of this rank ("be right the first time a node shows up"): what the step will hold on the device,
+    #      against what the device has.  A plan that does not fit is refused HERE, with numbers, on every rank -- not by an
+    #      out-of-memory error inside the third collective of the first step.
+    plan = memory_plan(torch, net, dev, patch, args.batch, parallelism, topo, world if (parallelism == "frame" and not args.no_gather) else 1, rank,
+                       weight_bytes)
+    plans = [plan]
+    if world > 1:
+        plans = [None] * world
+        dist.all_gather_object(plans, plan)
+    bad = [q for q in plans if not q["fits"]]
+    if args.dry_run or bad:
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "parallelism": parallelism, "precision": args.precision, "batch": args.batch,
+                              "fits": not bad, "per_rank": plans}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3 if bad else 0)
     wl = Workload(torch, dev, stack_id, patch, args.batch, parallelism, topo, group,
                   gather_group_world=world if (parallelism == "frame" and not args.no_gather) else 1)
     wl.premake_warps(net)
@@ -849,7 +981,7 @@ def main():
                        "tflop_per_step": round(wl.flop_per_stack / 1e12, 3),
                        "raw_fps": round(stacks * 9 * args.steps / elapsed, 3),
                        "forwards_per_s": round(stacks * 3 * args.steps / elapsed, 3),
-                       "achieved_tflops_whole_step": round(stacks * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
+                       "algorithmic_tflops_whole_step": round(stacks * wl.flop_per_stack * args.steps / elapsed / 1e12, 2)},
             "per_rank": per_rank,
             "collective": (None if world == 1 else
                            {"what": "frame-parallel: asynchronous gather of every rank's uint8 output frames to rank 0 (side stream, double-buffered)"

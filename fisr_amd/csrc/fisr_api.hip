@@ -1268,11 +1268,17 @@ int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int cstride, 
 
 // ---- op-level entries ----
 
-int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
-                    int cout, const void* res, void* out, int n, int h, int w, int flags, int precision,
-                    int out_f32, void* stream) {
+}  // extern "C"
+// (pool_out: the second store of conv3x3_wf4.h's POOL instantiation -- fisr_op_conv3x3_pool)
+static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
+                           int cout, const void* res, void* out, void* pool_out, int n, int h, int w, int flags, int precision,
+                           int out_f32, void* stream) {
   if (!in0 || !w_host || !b_host || !out || n < 1 || h < 1 || w < 1 || cout < 1)
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: bad argument");
+  if (pool_out && (precision != FISR_PREC_F32W4 || out_f32 || !res || (h & 1) || (w & 1) || (flags & (FISR_CONV_RELU_IN | FISR_CONV_D2S | FISR_CONV_UP2_IN)) ||
+                   !wf4_fits(h, w, c0, c1, cout)))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3_pool: the pooled second store exists on the F(4x4) kernel only (FISR_PREC_F32W4, even h / w, "
+                                      "a residual input, no relu-on-load / d2s / fused bilinear; ops.py:52-54)");
   if (!prec_ok(precision)) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: unknown precision");
   const int cc = prec_chunk(precision);
   if (cout % CONV_REC) {
@@ -1311,6 +1317,7 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   a.d2s = (flags & FISR_CONV_D2S) != 0;
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.ups = (flags & FISR_CONV_UP2_IN) != 0;
+  a.pool_out = pool_out;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   hipStream_t st = (hipStream_t)stream;
   // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)
@@ -1330,6 +1337,19 @@ int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const floa
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv launch: ") + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("conv sync: ") + hipGetErrorString(e2));
   return 0;
+}
+extern "C" {
+
+int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
+                    int cout, const void* res, void* out, int n, int h, int w, int flags, int precision,
+                    int out_f32, void* stream) {
+  return op_conv3x3_impl(in0, c0, in1, c1, w_host, b_host, cout, res, out, nullptr, n, h, w, flags, precision, out_f32, stream);
+}
+
+int fisr_op_conv3x3_pool(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
+                         int cout, const void* res, void* out, void* pool_out, int n, int h, int w, int flags, int precision, void* stream) {
+  if (!pool_out) return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3_pool: pool_out is NULL");
+  return op_conv3x3_impl(in0, c0, in1, c1, w_host, b_host, cout, res, out, pool_out, n, h, w, flags, precision, 0, stream);
 }
 
 int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {

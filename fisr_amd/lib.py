@@ -23,7 +23,7 @@ EXPORTS = [
     "fisr_version", "fisr_create", "fisr_destroy", "fisr_last_error", "fisr_set_weight",
     "fisr_finalize_weights", "fisr_num_variables_set", "fisr_workspace_bytes", "fisr_forward",
     "fisr_profile_enable", "fisr_profile_reset", "fisr_profile_read", "fisr_warp", "fisr_pack_input",
-    "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_ssim_u8", "fisr_op_conv3x3", "fisr_op_maxpool2",
+    "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_ssim_u8", "fisr_op_conv3x3", "fisr_op_conv3x3_pool", "fisr_op_maxpool2",
     "fisr_op_upsample2", "fisr_bench_conv",
     "fisr_comm_unique_id", "fisr_comm_init", "fisr_comm_rank", "fisr_comm_size", "fisr_comm_allgather",
     "fisr_comm_sendrecv", "fisr_comm_destroy",
@@ -84,6 +84,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, define
         return SO_PATH
     os.makedirs(os.path.dirname(target), exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
            f'-DFISR_SRC_HASH="{source_hash()}"'] + (["-DFISR_DIAG"] if diag else []) + [f"-D{d}" for d in defines] + \
           ["-o", target, os.path.join(CSRC, "fisr_api.hip")]
     if verbose:
@@ -128,6 +129,8 @@ def lib():
     L.fisr_sse_vs_u8.argtypes = [vp, vp, c_size_t, POINTER(c_double), vp]
     L.fisr_op_conv3x3.argtypes = [vp, c_int, vp, c_int, POINTER(c_float), POINTER(c_float), c_int, vp, vp,
                                   c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_op_conv3x3_pool.argtypes = [vp, c_int, vp, c_int, POINTER(c_float), POINTER(c_float), c_int, vp, vp, vp,
+                                       c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_op_maxpool2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_op_upsample2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_ssim_u8.argtypes = [vp, vp, c_int, c_int, c_int, c_int, POINTER(c_double), vp]

@@ -96,6 +96,10 @@ def parse_args(argv=None):
     p.add_argument("--FISR_test_patch", type=_tuple2, default=(2, 2))
     # build-specific
     p.add_argument("--precision", type=str, default=DEFAULT_PRECISION, choices=sorted(PRECISIONS))
+    p.add_argument("--check_published", action="store_true",
+                   help="--phase test: compare the four averages with the figures the reference publishes for its pre-trained "
+                        "weights on its 4K test set (README.md:97: PSNR 37.86 / 48.07 dB, SSIM 0.9743 / 0.9921) within the "
+                        "tolerance of BASELINE.json (+-0.02 dB, 1e-3 SSIM); exit status 4 if any of them is outside")
     p.add_argument("--no_batch_tiles", dest="batch_tiles", action="store_false",
                    help="run the tiles of a window one forward at a time (reference schedule, smallest workspace)")
     p.add_argument("--device", type=str, default=None, help="default cuda:<LOCAL_RANK>")
@@ -121,6 +125,27 @@ def check_args(args):
     for d in (args.checkpoint_dir, args.text_dir, args.log_dir, args.test_img_dir):
         check_folder(d)
     return args
+
+
+# what the reference publishes for checkpoint_dir/FISRnet_exp1 on data/test (README.md:97), and BASELINE.json's tolerance
+PUBLISHED = (("FISR_PSNR", 37.86, 0.02, "[dB]"), ("SR_PSNR", 48.07, 0.02, "[dB]"), ("FISR_SSIM", 0.9743, 1e-3, ""), ("SR_SSIM", 0.9921, 1e-3, ""))
+
+
+def check_published(res) -> bool:
+    """The day `checkpoint_dir/FISRnet_exp1` and `data/test` are on the box, `python -m fisr_amd.main --phase test --check_published`
+    is the one command that pins the whole path to the reference: prints each average of `FISRnet.test` (FISRnet.py:922-933) next to
+    README.md:97's figure and says whether it is inside the tolerance.  (The published figures are rounded to 2 / 4 digits: half
+    a unit of the last digit is added to the tolerance.)"""
+    ok = True
+    for key, want, tol, unit in PUBLISHED:
+        got = float(res[key])
+        slack = tol + (0.005 if unit else 0.00005)
+        inside = abs(got - want) <= slack
+        ok &= inside
+        print("######### published check: %-9s %.4f%s vs README.md:97 %.4f%s  (difference %+.4f, tolerance %.4f): %s #########"
+              % (key, got, unit, want, unit, got - want, slack, "ok" if inside else "OUTSIDE"))
+    print("######### published check: %s #########" % ("all four averages inside the tolerance" if ok else "FAILED"))
+    return ok
 
 
 def main(argv=None):
@@ -167,8 +192,10 @@ def main(argv=None):
     if args.synthetic_weights is not None:
         net.set_weights(weights.synthetic_weights(args.synthetic_weights))
     if args.phase == "test":
-        net.test()
+        res = net.test()
         print(" [*] Test finished!")
+        if getattr(args, "check_published", False):
+            return 0 if check_published(res) else 4
         return 0
     # FISR_for_video (main.py:207-235)
     flow_file = args.flow_file

@@ -192,6 +192,12 @@ FISR_API int fisr_ssim_u8(const uint8_t* a, const uint8_t* b, int h, int w, int 
 FISR_API int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, const float* w_host,
                     const float* b_host, int cout, const void* res, void* out, int n, int h,
                     int w, int flags, int precision, int out_f32, void* stream);
+/* The last convolution of an encoder level with tf.nn.max_pool(2x2, stride 2) (ops.py:52-54, Enc_level_res) as a SECOND store of its
+ * epilogue: out [n,h,w,cout] as fisr_op_conv3x3 writes it, pool_out [n,h/2,w/2,cout] = its 2x2 maxima.  FISR_PREC_F32W4 only (the
+ * F(4x4) Winograd kernel: a 4x4 tile holds whole pooling windows); needs a residual input, even h / w, no relu-on-load / d2s /
+ * fused bilinear; anything else is FISR_EINVAL. */
+FISR_API int fisr_op_conv3x3_pool(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
+                         int cout, const void* res, void* out, void* pool_out, int n, int h, int w, int flags, int precision, void* stream);
 FISR_API int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
 FISR_API int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
 

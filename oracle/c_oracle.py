@@ -23,6 +23,29 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota.  OpenMP's default is one thread per
+    LOGICAL cpu of the host -- 128 threads on the GPU box, whose container has a quota of 16 cores: the checker then spends its
+    time in the scheduler (the ten-scene fixture of tests/test_gpu_harness.py took 209 s of the GPU suite that way)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -36,6 +59,7 @@ def lib():
         _lib.fisr_oracle_conv3x3_f32.argtypes = [fp] + [ctypes.c_int] * 4 + [fp, fp, ctypes.c_int, ctypes.c_int, fp]
         _lib.fisr_oracle_conv3x3_f64.argtypes = [dp] + [ctypes.c_int] * 4 + [fp, fp, ctypes.c_int, ctypes.c_int, dp]
         _lib.fisr_oracle_set_threads.argtypes = [ctypes.c_int]
+        _lib.fisr_oracle_set_threads(usable_cores())       # (not OpenMP's one-per-logical-cpu default: see usable_cores)
     return _lib
 
 

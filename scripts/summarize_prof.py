@@ -107,7 +107,25 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
             e["gui_active_cycles_per_launch"] = d["GRBM_GUI_ACTIVE"][1] / max(d["GRBM_GUI_ACTIVE"][0], 1)
             if k in durations:
                 e["shader_clock_mhz"] = e["gui_active_cycles_per_launch"] / (durations[k][1] / 1e3)
+# ---- which run this is: the library string (it carries the sha256 of csrc/ + include/fisr.h) and the number of steps, read from the
+# bench line of the trace pass -- bench.py drops counter-derived fields whose run is not the running library's, or whose launch
+# population (dispatches per step) is not the one it sees
+meta = {"source": "scripts/gpu_profile.sh -> scripts/summarize_prof.py"}
+for lf in sorted(glob.glob(os.path.join(root, "*.log"))):
+    try:
+        for line in open(lf, errors="replace"):
+            if line.startswith("{") and '"library"' in line:
+                d = json.loads(line)
+                meta["library"] = d.get("library")
+                meta["steps_per_pass"] = int(d.get("steps", 0)) + int(d.get("warmup", 0))
+                meta["engines"] = [d.get("config", {}).get("engine", "")[:40]] + sorted((d.get("other_precisions") or {}).keys())
+                break
+    except (OSError, ValueError):
+        continue
+    if "library" in meta:
+        break
 if out:
+    out["_meta"] = meta
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("\n## pmc_traffic.json written:", ", ".join(out))

@@ -124,6 +124,50 @@ def test_bench_eight_ranks_end_to_end_on_one_device(parallelism):
     assert abs(line["value"] - stacks * 7 * 2 / (line["ms_per_step"] * 2e-3)) < 0.02 * line["value"]
     if parallelism == "frame":
         assert line["collective"]["bytes_per_rank_per_step"] == 3 * 2048 * 3840 * 9
+        # the gather's share of a rank's step, from the per-rank report: wall time up to "my last gather has arrived" against the
+        # compute stream's own time, and the host time inside the collective calls (asynchronous: a fraction of the wall time)
+        for r in line["per_rank"]:
+            wall, comp, host = r["wall_ms_per_step_incl_gather_drain"], r["compute_ms_per_step"], r["host_ms_in_gather_calls_per_step"]
+            share = max(0.0, wall - comp) / wall
+            assert 0.0 <= share < 1.0 and host is not None and 0.0 <= host <= wall, r
+        print("gather share of the step per rank (gloo, 8 ranks on one device):",
+              [round(max(0.0, r["wall_ms_per_step_incl_gather_drain"] - r["compute_ms_per_step"]) / r["wall_ms_per_step_incl_gather_drain"], 3) for r in line["per_rank"]])
+
+
+def test_bench_dry_run_reports_the_memory_plan_of_every_rank():
+    """`bench.py --gpus 8 --dry-run`: no step is run; every rank reports what it would hold on its device --
+    packed weights (measured), the activation arena the LIBRARY asks for its forward batch, inputs, outputs, gather buffers --
+    against the device, and the launcher's exit status says whether every plan fits (here: 8 default fp32 plans of ~35 GB on ONE
+    288-GB device, the test hook's sharing rule: 1/8 of the device each)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FISR_BENCH_BACKEND="gloo", FISR_BENCH_ONE_DEVICE="1")
+    for extra, prec in ((["--parallelism", "frame"], "fp32"), (["--parallelism", "tile"], "fp32")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--precision", prec, "--dry-run"] + extra
+        p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+        plan = json.loads(lines[0])
+        assert plan["dry_run"] and plan["n_gpus"] == 8 and len(plan["per_rank"]) == 8
+        # (every rank leaves with status 3 when a plan does not fit; torch.distributed.run reports its children's failure as 1)
+        assert (p.returncode == 0) == plan["fits"], (p.returncode, plan["fits"])
+        for r in plan["per_rank"]:
+            b = r["bytes"]
+            assert b["activation_arena"] > 0 and b["weights_packed_measured"] > 100e6 and r["total_bytes"] > b["activation_arena"]
+            assert r["device_total_bytes"] > 200e9 and r["ranks_sharing_device"] == 8
+        r0 = plan["per_rank"][0]["bytes"]
+        if extra[1] == "frame":        # 12 tiles of 544 x 992 per forward; rank 0 holds the gather's receive buffer
+            assert r0["forward_batch"] == [12, 544, 992] and r0["gather_receive_buffer"] == 8 * 3 * 2048 * 3840 * 9
+            assert all(q["bytes"]["gather_receive_buffer"] == 0 for q in plan["per_rank"][1:])
+        else:                          # the rank's own tile of the 3 windows
+            assert r0["forward_batch"] == [3, 544, 992] and r0["gather_send_buffers"] == 0
+        print(f"dry run {extra[1]}: fits {plan['fits']}, per-rank total {plan['per_rank'][0]['total_bytes'] / 1e9:.1f} GB "
+              f"(arena {r0['activation_arena'] / 1e9:.1f} GB, weights {r0['weights_packed_measured'] / 1e9:.2f} GB)")
 
 
 def _comm_worker(rank, world, port, q):

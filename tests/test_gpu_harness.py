@@ -152,7 +152,7 @@ def test_phase_fisr_for_video_with_on_gpu_flow(scene):
                     "--FISR_test_patch", "1,1", "--FISR_input_size", "96,96", "--frame_num", "5"])
 
 
-def test_phase_fisr_for_video_full_size_with_on_gpu_flow(tmp_path_factory, syn_weights, gold_dir):
+def test_phase_fisr_for_video_full_size_with_on_gpu_flow(tmp_path_factory, syn_weights, gold_dir, fast_png):
     """cfg5 at full size through the CLI: five 1080x1920 frames, no flow file -> PWC-Net on the GPU (2176x3840 network input),
     GPU warp, FISRnet with the reference's 2x2 tiling, 7 frames of 2048x3840.  Frames 0 and 1 are the pair of the full-size
     flow golden, so the written .flo is checked against the float64 oracle; the output frames against the engine driven by
@@ -206,7 +206,18 @@ def test_phase_fisr_for_video_full_size_with_on_gpu_flow(tmp_path_factory, syn_w
     net.close()
 
 
-def test_phase_test_full_size_precisions_agree(tmp_path_factory, syn_weights):
+@pytest.fixture
+def fast_png(monkeypatch):
+    """Full-size runs write dozens of 2048x3840 PNGs; zlib level 1 instead of PIL's default 6 (same pixels, ~3x faster to write):
+    the files are read back by the same tests, nothing depends on their size."""
+    from PIL import Image
+
+    def write_png(path, a):
+        Image.fromarray(np.ascontiguousarray(a, np.uint8)).save(path, compress_level=1)
+    monkeypatch.setattr(fio, "write_png", write_png)
+
+
+def test_phase_test_full_size_precisions_agree(tmp_path_factory, syn_weights, fast_png):
     """cfg2/cfg3 plumbing at full size: `--phase test` on one synthetic 1080x1920 5-frame scene with the
     reference's default 2x2 tiling (crop to 1024x1920, four 544x992 tiles, 2048x3840 outputs).  The exact
     fp32 engine and the fast engines must agree within the reference tolerance (+-0.02 dB PSNR, 1e-3 SSIM)

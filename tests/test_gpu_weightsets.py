@@ -174,3 +174,66 @@ def test_full_size_ten_scenes_fast_engines_vs_fp32(syn_weights):
     ref.close()
     for e in engines.values():
         e.close()
+
+
+def test_two_by_four_tile_plan_vs_the_reference_two_by_two_seams(syn_weights):
+    """the 8-GPU tile plan 1 window x 2 x 4 tiles moves the seams away from where the reference's 2 x 2 plan
+    (FISRnet.py:847-880, utils.py:118-159) has them, "so parity (+-0.02 dB) must be re-verified".  Measured here, on one full-size
+    window (1024 x 1920 -> 2048 x 3840 x 9, shipped fp32 engine, all plans in one process, pseudo ground truth = a plan's own
+    prediction + Gaussian noise at the published operating point, README.md:97):
+
+      * what the reference's OWN seams cost on these weights: 2 x 2 plan against the untiled forward (--test_patch 1,1);
+      * what the 2 x 4 plan costs against the 2 x 2 plan.
+
+    With the synthetic (untrained) weights the network's coarse levels carry every tile's content to every pixel (all 3840
+    columns of the two plans differ), so NEITHER comparison is inside 0.02 dB on the 48-dB SR frame: r04 measured 0.32 dB for
+    2 x 4 vs 2 x 2.  That is a property of tiling with weights that were never trained to be local, not of the plan -- which is
+    why the default 8-GPU topology is 2 windows x the reference's 2 x 2 seams (dist.TileTopology), bit-identical to the
+    single-GPU result, and the 2 x 4 plan is opt-in.  What the test pins: the 2 x 4 plan's seams cost no more than twice what the
+    reference's own seams cost on the same weights (+ the 0.02 dB of the tolerance), and the FI-SR frames (38-dB operating
+    point) stay inside 0.05 dB.  With `checkpoint_dir/FISRnet_exp1` the +-0.02 dB question is one `--phase test
+    --test_patch 2,4 --check_published` run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import math
+    dev = torch.device("cuda:0")
+    net = FISRnet(device="cuda:0", precision="fp32")
+    net.set_weights(syn_weights)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    coarse = torch.rand((1, 3, 1080 // 8 + 8, 1920 // 8 + 8), generator=gen, device=dev)
+    big = torch.nn.functional.interpolate(coarse, scale_factor=8, mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    frames = []
+    for k in range(3):
+        f = big[8 + 3 * k:8 + 3 * k + 1080, 16 + 5 * k:16 + 5 * k + 1920] + 0.02 * torch.randn((1080, 1920, 3), generator=gen, device=dev)
+        frames.append((f.clamp(0, 1) * 255).to(torch.uint8).contiguous())
+    fc = torch.randn((4, 2, 1080 // 32 + 2, 1920 // 32 + 2), generator=gen, device=dev) * 4
+    flows = torch.nn.functional.interpolate(fc, scale_factor=32, mode="bilinear", align_corners=False)[:, :, :1080, :1920].permute(0, 2, 3, 1).contiguous()
+    warps = [net.warp(frames[1], flows[0]), net.warp(frames[0], flows[1]), net.warp(frames[2], flows[2]), net.warp(frames[1], flows[3])]
+    inp = net.pack_input(frames, list(flows), warps, 1024, 1920)
+    try:
+        p11 = net.forward_tiled(inp, (1, 1)).clamp(0, 1)
+        p22 = net.forward_tiled(inp, (2, 2)).clamp(0, 1)
+        p24 = net.forward_tiled(inp, (2, 4)).clamp(0, 1)
+        torch.cuda.synchronize()
+        assert p11.shape == p22.shape == p24.shape == (2048, 3840, 9)
+        sig = (10 ** (-37.86 / 20), 10 ** (-48.07 / 20), 10 ** (-37.86 / 20))
+        noise = torch.randn(p22.shape, generator=gen, device=dev)
+
+        def shifts(ref, other):
+            out = []
+            for f in range(3):
+                sl = slice(3 * f, 3 * f + 3)
+                gt = ref[..., sl] + sig[f] * noise[..., sl]
+                ps = [10 * math.log10(1.0 / float(((p[..., sl] - gt).double() ** 2).mean())) for p in (ref, other)]
+                out.append(abs(ps[0] - ps[1]))
+            return out
+        own = shifts(p11, p22)            # the reference's seams vs no seams
+        new = shifts(p22, p24)            # the 8-GPU plan's seams vs the reference's
+        d = (p22 - p24).abs().amax(dim=2)
+        print(f"dPSNR per frame (FI-SR, SR, FI-SR): 2x2 plan vs untiled {[round(v, 4) for v in own]} dB; 2x4 plan vs 2x2 plan {[round(v, 4) for v in new]} dB; "
+              f"max |2x4 - 2x2| {float(d.max()):.3e}, columns that differ {int((d.amax(dim=0) > 0).sum())} of 3840")
+        for f in range(3):
+            assert new[f] <= 2.0 * own[f] + 0.02, (f, new, own)
+        assert max(new[0], new[2]) <= 0.05 and float(d.max()) < 0.1
+    finally:
+        net.close()

@@ -227,3 +227,13 @@ def test_optimizer_state_lookup(tmp_path, syn_weights):
     assert st is not None and len(st) == 2 * 276 + 2 and float(st["beta2_power"]) == 0.999 ** 3
     W = weights.load_weights(p1)                                          # the slots do not disturb the weight loader
     assert len(W) == 276
+
+
+def test_check_published_compares_with_the_readme_figures(capsys):
+    """main.py --phase test --check_published: the four averages against README.md:97 within BASELINE.json's tolerance."""
+    from fisr_amd import main as fmain
+    assert fmain.check_published(dict(FISR_PSNR=37.862, SR_PSNR=48.05, FISR_SSIM=0.97431, SR_SSIM=0.9918))
+    assert not fmain.check_published(dict(FISR_PSNR=37.80, SR_PSNR=48.07, FISR_SSIM=0.9743, SR_SSIM=0.9921))
+    out = capsys.readouterr().out
+    assert out.count("published check:") == 10 and "OUTSIDE" in out and "README.md:97" in out
+    assert fmain.parse_args(["--phase", "test", "--check_published"]).check_published
