@@ -93,6 +93,9 @@ constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; 
 #define FISR_F4_UQ 0
 #endif
 // the plain residual instantiation issues ALL 36 weight copies of a chunk from the copy waves (A/B hook: 0 = the 4 + 5 split of the others)
+#ifndef FISR_F4_SOFF_RUN
+#define FISR_F4_SOFF_RUN 1       // the stores' uniform offsets as running scalar sums (A/B hook: 0 = sixteen hoisted products)
+#endif
 #ifndef FISR_F4_UALL
 #define FISR_F4_UALL 1
 #endif
@@ -120,6 +123,18 @@ __device__ __forceinline__ void wf4_at(float m0, float m1, float m2, float m3, f
   y3 = fmaf(8.f, d2, d1) + m5;
 }
 
+// 16-byte buffer store (lane offset + uniform offset in the soffset field) with one wait state pinned behind it: see the epilogue.
+// (The store stays the compiler's builtin: the soffset registers are SGPR spills reloaded by v_readlane, and "VALU writes SGPR ->
+// VMEM reads it" wants 5 wait states that only the hazard recogniser inserts -- as inline asm the store went out one slot behind
+// its v_readlane and landed anywhere.  The two scheduling barriers keep everything else out from between store and s_nop.)
+typedef unsigned int wf4_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wf4_store16(wf4_u32x4 data, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(data, rs, voff, soff, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 0" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // POOL: p.pool_out gets the 2x2 max pooling of the output as a second store of the epilogue (its own instantiation: the sixteen
 // registers of the pooled pixels cost the other layers 1.5-3 % in spills around the output stage).
 // UPS: p.in0 is the HALF-resolution map [N, H/2, W/2, C0] and the convolution runs on its x2 bilinear enlargement (ops.py:69,
@@ -128,8 +143,16 @@ __device__ __forceinline__ void wf4_at(float m0, float m1, float m2, float m3, f
 // full-resolution halo) into a staging buffer and blend them into the raw pair buffer where the relu-on-load pass of the other
 // instantiations sits -- one 2 x 2 output quad per lane, out[2i+1] = x[i] + (x[i+1] - x[i]) / 2, out[2i+2] = x[i+1], the same
 // operations in the same order as the stand-alone kernel (fma(d, 0.5, a) rounds like a + d * 0.5: the product is exact).
-template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false>
+// GENERAL (r04; PWC-Net's dense and context layers, as conv3x3_wino8p.h's flag of the same name): input and output are channel
+// RANGES of wider buffers (pixel strides p.in0_cs / p.rec_cs, first output channel p.rec_co; the pointers carry the input
+// offset), Cout is padded to the 64-channel block (channels >= Cout are computed from zero weights and not stored), relu is leaky
+// (max(v, slope v)), and the convolution may be DILATED: a dilated 3x3 convolution is an ordinary one inside each of the d x d
+// interleaved sub-images (pixel (y, x) belongs to sub-image (y % d, x % d)), zero padding included, so tiles and all tile
+// coordinates live in a sub-image and only the addresses are scaled back.  Its own instantiation: one source, no relu-on-load,
+// no residual, no pooled store, no fused bilinear, no depth_to_space.
+template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false, bool GENERAL = false>
 __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
+  static_assert(!GENERAL || (!RELU_IN && !HAS_RES && !POOL && !UPS), "GENERAL is the plain instantiation on channel ranges");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sU = smem;
   char* const sV = smem + 2 * F4_U_BYTES;
@@ -145,9 +168,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   //      the next one): only a workgroup's first item pays the prologue, and no item waits for a workgroup launch.
   //      Work item id -> (pixel tile, N block), XCD-aware as in conv3x3_wino8p.h: workgroup w runs on XCD w % 8, gridDim.x is a
   //      multiple of 8, each XCD walks a contiguous range of virtual ids in which the N blocks of one pixel tile are neighbours.
-  const int tiles_x = (p.W + F4_TW - 1) / F4_TW, tiles_y = (p.H + F4_TH - 1) / F4_TH;
+  const int dil = GENERAL ? p.dil : 1;                  // (a compile-time 1 for FISRnet: no index arithmetic is added)
+  const int in0_cs = GENERAL ? p.in0_cs : p.C0;
+  const int rec_cs = GENERAL ? p.rec_cs : p.Cout, rec_co = GENERAL ? p.rec_co : 0;
+  const int tiles_x = ((p.W + dil - 1) / dil + F4_TW - 1) / F4_TW, tiles_y = ((p.H + dil - 1) / dil + F4_TH - 1) / F4_TH;
   const int nblocks = p.CoutPad / F4_BN;
-  struct Item { int x0, y0, nb, nblk; };
+  struct Item { int x0, y0, nb, nblk, ry, rx; };        // (x0, y0): inside sub-image (ry, rx) of image nb
   auto item_of = [&](int b) __attribute__((always_inline)) {
     const int q = n_items >> 3, r = n_items & 7;
     const int xcd = b & 7, loc = b >> 3;
@@ -158,7 +184,14 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     const int tx = t % tiles_x; t /= tiles_x;
     it.x0 = tx * F4_TW;
     it.y0 = (t % tiles_y) * F4_TH;
-    it.nb = t / tiles_y;
+    t /= tiles_y;
+    it.ry = 0; it.rx = 0;
+    if (GENERAL) {
+      const int sub = t % (dil * dil);
+      t /= dil * dil;
+      it.ry = sub / dil; it.rx = sub - it.ry * dil;
+    }
+    it.nb = t;
     if (FISR_F4ABL & 4096) { it.x0 = (tx & 1) * F4_TW; it.y0 = 0; it.nb = 0; }      // (ablation 4096: every item works on two tiles of image 0 -- no DRAM traffic)
     return it;
   };
@@ -211,12 +244,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       const int s = 32 * (cw + 4 * q) + (l >> 1);
       const int py = s / F4_HW, r = s - py * F4_HW;
       const int px = r < 9 ? 4 * r : r < 18 ? 4 * (r - 9) + 1 : r < 26 ? 4 * (r - 18) + 2 : 4 * (r - 26) + 3;
-      const int gy = it.y0 - 1 + py, gx = it.x0 - 1 + px;
+      const int gy = (it.y0 - 1 + py) * dil + it.ry, gx = (it.x0 - 1 + px) * dil + it.rx;      // (a halo pixel left of / above sub-image row 0 is negative for every ry, rx < dil)
       const bool ok = s < F4_HALO && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       rpix[q] = ok ? gy * p.W + gx : -1;
       rsub |= (unsigned)((l & 1) ^ ((py >> 2) & 1)) << q;
     }
-    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.in0 + (size_t)it.nb * img_px * p.C0), 0, (unsigned)(img_px * p.C0 * 4), 0x00020000);
+    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.in0 + (size_t)it.nb * img_px * in0_cs), 0, (unsigned)(img_px * in0_cs * 4), 0x00020000);
     rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? (const float*)p.in1 + (size_t)it.nb * img_px * p.C1 : (const float*)p.in0), 0,
                                             (unsigned)(img_px * (p.in1 ? p.C1 : p.C0) * 4), 0x00020000);
   };
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   unsigned ro[5] = {OOB, OOB, OOB, OOB, OOB};
   bool ro_first = true;
   auto raw_offsets = [&](bool first) __attribute__((always_inline)) {
-    const unsigned csb = (unsigned)(first ? p.C0 : p.C1) * 4u;
+    const unsigned csb = (unsigned)(first ? in0_cs : p.C1) * 4u;
 #pragma unroll
     for (int j = 0; j < 5; ++j) ro[j] = rpix[j] < 0 ? OOB : (unsigned)rpix[j] * csb + ((rsub >> j) & 1u) * 16u;
     ro_first = first;
@@ -712,33 +745,34 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       const bool c_ok = c0 < p.Cout;
       const int cq_shift = p.d2s_shift;
       const unsigned sub = (unsigned)c0 >> cq_shift;
-      const unsigned sA = p.d2s ? (unsigned)(4 * p.W) << cq_shift : (unsigned)p.W * (unsigned)p.Cout;
-      const unsigned sB = p.d2s ? 2u << cq_shift : (unsigned)p.Cout;
+      const unsigned sA = p.d2s ? (unsigned)(4 * p.W) << cq_shift : (unsigned)p.W * (unsigned)rec_cs;
+      const unsigned sB = p.d2s ? 2u << cq_shift : (unsigned)rec_cs;
       const unsigned vC = p.d2s ? ((((sub >> 1) * 2u * (unsigned)p.W + (sub & 1u)) << cq_shift) + ((unsigned)c0 & ((1u << cq_shift) - 1u))) : (unsigned)c0;
-      const unsigned out_bytes = p.d2s ? ((unsigned)(4 * p.H * p.W) << cq_shift) * 4u : (unsigned)(p.H * p.W) * (unsigned)p.Cout * 4u;
+      const unsigned out_bytes = p.d2s ? ((unsigned)(4 * p.H * p.W) << cq_shift) * 4u : (unsigned)(p.H * p.W) * (unsigned)rec_cs * 4u - (unsigned)rec_co * 4u;
       const __amdgpu_buffer_rsrc_t os = __builtin_amdgcn_make_buffer_rsrc(
-          (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4 : (size_t)cur.nb * img_px * p.Cout * 4), 0, out_bytes, 0x00020000);
+          (char*)p.out + (p.d2s ? ((size_t)cur.nb * 2 * p.H * 2 * p.W << cq_shift) * 4 : ((size_t)cur.nb * img_px * rec_cs + rec_co) * 4), 0, out_bytes, 0x00020000);
       typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
       // Record (i, j) of the lane's 4 x 4 pixels sits at byte  vbase + 4 (i sA + j sB):  one lane offset + a UNIFORM offset that rides
       // in the scalar-offset operand of the buffer instruction -- no vector instruction per record (they are paid in full beside the
       // MFMAs' pipe: the epilogue is bound by its vector instruction count).  Lanes outside the image get an offset behind the
       // buffer's end (loads return zeros, stores are dropped); only a tile on the image's right / bottom edge needs that per record.
-      const int oy0 = cur.y0 + 4 * e_ty, ox0 = cur.x0 + 4 * e_tx;
-      const unsigned vbase = c_ok ? ((unsigned)oy0 * sA + (unsigned)ox0 * sB + vC) * 4u : OOB;
-      const bool interior = cur.y0 + F4_TH <= p.H && cur.x0 + F4_TW <= p.W;      // (uniform)
+      const int oy0 = cur.y0 + 4 * e_ty, ox0 = cur.x0 + 4 * e_tx;         // (in the item's sub-image)
+      const int hs = GENERAL ? (p.H - cur.ry + dil - 1) / dil : p.H, ws = GENERAL ? (p.W - cur.rx + dil - 1) / dil : p.W;     // the sub-image's size
+      const unsigned vbase = c_ok ? ((unsigned)(oy0 * dil + cur.ry) * sA + (unsigned)(ox0 * dil + cur.rx) * sB + vC) * 4u : OOB;
+      const bool interior = cur.y0 + F4_TH <= hs && cur.x0 + F4_TW <= ws;      // (uniform)
       unsigned off[4][4];
       if (!interior) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) off[i][j] = ((oy0 + i < p.H) & (ox0 + j < p.W)) ? vbase : OOB;
+          for (int j = 0; j < 4; ++j) off[i][j] = ((oy0 + i < hs) & (ox0 + j < ws)) ? vbase : OOB;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) off[i][j] = vbase;
       }
-      const unsigned sA4 = sA * 4u, sB4 = sB * 4u;
+      const unsigned sA4 = sA * 4u * (unsigned)dil, sB4 = sB * 4u * (unsigned)dil;      // (neighbouring pixels of a sub-image are dil apart)
 #define FISR_F4_SOFF(I, J) ((unsigned)(I) * sA4 + (unsigned)(J) * sB4)
       // output transform, packed on the channel pairs (r0, r1), (r2, r3) of every accumulator: rows first (W = M A, 6 x 4 per pair),
       // then columns (Y = A^T W).  The residual records are requested after the first half of the row pass -- from there on the
@@ -778,10 +812,22 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       half(std::integral_constant<int, 0>{});
       half(std::integral_constant<int, 1>{});
       f32x4 pm[2][2];                              // 2x2 max pooling of the lane's 4 x 4 pixels (p.pool_out)
+      // The stores' uniform offsets i sA4 + j sB4 are RUNNING scalar sums made opaque to the compiler: as sixteen loop-invariant
+      // values it kept them in SGPRs across the K loops, spilled them into VGPR lanes and brought each back with a v_readlane
+      // + the 4 wait states "VALU writes SGPR -> VMEM reads it" needs -- a vector instruction and 16 idle cycles per store in the
+      // stage of the kernel that is bound by exactly that (r04).  A scalar add in front of the store has no such hazard.
+      unsigned so_row = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        unsigned so_ij = so_row;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#if FISR_F4_SOFF_RUN
+          asm volatile("" : "+s"(so_ij));
+#define FISR_F4_SOFF_ST(I, J) so_ij
+#else
+#define FISR_F4_SOFF_ST(I, J) FISR_F4_SOFF(I, J)
+#endif
           const float y0 = yp[i][j][0][0], y1 = yp[i][j][0][1], y2 = yp[i][j][1][0], y3 = yp[i][j][1][1];
           f32x4 o;
           o[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y0)));
@@ -789,12 +835,30 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           o[2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y2)));
           o[3] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_addr, __builtin_bit_cast(int, y3)));
           if constexpr (HAS_RES) o += res[i][j];
-          if (p.relu_out) {
+          if constexpr (GENERAL) {        // leaky relu: max(v, slope v), slope 1 when the layer has none
+            const float sl = p.relu_out ? p.slope : 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t_;
+              asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t_) : "s"(sl), "v"(o[e]));
+              asm volatile("v_max_f32 %0, %1, %0" : "+v"(o[e]) : "v"(t_));
+            }
+          } else if (p.relu_out) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) asm("v_max_f32 %0, 0, %0" : "+v"(o[e]));
           }
-          if (!(FISR_F4ABL & 512) || (i == 0 && j == 0))        // (ablation 512: one store per lane instead of 16)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF(i, j), FISR_F4_STORE_AUX);
+          // A 16-byte buffer store reads its data registers AFTER it has issued, and a vector instruction that overwrites one of
+          // them in the very next slot wins that race now and then -- measured on gfx950 WITH a register in the soffset field, the
+          // case the compiler's hazard recogniser exempts (createsVALUHazard): in the GENERAL instantiation the leaky relu's
+          // temporary was allocated to dword 2 of the previous record and scheduled right behind its store, and pixel j came out
+          // with channel 4g + 2 = pixel j + 1's channel 4g, in the younger waves of a SIMD only, in 0.02-0.15 % of the outputs,
+          // differently on every run (r04; scripts/isa_store_hazard.py finds such pairs in a listing, tests/test_host.py runs it on
+          // the built code object).  So every store has one wait state pinned behind it (wf4_store16).
+          if (!(FISR_F4ABL & 512) || (i == 0 && j == 0)) {      // (ablation 512: one store per lane instead of 16)
+            if (FISR_F4_STORE_AUX == 0) wf4_store16(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF_ST(i, j));
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), os, off[i][j], FISR_F4_SOFF_ST(i, j), FISR_F4_STORE_AUX);
+          }
+          so_ij += sB4;
           if constexpr (POOL) {
             if ((i & 1) == 0 && (j & 1) == 0) pm[i >> 1][j >> 1] = o;
             else {
@@ -803,6 +867,9 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
             }
           }
         }
+        so_row += sA4;
+      }
+#undef FISR_F4_SOFF_ST
       if constexpr (POOL) {       // ops.py:54 max_pool 2x2 / 2 of what was just stored: [N, H/2, W/2, Cout]
         const unsigned ph = (unsigned)p.H >> 1, pw = (unsigned)p.W >> 1;
         const unsigned pool_bytes = ph * pw * (unsigned)p.Cout * 4u;
@@ -813,8 +880,9 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
 #pragma unroll
           for (int bj = 0; bj < 2; ++bj) {
             const unsigned o_ = (interior || ((oy0 + 2 * bi < p.H) & (ox0 + 2 * bj < p.W))) ? pbase : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pm[bi][bj]), ps_, o_,
-                                                   ((unsigned)bi * pw + (unsigned)bj) * (unsigned)p.Cout * 4u, FISR_F4_STORE_AUX);
+            if (FISR_F4_STORE_AUX == 0) wf4_store16(__builtin_bit_cast(u32x4_t, pm[bi][bj]), ps_, o_, ((unsigned)bi * pw + (unsigned)bj) * (unsigned)p.Cout * 4u);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pm[bi][bj]), ps_, o_,
+                                                        ((unsigned)bi * pw + (unsigned)bj) * (unsigned)p.Cout * 4u, FISR_F4_STORE_AUX);
           }
       }
     }
@@ -882,6 +950,11 @@ inline void pack_weights_wf4(const float* w, int ci, int co, int cin_pad, std::v
 inline bool wf4_fits(int h, int w, int c0, int c1, int co) {
   return co % F4_BN == 0 && c0 > 0 && c0 % (2 * F4_CH) == 0 && c1 % (2 * F4_CH) == 0 && (c0 + c1) / F4_CH >= 4 && (double)h * w * std::max(std::max(c0, c1), co) * 4.0 < 2147483648.0;
 }
+// the GENERAL instantiation: one source of whole raw pairs out of a buffer with pixel stride in_cs, an output range of a buffer
+// with pixel stride out_cs (the 64-channel output blocks are padded: CoutPad), the same 31-bit byte offsets
+inline bool wf4_fits_general(int h, int w, int c0, int in_cs, int out_cs) {
+  return c0 > 0 && c0 % (2 * F4_CH) == 0 && c0 / F4_CH >= 4 && (double)h * w * std::max(in_cs, out_cs) * 4.0 < 2147483648.0;
+}
 // ... and where it is the faster of the two Winograd kernels (measured per map size and depth, scripts/conv_bench.py, 12 tiles:
 // 68 x 124 maps 1.2-1.35x at every channel count, 34 x 62 maps 0.72-0.77x with 64-256 channels -- its 16 x 32-pixel items waste
 // more of a small map than the 8 x 32 ones of conv3x3_wino8p.h -- but 1.04x / 1.4x on the 512-channel 34 x 62 / 17 x 31 maps,
@@ -912,8 +985,26 @@ inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
     n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     attr_done[dev] = true;
   }
-  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && a.dil == 1;
-  if (!plain || !wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s) || a.CoutPad != a.Cout) return hipErrorInvalidValue;
+  const bool plain = a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) && a.rec_cs == a.Cout && a.rec_co == 0 && a.slope == 0.f && a.dil == 1 &&
+                     a.CoutPad == a.Cout;
+  if (!plain) {
+    // GENERAL (PWC-Net): channel ranges, padded output blocks, leaky relu, dilation -- one source, nothing fused
+    if (a.C1 || a.in1 || a.res || a.d2s || a.relu_in || a.pool_out || a.ups || a.dil < 1 || a.CoutPad % F4_BN || a.Cout % 4 || a.Cout > a.CoutPad ||
+        a.in0_cs < a.C0 || a.rec_co + a.Cout > a.rec_cs || ((a.in0_cs | a.rec_cs | a.rec_co) & 3) || !wf4_fits_general(a.H, a.W, a.C0, a.in0_cs, a.rec_cs))
+      return hipErrorInvalidValue;
+    static bool gattr[64] = {};
+    if (!gattr[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false, false, false, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      gattr[dev] = true;
+    }
+    const int d = a.dil;
+    const int gitems = (((a.W + d - 1) / d + F4_TW - 1) / F4_TW) * (((a.H + d - 1) / d + F4_TH - 1) / F4_TH) * d * d * a.N * (a.CoutPad / F4_BN);
+    hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false, false, false, true>), dim3(std::min(gitems, std::max(8, n_cu[dev] & ~7))), dim3(512), lds, st, a, gitems);
+    return hipGetLastError();
+  }
+  if (!wf4_fits(a.H, a.W, a.C0, a.C1, a.Cout) || (a.res && a.d2s)) return hipErrorInvalidValue;
   // (fused pooling: instantiated for what FISRnet needs it for, the last conv of an encoder level -- residual, no relu-on-load)
   if (a.pool_out && (a.d2s || (a.H & 1) || (a.W & 1) || a.relu_in || !a.res)) return hipErrorInvalidValue;
   // (fused x2 bilinear: the decoder's resize convolution -- one source, no relu-on-load, no residual)

@@ -51,6 +51,7 @@ struct PwcConv {                 // one packed convolution
   float* d_w = nullptr; float* d_b = nullptr;     // generic implicit-GEMM kernel (fp32 weights, any stride / dilation)
   Conv1aWeights* w1a = nullptr;  // conv1a (3 -> 16, stride 2): [9][4][16] + bias [16] for the vector-ALU kernel (host copy, passed by value)
   char* d_wu = nullptr;          // fp32 engine: Winograd slabs for conv3x3_wino8p_kernel (stride 1, Cout >= 32)
+  char* d_wu4 = nullptr;         // fp32 engine with F(4x4) (FISR_PREC_F32W4): slabs for conv3x3_wf4_kernel<GENERAL> beside them
   void* d_wd = nullptr;          // fp16 engine: weight slabs of the LDS-DMA kernel conv3x3_dma.h (stride 1, Cout >= 16)
   int cout_pad_d = 0, nt_d = 2;  // ... its Cout padding and N block (32 * nt_d channels: 32 when Cout % 64 == 32)
   ConvW dw;                      // FISRnet's direct kernel in the engine's arithmetic (stride 1, dilation 1: the 2-channel flow heads; fp32: also level 1)
@@ -68,6 +69,7 @@ struct fisr_pwc {
   int dev = 0;
   bool finalized = false;
   int precision = FISR_PREC_F32W;  // FISR_PREC_F32W: fp32 tensors and arithmetic (Winograd for the dense layers); FISR_PREC_F16: fp16 features
+  bool f4 = false;                 // FISR_PREC_F32W4: the fp32 engine with F(4x4,3x3) on the maps where it is the faster Winograd kernel
   std::map<std::string, PwcVar> vars;
   std::map<std::string, PwcConv> convs;
   std::map<std::string, PwcDeconv> deconvs;
@@ -173,6 +175,12 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
     pack_weights_wino(dense.data(), cin_buf, co, cin_buf, wu);
     HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu, wu.size()));
     HIP_OK(nullptr, hipMemcpy(pc.d_wu, wu.data(), wu.size(), hipMemcpyHostToDevice));
+    if (ctx->f4 && co % 4 == 0 && cin_buf % (2 * F4_CH) == 0) {
+      std::vector<char> wu4;
+      pack_weights_wf4(dense.data(), cin_buf, co, cin_buf, wu4);
+      HIP_OK(nullptr, hipMalloc((void**)&pc.d_wu4, wu4.size()));
+      HIP_OK(nullptr, hipMemcpy(pc.d_wu4, wu4.data(), wu4.size(), hipMemcpyHostToDevice));
+    }
   } else if (as_direct) {
     pc.dw.ci = cin_buf; pc.dw.co = co; pc.dw.w = std::move(dense); pc.dw.b = kb.v;
     int rc = upload_conv<float>(nullptr, pc.dw, false);
@@ -267,6 +275,9 @@ struct PwcRunner {
       return 1;
     }
     (void)n;
+    // (5: the F(4x4) kernel, where it is the faster of the two -- the size rule of the FISRnet engine on the SUB-image of a dilated layer)
+    if (pc.d_wu4 && stride == 1 && !has_add && act_ok && wf4_fits_general(h, w, pc.cin_buf, in_cs, out_cs) &&
+        wf4_wins((h + dil - 1) / dil, (w + dil - 1) / dil, pc.cin_buf)) return 5;
     if (pc.d_wu && stride == 1 && !has_add && act_ok && wino_fits(1, h, w, in_cs, 0, out_cs)) return 2;
     if (pc.have_dw && stride == 1 && dil == 1 && !has_add && act_ok) return 3;
     return 1;
@@ -284,6 +295,14 @@ struct PwcRunner {
     a.relu_in = 0; a.relu_out = slope != 1.f; a.d2s = 0; a.d2s_shift = 0;
     a.out_cstride = out_cs; a.out_coff = out_co; a.out_split = 1 << 30; a.out_gap = 0; a.wexp = 0;
     a.in0_cs = in_cs; a.in1_cs = 0; a.slope = slope != 1.f ? slope : 0.f; a.trace = nullptr;
+    if (route == 5) {
+      a.wpk = pc.d_wu4;
+      a.C0 = pc.cin_buf; a.C1 = 0; a.CoutPad = round_up(pc.cout, F4_BN);
+      a.rec_cs = out_cs; a.rec_co = out_co; a.dil = dil;
+      hipError_t e = launch_conv_wf4(a, st);
+      if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, name + " (winograd F(4x4)): " + hipGetErrorString(e));
+      return;
+    }
     if (route == 2 || route == 4) {
       // FISRnet's persistent Winograd kernel / LDS-DMA kernel on a channel range of the buffer
       a.wpk = route == 2 ? (const void*)pc.d_wu : pc.d_wd;
@@ -540,6 +559,7 @@ static void pwc_release_packed(fisr_pwc* c) {
   for (auto& kv : c->convs) {
     PwcConv& pc = kv.second;
     if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd);
+    if (pc.d_wu4) (void)hipFree(pc.d_wu4);
     delete pc.w1a; pc.w1a = nullptr;
     if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
   }
@@ -591,13 +611,14 @@ int fisr_pwc_set_weight(fisr_pwc* c, const char* name, const float* host, const 
 // tensors, fp32 accumulation, fp32 flows; the dense layers on the LDS-DMA kernel)
 int fisr_pwc_finalize_precision(fisr_pwc* c, int precision) {
   if (!c) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_finalize: ctx is NULL");
-  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F32 && precision != FISR_PREC_F16)
-    return pfail(c, FISR_EINVAL, "fisr_pwc_finalize_precision: FISR_PREC_F32W or FISR_PREC_F16");
+  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F32W4 && precision != FISR_PREC_F32 && precision != FISR_PREC_F16)
+    return pfail(c, FISR_EINVAL, "fisr_pwc_finalize_precision: FISR_PREC_F32W, FISR_PREC_F32W4 or FISR_PREC_F16");
   for (auto& kv : c->vars) if (!kv.second.have) return pfail(c, FISR_EMISSING, "missing variable " + kv.first);
   DeviceGuard guard(c->dev);
   HIP_OK(nullptr, guard.err);
   pwc_release_packed(c);
   c->precision = precision == FISR_PREC_F16 ? FISR_PREC_F16 : FISR_PREC_F32W;
+  c->f4 = precision == FISR_PREC_F32W4;
   int rc = 0;
   const int real[7] = {3, 16, 32, 64, 96, 128, 196};
   for (int l = 1; l <= PWC_LVLS && !rc; ++l) {
@@ -721,18 +742,20 @@ int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, 
 // channel range [in_co, in_co + cin_buf) of a buffer with pixel stride in_cs, the output the range [out_co, out_co + cout)
 // of a buffer with pixel stride out_cs.  w_host: TF HWIO [3,3,ci,cout]; chmap (nullable = identity, then ci == cin_buf):
 // buffer channel, relative to in_co, of TF input channel j (the dense blocks' padded channel groups).  route 0: the
-// network's own choice, 1: generic implicit GEMM, 2: fp32 Winograd, 3: FISRnet's direct kernel, 4: fp16 LDS-DMA kernel (2 - 4: error
-// if the layer is not eligible).  Returns the route taken (1 .. 4) or a negative error.
+// network's own choice, 1: generic implicit GEMM, 2: fp32 Winograd F(2x2), 3: FISRnet's direct kernel, 4: fp16 LDS-DMA kernel, 5: fp32
+// Winograd F(4x4) (FISR_PREC_F32W4 only) (2 - 5: error if the layer is not eligible).  Returns the route taken (1 .. 5) or a negative error.
 int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
                      const int* chmap, void* out, int out_f32, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
                      int stride, int dil, float slope, int route, int precision, void* stream) {
   if (!in || !w_host || !b_host || !out || ci < 1 || cout < 1 || cin_buf < ci || n < 1 || h < 1 || w < 1 || stride < 1 || stride > 2 || dil < 1)
     return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: bad argument");
-  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F16) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: FISR_PREC_F32W or FISR_PREC_F16");
+  if (precision != FISR_PREC_F32W && precision != FISR_PREC_F32W4 && precision != FISR_PREC_F16)
+    return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: FISR_PREC_F32W, FISR_PREC_F32W4 or FISR_PREC_F16");
   if ((in_cs | in_co | out_cs | out_co | cin_buf) & 3) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: channel strides / offsets / cin_buf must be multiples of 4");
   fisr_pwc tmp;
   tmp.dev = device_of(out);
-  tmp.precision = precision;
+  tmp.precision = precision == FISR_PREC_F32W4 ? FISR_PREC_F32W : precision;
+  tmp.f4 = precision == FISR_PREC_F32W4;
   DeviceGuard guard(tmp.dev);
   HIP_OK(nullptr, guard.err);
   PwcVar& kw = tmp.vars["op/kernel"]; PwcVar& kb = tmp.vars["op/bias"];

@@ -52,13 +52,14 @@ def synthetic_weights(seed: int = 595000, flow_gain: float = 1.0) -> "OrderedDic
 
 
 class PWCNet:
-    """precision "fp32" (float32 tensors and arithmetic) or "fp16" (fp16 feature tensors, fp32 accumulation, float32 flows: the
-    16-bit flow of cfg5)."""
+    """precision "fp32" (float32 tensors and arithmetic; r04: the dense and context layers on the F(4x4,3x3) Winograd kernel where
+    the (sub-)image is at least 48 x 64, F(2x2,3x3) below), "fp32w" (the same with F(2x2) everywhere: round 3's fp32 flow) or "fp16"
+    (fp16 feature tensors, fp32 accumulation, float32 flows: the 16-bit flow of cfg5)."""
 
     def __init__(self, device: str = "cuda:0", precision: str = "fp32"):
         import torch
-        if precision not in ("fp32", "fp16"):
-            raise ValueError("PWCNet precision must be 'fp32' or 'fp16'")
+        if precision not in ("fp32", "fp32w", "fp16"):
+            raise ValueError("PWCNet precision must be 'fp32', 'fp32w' or 'fp16'")
         self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
@@ -85,7 +86,7 @@ class PWCNet:
             a = np.ascontiguousarray(weights[name], np.float32)
             shp = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
             self._check(self._L.fisr_pwc_set_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), shp, a.ndim))
-        self._check(self._L.fisr_pwc_finalize_precision(self._ctx, _lib.PREC_F16 if self.precision == "fp16" else _lib.PREC_F32W))
+        self._check(self._L.fisr_pwc_finalize_precision(self._ctx, {"fp16": _lib.PREC_F16, "fp32w": _lib.PREC_F32W}.get(self.precision, _lib.PREC_F32W4)))
         self._finalized = True
 
     def load(self, path_or_prefix: str) -> None:

@@ -242,7 +242,9 @@ FISR_API int fisr_pwc_variable(int i, const char** name, int64_t* shape4);
 /* host float32 tensor in TF layout; unknown names (optimizer slots, ...) are ignored with return 1 */
 FISR_API int fisr_pwc_set_weight(fisr_pwc* ctx, const char* tf_var_name, const float* host, const int64_t* shape, int rank);
 FISR_API int fisr_pwc_finalize(fisr_pwc* ctx);   /* FISR_EMISSING names the first absent variable; = ..._precision(ctx, FISR_PREC_F32W) */
-/* precision FISR_PREC_F32W: float32 tensors and arithmetic (dense layers on the Winograd kernel).  FISR_PREC_F16 (cfg5 of
+/* precision FISR_PREC_F32W: float32 tensors and arithmetic (dense layers on the F(2x2,3x3) Winograd kernel); FISR_PREC_F32W4: the
+ * same engine with the F(4x4,3x3) kernel's GENERAL instantiation where the (sub-)image of a layer is at least 48 x 64 (r04).
+ * FISR_PREC_F16 (cfg5 of
  * BASELINE.json, "bf16"-class 16-bit arithmetic): fp16 feature tensors, fp32 accumulation, float32 flows (flow heads, refinement
  * sums, what is handed to the next level and to the caller); dense layers on the LDS-DMA kernel. */
 FISR_API int fisr_pwc_finalize_precision(fisr_pwc* ctx, int precision);

@@ -56,7 +56,7 @@ def _host(t):
     return t.float().cpu().numpy()
 
 
-PID = {"fp32": flib.PREC_F32W, "fp16": flib.PREC_F16}
+PID = {"fp32": flib.PREC_F32W, "fp32w4": flib.PREC_F32W4, "fp16": flib.PREC_F16}
 
 
 def _run_conv(x_buf, in_co, cin_buf, w, b, chmap, out_buf, out_co, n, h, wd, stride, dil, slope, route, add_buf=None, add_co=0, prec="fp32"):
@@ -97,6 +97,60 @@ def test_winograd_general_dilated_vs_oracle(dil, shape):
     print(f"wino GENERAL dil {dil} {h}x{wd}: max|err| {err:.2e} (|y| max {np.abs(exp).max():.2f})")
     assert err < 2e-5
     assert (got[..., :out_co] == 7.25).all() and (got[..., out_co + cout:] == 7.25).all()     # neighbours of the range untouched
+
+
+@pytest.mark.parametrize("dil,shape", [(1, (272, 480)), (2, (272, 480)), (4, (272, 480)), (1, (136, 240)), (2, (139, 251)), (4, (300, 270)), (1, (75, 133))])
+def test_winograd_f4_general_dilated_vs_oracle(dil, shape):
+    """conv3x3_wf4_kernel<GENERAL> (r04: the fp32 flow engine's dense and context layers on F(4x4,3x3), route 5): the same layer
+    as the F(2x2) test above -- dilation as d x d interleaved sub-images of several 16x32 items each, channel-range input and
+    output, leaky relu, a Cout of one and a half 64-channel blocks, ragged sizes -- against the float64 oracle, and the channels
+    next to the output range untouched.  (F(4,3)'s transforms: ~10x F(2x2)'s rounding, the bound of tests/test_gpu_parity.py.)"""
+    h, wd = shape
+    rng = np.random.default_rng(100 * dil + h + 7)
+    in_cs, in_co, cin = 160, 32, 96
+    out_cs, out_co, cout = 192, 64, 96
+    x = (rng.standard_normal((1, h, wd, in_cs)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    xb = torch.from_numpy(x).cuda()
+    ob = torch.full((1, h, wd, out_cs), 7.25, dtype=torch.float32, device="cuda")
+    took = _run_conv(xb, in_co, cin, w, b, None, ob, out_co, 1, h, wd, 1, dil, 0.1, 5, prec="fp32w4")
+    assert took == 5
+    got = ob.cpu().numpy()
+    exp = _oracle_conv(x[..., in_co:in_co + cin], w, b, 1, dil, 0.1)
+    err = np.abs(got[..., out_co:out_co + cout] - exp)
+    print(f"F(4x4) GENERAL dil {dil} {h}x{wd}: max|err| {err.max():.2e} rms {np.sqrt((err ** 2).mean()):.2e} (|y| max {np.abs(exp).max():.2f})")
+    assert err.max() < 1.2e-4 and np.sqrt((err ** 2).mean()) < 1e-5
+    assert (got[..., :out_co] == 7.25).all() and (got[..., out_co + cout:] == 7.25).all()
+
+
+def test_winograd_f4_general_batch_padded_groups_and_routing():
+    """Two images, a dense block's padded channel groups (chmap), Cout = 32 (half a block; the other 32 channels of the block are
+    computed from zero weights and never stored) on the F(4x4) route; and the engine's own choice (route 0): F(4x4) where the
+    (sub-)image is at least 48 x 64, F(2x2) below -- a dilation of 16 on a 272 x 480 map leaves 17 x 30 sub-images."""
+    h, wd, n = 136, 240, 2
+    rng = np.random.default_rng(6)
+    cin_buf = 128
+    chmap = list(range(0, 40)) + list(range(48, 48 + 41)) + list(range(96, 96 + 30))
+    ci, cout = len(chmap), 32
+    x = (rng.standard_normal((n, h, wd, cin_buf)) * 0.5).astype(np.float32)
+    x[..., 40:48] = 3.0
+    w = (rng.standard_normal((3, 3, ci, cout)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    xb = torch.from_numpy(x).cuda()
+    ob = torch.zeros((n, h, wd, cout), dtype=torch.float32, device="cuda")
+    assert _run_conv(xb, 0, cin_buf, w, b, chmap, ob, 0, n, h, wd, 1, 1, 0.1, 0, prec="fp32w4") == 5
+    exp = _oracle_conv(x[..., chmap], w, b, 1, 1, 0.1)
+    err = np.abs(ob.cpu().numpy() - exp).max()
+    print(f"F(4x4) GENERAL batch 2, padded groups: max|err| {err:.2e}")
+    assert err < 1.2e-4
+    # routing by (sub-)image size
+    x2 = torch.zeros((1, 272, 480, 64), device="cuda")
+    o2 = torch.zeros((1, 272, 480, 64), device="cuda")
+    w2, b2 = np.zeros((3, 3, 64, 64), np.float32), np.zeros(64, np.float32)
+    for dil, want in ((1, 5), (4, 5), (8, 2), (16, 2)):
+        assert _run_conv(x2, 0, 64, w2, b2, None, o2, 0, 1, 272, 480, 1, dil, 0.1, 0, prec="fp32w4") == want, dil
+    assert _run_conv(x2, 0, 64, w2, b2, None, o2, 0, 1, 272, 480, 1, 1, 0.1, 0, prec="fp32") == 2        # FISR_PREC_F32W keeps F(2x2)
 
 
 def test_winograd_general_batch_and_padded_groups_vs_oracle():
