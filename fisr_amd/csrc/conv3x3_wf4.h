@@ -96,6 +96,13 @@ constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; 
 #ifndef FISR_F4_SOFF_RUN
 #define FISR_F4_SOFF_RUN 1       // the stores' uniform offsets as running scalar sums (A/B hook: 0 = sixteen hoisted products)
 #endif
+// FISR_F4_RAWEARLY (r04): the raw pair is requested at the START of its odd iteration instead of behind that iteration's weight
+// copies (+0.6 of an iteration of latency budget: 1.5-2.0 instead of 1.0-1.4 iterations until it is needed).  vmcnt is one
+// in-order counter, so the weight copies of an odd iteration then all come from the transform waves (9 each) and those of an even
+// one from the copy waves (9 each): a wave that waits for weight copies never has an older raw copy in front of them.
+#ifndef FISR_F4_RAWEARLY
+#define FISR_F4_RAWEARLY 0
+#endif
 #ifndef FISR_F4_UALL
 #define FISR_F4_UALL 1
 #endif
@@ -298,8 +305,21 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   //  on the copy waves it costs 2.4 % (87.8 -> 89.9 ms per 94 launches), with the blend of the fused bilinear 3-4 %, with the
   //  pooling epilogue 1 %, plain without residual nothing; splits that left the transform waves 2-5 copies each: +-1 %.)
   constexpr bool UALL = FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL && !UPS;
+  constexpr bool RAWE = FISR_F4_RAWEARLY && !UALL && !UPS;
   auto copy_u1 = [&](int nblk, int kc, int buf, int j) __attribute__((always_inline)) {
     unsigned c = (UALL ? (unsigned)(cw + 4 * j) : j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave)) + u_rot;
+    c = c >= 36u ? c - 36u : c;
+    const unsigned so = (unsigned)(((size_t)kc * nblocks + nblk) * F4_U_BYTES) + c * 1024u;
+    const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES + c * 1024u;
+    {
+      unsigned keep_;
+      asm volatile(FISR_F4_BEGIN(keep, lds) FISR_F4_COPYU(o, rs, so) FISR_F4_END(keep)
+                   : [keep] "=&s"(keep_) : [rs] "s"(rsw), [lds] "s"(lds), [o] "v"(u_voff), [so] "s"(so) : "memory", "scc");
+    }
+  };
+  // RAWEARLY: weight copy j (0..8) of the nine this wave issues in "its" iterations: piece (wave & 3) + 4 j
+  auto copy_u9 = [&](int nblk, int kc, int buf, int j) __attribute__((always_inline)) {
+    unsigned c = (unsigned)((wave & 3) + 4 * j) + u_rot;
     c = c >= 36u ? c - 36u : c;
     const unsigned so = (unsigned)(((size_t)kc * nblocks + nblk) * F4_U_BYTES) + c * 1024u;
     const unsigned lds = u_lds0 + (unsigned)buf * (unsigned)F4_U_BYTES + c * 1024u;
@@ -656,6 +676,13 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           if (q < 4) { copy_u1(u_nblk, ku, buf ^ 1, 2 * q); copy_u1(u_nblk, ku, buf ^ 1, 2 * q + 1); }
           if (q == 4) copy_u1(u_nblk, ku, buf ^ 1, 8);
         }
+      } else if constexpr (RAWE) {
+        // odd iterations: the transform waves issue all 36 weight copies (two behind quad 0, one behind each later quad), even
+        // iterations: the copy waves
+        if (!(FISR_F4ABL & 1) && ((ROLE < 2) == ODD)) {
+          if (q == 0) { copy_u9(u_nblk, ku, buf ^ 1, 0); copy_u9(u_nblk, ku, buf ^ 1, 1); }
+          else copy_u9(u_nblk, ku, buf ^ 1, q + 1);
+        }
       } else if (!(FISR_F4ABL & 1) && q >= FISR_F4_UQ && q - FISR_F4_UQ < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q - FISR_F4_UQ);
       if constexpr (ROLE < 2) {
         if (!(FISR_F4ABL & 4)) {
@@ -673,13 +700,16 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
           if (q == 5) { copy_l1(pc, pbt, 0); if (cw < 2) copy_l1(pc, pbt, 1); }     // (behind this iteration's five weight copies)
         }
       } else if constexpr (ODD) {
-        if (q == 5) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
-        if (q == 6) { copy_pair1(pc, pbt ^ 1, 2); copy_pair1(pc, pbt ^ 1, 3); }
-        if (q == 7) copy_pair1(pc, pbt ^ 1, 4);
+        constexpr int Q0 = RAWE ? 0 : 5;            // (RAWEARLY: first thing in the iteration -- this wave has no weight copies in it)
+        if (q == Q0) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
+        if (q == Q0 + 1) { copy_pair1(pc, pbt ^ 1, 2); copy_pair1(pc, pbt ^ 1, 3); }
+        if (q == Q0 + 2) copy_pair1(pc, pbt ^ 1, 4);
       } else if constexpr (RELU_IN) {
-        // the pair requested an iteration ago is older than this iteration's five weight copies
+        // the pair requested an iteration ago is older than this iteration's weight copies so far (five; RAWEARLY: six, quads 0-4)
         if (q == 4) {
-          if constexpr (UALL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          if constexpr (UALL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else if constexpr (RAWE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
           relu_read(pbt ^ 1, 0);
         }
         if (q == 5) relu_write(pbt ^ 1, 0);
@@ -691,7 +721,9 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     if (FISR_F4ABL & 2048) { }                                                // (ablation 2048: no wait for the copies at the end of an iteration)
     else if (ROLE == 2 && UPS && !ODD) {                                           // U(g+1) landed; the staged pair stays in flight
       if (cw < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    } else if (ROLE == 2 && ODD && !UPS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
+    } else if (RAWE && ROLE == 2 && ODD) { }                                  // RAWEARLY: only the raw pair is in flight, and it stays
+    else if (RAWE && ROLE < 2 && !ODD) { }                                    // RAWEARLY: no copies of this wave in an even iteration
+    else if (ROLE == 2 && ODD && !UPS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
     else if (ROLE < 2 && UALL) { }                                           // (nothing of this wave's to wait for)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // U(g+1) (and the raw pair of the iteration before) landed
     lds_barrier();

@@ -96,10 +96,25 @@ int fisr_train_conv3x3(const float* in0, int c0, const float* in1, int c1, const
   static const long env_items = [] { const char* e = getenv("FISR_TRAIN_WINO_ITEMS"); return e ? atol(e) : 0L; }();
   if (env_items > 0) min_items = env_items;
 #endif
-  if (d_packed_wino && !scatter && cout % W_BN == 0 && (c0 + c1) / W_CH >= 4 && items >= min_items && wino_fits(n, h, w, c0, c1, cout)) {
+  if (d_packed_wino && !scatter && cout % W_BN == 0 && (c0 + c1) / W_CH >= 4 && items >= min_items && wino_fits(1, h, w, c0, c1, cout)) {
     a.wpk = d_packed_wino;
     a.CoutPad = cout;
-    HIP_OK(nullptr, launch_conv_wino(a, (hipStream_t)stream));
+    // The Winograd kernel addresses a launch's whole batch with 32-bit byte offsets: a batch that does not fit goes out in
+    // chunks of images (train.py no longer allocates the direct kernel's pack for these layers, so a large batch or
+    // patch used to fail the step with EINVAL instead of falling back; fisr_pwc.h splits the same way).
+    int per = n;
+    while (per > 1 && !wino_fits(per, h, w, c0, c1, cout)) per = (per + 1) / 2;
+    const size_t px = (size_t)h * w;
+    const size_t out_px = a.d2s ? px * 4 * (size_t)(cout / 4) : px * (size_t)cout;
+    for (int k = 0; k < n; k += per) {
+      ConvArgs b = a;
+      b.N = std::min(per, n - k);
+      b.in0 = in0 + (size_t)k * px * c0;
+      b.in1 = in1 ? in1 + (size_t)k * px * c1 : nullptr;
+      b.res = res ? res + (size_t)k * px * cout : nullptr;
+      b.out = out + (size_t)k * out_px;
+      HIP_OK(nullptr, launch_conv_wino(b, (hipStream_t)stream));
+    }
     return 0;
   }
   if (!d_packed) return fail(nullptr, FISR_EINVAL, "fisr_train_conv3x3: this call needs the direct kernel's packed weights (d_packed)");

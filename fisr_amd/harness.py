@@ -87,11 +87,16 @@ def flow_file_name(args):
     return os.path.join(folder, os.path.basename(folder) + "_test_ss{}_fr{}.flo".format(1, args.frame_num))
 
 
-def compute_flow(net, args):
+def compute_flow(net, args, rank: int = 0, world: int = 1, return_array: bool = False):
     """`FISR_for_video_Compute_Flow(args)` (FISR_tfoptflow/FISR_for_video_pwcnet_predict_from_img_test.py:84-147) on the
     GPU: the first frame_num YUV frames of the folder, PWC-Net-large in both directions per consecutive pair, written
     as the reference's 5-D .flo `<folder>/<folder name>_test_ss1_fr<frame_num>.flo` [frame_num-1, 2, h, w, 2].
-    Returns the file name."""
+    Returns the file name (and the array with return_array).
+
+    world > 1 (one process per GPU, torch.distributed initialised): the frame PAIRS are sharded over the ranks (pair p on rank
+    p % world), every rank gathers all flows in memory and rank 0 writes the file -- no rank idles in a barrier for the length of
+    the clip (the process group's watchdog would abort a long one), and nobody re-reads the file, so the ranks need no shared
+    file system."""
     import torch
     from . import pwcnet
     paths = sorted_pngs(args.frame_folder_path)
@@ -109,16 +114,30 @@ def compute_flow(net, args):
                 raise FileNotFoundError(f"PWC-Net weights not found at {ck!r} (the reference downloads them separately, "
                                         "script :31); pass --pwc_ckpt, --flow_file or --synthetic_weights")
             pwc.load(ck)
-        frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[:num_fr]]
-        pred = pwc.compute_flow(frames).cpu().numpy()
+        if world <= 1:
+            frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[:num_fr]]
+            pred = pwc.compute_flow(frames).cpu().numpy()
+        else:
+            import torch.distributed as dist
+            mine = {}
+            for pair in range(rank, num_fr - 1, world):
+                fr = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[pair:pair + 2]]
+                mine[pair] = pwc.compute_flow(fr).cpu().numpy()[0]            # [2, h, w, 2]
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+            allp = {}
+            for d in parts:
+                allp.update(d)
+            pred = np.stack([allp[p] for p in range(num_fr - 1)], axis=0)
     finally:
         pwc.close()
     print(pred.shape)
     name = flow_file_name(args)
-    tmp = name + ".tmp%d" % os.getpid()
-    fio.write_flow(pred, tmp)
-    os.replace(tmp, name)                      # atomic: a concurrent reader sees the old file or the whole new one
-    return name
+    if rank == 0:
+        tmp = name + ".tmp%d" % os.getpid()
+        fio.write_flow(pred, tmp)
+        os.replace(tmp, name)                  # atomic: a concurrent reader sees the old file or the whole new one
+    return (name, pred) if return_array else name
 
 
 def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_test_in_seq, H, W, num_patch):

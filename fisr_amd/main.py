@@ -200,21 +200,17 @@ def main(argv=None):
     # FISR_for_video (main.py:207-235)
     flow_file = args.flow_file
     if not flow_file:
-        # FISR_for_video_Compute_Flow (main.py:210): PWC-Net-large on the GPU, both directions of every frame pair.
-        # With several ranks rank 0 computes and writes the file (to a temporary name, then os.replace: a reader never
-        # sees a truncated file); the others wait at the barrier and read it afterwards.
+        # FISR_for_video_Compute_Flow (main.py:210): PWC-Net-large on the GPU, both directions of every frame pair.  With several
+        # ranks the pairs are sharded, gathered in memory on every rank, and rank 0 writes the reference's .flo file.
         if world > 1:
             import torch.distributed as dist
-            if dist.get_rank() == 0:
-                flow_file = harness.compute_flow(net, args)
-            dist.barrier()
-            flow_file = harness.flow_file_name(args)
+            _, flow_file = harness.compute_flow(net, args, dist.get_rank(), world, return_array=True)      # (the array, not the name)
         else:
             flow_file = harness.compute_flow(net, args)
         print("[*] Flow file saved!")
     warp_file = args.warp_file
     if warp_file is None:
-        flow = fio.read_flo_file_5dim(flow_file)
+        flow = fio.read_flo_file_5dim(flow_file) if isinstance(flow_file, str) else flow_file
         frames = harness.sorted_pngs(args.frame_folder_path)
         warp_file = harness.warp_img(net, frames, flow)          # ndarray, stays in memory
         print("[*] Warp done on the GPU")

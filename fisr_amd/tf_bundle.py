@@ -301,17 +301,21 @@ def _entry_proto(dtype, shape, offset, size, crc):
 
 
 def write_bundle(prefix: str, tensors, block_size: int = 4096, with_crc: bool = True) -> None:
-    """Write `tensors` (name -> float32 ndarray) as a one-shard checkpoint-V2 bundle, plus the
+    """Write `tensors` (name -> ndarray: float32, or an integer type for counters) as a one-shard checkpoint-V2 bundle, plus the
     `checkpoint` state file tf.train.get_checkpoint_state reads (FISRnet.py:1106)."""
     names = sorted(tensors)
     entries = []
     with open(prefix + ".data-00000-of-00001", "wb") as f:
         off = 0
         for n in names:
-            raw = np.ascontiguousarray(tensors[n], np.float32).tobytes()
+            a = np.asarray(tensors[n])
+            # integer tensors keep their type (the reference's global step `Variable`, FISRnet.py:232, is a DT_INT32 scalar)
+            dt, npdt = (DT_INT32, np.int32) if a.dtype.kind in "iu" and a.dtype.itemsize <= 4 else \
+                       (DT_INT64, np.int64) if a.dtype.kind in "iu" else (DT_FLOAT, np.float32)
+            raw = np.ascontiguousarray(a, npdt).tobytes()
             f.write(raw)
             crc = mask_crc(crc32c(raw)) if with_crc else 0
-            entries.append((n.encode(), _entry_proto(DT_FLOAT, np.shape(tensors[n]), off, len(raw), crc)))
+            entries.append((n.encode(), _entry_proto(dt, np.shape(a), off, len(raw), crc)))
             off += len(raw)
     header = b"\x08\x01" + b"\x1a\x02\x08\x01"       # num_shards=1, version{producer=1}
     items = [(b"", header)] + entries

@@ -220,7 +220,12 @@ def run_train(args):
                 # tf.train.Saver's checkpoint-V2 files (<name>.index / .data-00000-of-00001) under the reference's variable
                 # names, so that the reference's FISRnet.load (FISRnet.py:1101-1115) restores what was trained here
                 from . import tf_bundle
-                tf_bundle.write_bundle(os.path.join(ckpt_dir, name), Wn)
+                # ... incl. the global step the reference's training-mode Saver also stores and restores: the unnamed
+                # tf.Variable(0, trainable=False) of FISRnet.py:232 is called `Variable` (int32 scalar) and drives
+                # piecewise_constant (without it saver.restore of this bundle fails with NotFound in train mode)
+                Wb = dict(Wn)
+                Wb["Variable"] = np.array(counter, np.int32)
+                tf_bundle.write_bundle(os.path.join(ckpt_dir, name), Wb)
             with open(os.path.join(ckpt_dir, "checkpoint"), "w") as f:
                 f.write(f'model_checkpoint_path: "{name}"\nall_model_checkpoint_paths: "{name}"\n')
             # Saver(max_to_keep=1) (FISRnet.py:585): the previous checkpoint SAVED BY THIS RUN goes once the state file names the new

@@ -90,6 +90,60 @@ def test_tile_parallel_real_engine_bit_exact(num_patch, groups, precision):
         assert r[2] == (2, 2 * H, 2 * W, 9)
 
 
+def _flow_worker(rank, world, port, folder, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from fisr_amd import harness
+        torch.cuda.set_device(0)
+        args = types.SimpleNamespace(frame_folder_path=folder, FISR_input_size=(96, 96), frame_num=5, flow_precision="fp32",
+                                     synthetic_weights=3, pwc_ckpt=None)
+        net = types.SimpleNamespace(device=torch.device("cuda:0"))
+        name, pred = harness.compute_flow(net, args, rank, world, return_array=True)
+        q.put((rank, name, pred.shape, float(np.abs(pred).sum()), pred if rank == 1 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flow_of_a_clip_is_sharded_over_the_ranks(tmp_path):
+    """`FISR_for_video` under several ranks used to let rank 0 compute the whole clip's flow while the others sat in a
+    barrier, then re-read the file by name.  Now the frame pairs are sharded (pair p on rank p % world), every rank gathers all
+    flows in memory and rank 0 writes the reference's .flo: two gloo ranks on cuda:0 against the single-process result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import types
+    from fisr_amd import harness
+    from fisr_amd import io as fio
+    rng = np.random.default_rng(5)
+    folder = tmp_path / "clip"
+    folder.mkdir()
+    base = rng.integers(0, 256, (12, 12, 3)).astype(np.float32)
+    for k in range(5):
+        fr = np.kron(np.roll(base, k, axis=1), np.ones((8, 8, 1), np.float32)) + rng.normal(0, 3, (96, 96, 3))
+        fio.write_png(str(folder / f"fr_{k:02d}.png"), np.clip(fr, 0, 255).astype(np.uint8))
+    args = types.SimpleNamespace(frame_folder_path=str(folder), FISR_input_size=(96, 96), frame_num=5, flow_precision="fp32",
+                                 synthetic_weights=3, pwc_ckpt=None)
+    name1, solo = harness.compute_flow(types.SimpleNamespace(device=torch.device("cuda:0")), args, return_array=True)
+    assert solo.shape == (4, 2, 96, 96, 2)
+    os.remove(name1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flow_worker, args=(r, 2, port, str(folder), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][2] == res[1][2] == (4, 2, 96, 96, 2) and res[0][3] == res[1][3]          # both ranks hold the same, whole flow
+    # (a pair run alone and inside a 5-frame run share the pyramid code path: same kernels, same inputs -> the same flow)
+    assert np.abs(res[1][4] - solo).max() < 1e-4, float(np.abs(res[1][4] - solo).max())
+    assert os.path.isfile(name1) and np.array_equal(fio.read_flo_file_5dim(name1), res[1][4])   # rank 0 wrote the reference's file
+
+
 def _run_bench(world, extra, port):
     import json
     import subprocess

@@ -259,6 +259,8 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     from fisr_amd import tf_bundle                                  # the TF checkpoint-V2 twin holds the same tensors
     Wb = tf_bundle.read_bundle(os.path.join(d, "ck", "FISRnet_exp1", "FISRnet-4"), name_filter="FISRnet")
     assert all(np.array_equal(Wb[k], W[k]) for k in W)
+    gs = tf_bundle.read_bundle(os.path.join(d, "ck", "FISRnet_exp1", "FISRnet-4"))["Variable"]      # the reference's global step (FISRnet.py:232)
+    assert gs.dtype == np.int32 and gs.shape == () and int(gs) == 4
     W0 = weights.xavier_weights(1)                                  # the from-scratch initialiser (ops.py:8-9), seed = exp_num
     assert any(not np.array_equal(W[k], W0[k]) for k in W)
     # Saver(max_to_keep=1): only the last step's files are left; they hold the Adam slots and beta powers
@@ -282,6 +284,32 @@ def test_phase_train_cli_writes_a_checkpoint_the_inference_engine_loads(env, tmp
     p1, p2, p3 = net.model(x)
     assert torch.isfinite(p3).all()
     net.close()
+
+
+def test_winograd_training_conv_splits_a_batch_beyond_32_bit_offsets(env):
+    """train.py allocates no direct-kernel pack for layers that have Winograd slabs, and the Winograd kernel addresses
+    one launch's batch with 32-bit byte offsets -- a batch beyond 4 GiB used to fail the step with FISR_EINVAL.  Now the entry
+    launches it in chunks of images: 1900 images of 96 x 96 x 64 (4.5 GB in, 4.5 GB out) through the Winograd-only call, equal bit
+    for bit to the same images run as two calls that fit."""
+    torch, L, lib = env
+    n, h, w, c = 1900, 96, 96, 64
+    assert n * h * w * c * 4 > 2 ** 32
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    x = torch.randn((n, h, w, c), device="cuda:0", generator=g)
+    wt = torch.randn((3, 3, c, c), device="cuda:0", generator=g) * 0.05
+    bias = torch.randn(1024, device="cuda:0", generator=g) * 0.1
+    pkw = torch.empty(L.fisr_train_wino_bytes(c, c, 0) // 4, device="cuda:0")
+    assert L.fisr_train_pack_wino(_ptr(wt), c, c, 0, _ptr(pkw), None) == 0
+    y = torch.empty((n, h, w, c), device="cuda:0")
+    assert L.fisr_train_conv3x3(_ptr(x), c, None, 0, None, _ptr(bias), c, None, _ptr(y), n, h, w, 1, 0, 0, 0, 0, _ptr(pkw), None) == 0
+    torch.cuda.synchronize()
+    half = n // 2
+    y2 = torch.empty((half, h, w, c), device="cuda:0")
+    for k in (0, half):
+        assert L.fisr_train_conv3x3(_ptr(x[k:k + half]), c, None, 0, None, _ptr(bias), c, None, _ptr(y2), half, h, w, 1, 0, 0, 0, 0, _ptr(pkw), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y[k:k + half], y2), k
+    assert float(y.abs().max()) > 0.5
 
 
 def _dp_worker(rank, world, port, q):
