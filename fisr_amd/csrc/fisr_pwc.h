@@ -56,11 +56,13 @@ struct PwcConv {                 // one packed convolution
   int cout_pad_d = 0, nt_d = 2;  // ... its Cout padding and N block (32 * nt_d channels: 32 when Cout % 64 == 32)
   ConvW dw;                      // FISRnet's direct kernel in the engine's arithmetic (stride 1, dilation 1: the 2-channel flow heads; fp32: also level 1)
   bool have_dw = false;
+  float* d_wp = nullptr;         // fp32 engines, two output channels, cin_buf % 32 == 0: pack_pointwise() of [cin_buf][tap * 2 + o] for pwc_pointwise_f32_kernel<20>
   int cin_buf = 0, cout = 0, cout_pad = 0;
 };
 struct PwcDeconv {
   float* d_w = nullptr; float* d_b = nullptr; int cin4 = 0;
   void* d_wd = nullptr; float* d_bz = nullptr;   // fp16 engine, wide inputs: the 16 taps x 2 outputs as a 32-channel centre-tap conv on the LDS-DMA kernel
+  float* d_wp = nullptr;                         // fp32 engines, cin4 % 32 == 0: pack_pointwise() of [cin4][32] for pwc_pointwise_f32_kernel<32> (the same 32 channels)
 };
 
 }  // namespace
@@ -165,6 +167,17 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
     }
     return 0;
   }
+  if (co == 2 && cin_buf % PW_CH == 0) {
+    // fp32 engines: the two-channel layers as a pointwise map to tap x output channels + a 9-tap gather (pwc_kernels.h)
+    std::vector<float> pw((size_t)cin_buf * 20, 0.f);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int c = 0; c < cin_buf; ++c)
+        for (int o = 0; o < 2; ++o) pw[(size_t)c * 20 + tap * 2 + o] = dense[((size_t)tap * cin_buf + c) * co + o];
+    std::vector<float> pk;
+    pack_pointwise(pw.data(), cin_buf, 20, pk);
+    HIP_OK(nullptr, hipMalloc((void**)&pc.d_wp, pk.size() * 4));
+    HIP_OK(nullptr, hipMemcpy(pc.d_wp, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+  }
   // fp32 engine: the stride-1 layers with 32 or more output channels (the dense flow estimators, the context convs incl. the
   // dilated ones: 97 % of the network's FLOPs) get FISRnet's Winograd slabs, the ones with fewer (the 2-channel flow heads, which
   // the 64-wide generic kernel computes 32 times over, and the 16-channel level-1 features) the weights of its direct kernel
@@ -204,6 +217,17 @@ int pwc_pack_deconv(fisr_pwc* ctx, const std::string& name, const std::vector<in
   HIP_OK(nullptr, hipMalloc((void**)&pd.d_b, 8));
   HIP_OK(nullptr, hipMemcpy(pd.d_w, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(nullptr, hipMemcpy(pd.d_b, kb.v.data(), 8, hipMemcpyHostToDevice));
+  if (ctx->precision != FISR_PREC_F16 && cin4 % PW_CH == 0) {
+    // fp32 engines: P[pixel][tap * 2 + o] by the pointwise kernel, then the same 2x2 gather
+    std::vector<float> pw((size_t)cin4 * 32, 0.f);
+    for (int k = 0; k < 16; ++k)
+      for (int o = 0; o < 2; ++o)
+        for (int j = 0; j < ci; ++j) pw[(size_t)chmap[j] * 32 + k * 2 + o] = kw.v[((size_t)k * 2 + o) * ci + j];
+    std::vector<float> pk;
+    pack_pointwise(pw.data(), cin4, 32, pk);
+    HIP_OK(nullptr, hipMalloc((void**)&pd.d_wp, pk.size() * 4));
+    HIP_OK(nullptr, hipMemcpy(pd.d_wp, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+  }
   if (ctx->precision == FISR_PREC_F16 && cin4 >= 32 && cin4 % D_CH == 0) {
     // P[pixel][tap * 2 + o] as a 3x3 convolution with 32 output channels whose only non-zero tap is the centre
     std::vector<float> dense((size_t)9 * cin4 * 32, 0.f);
@@ -264,6 +288,7 @@ struct PwcRunner {
   void zero(void* p, size_t bytes) { if (!ar.dry && !rc) (void)hipMemsetAsync(p, 0, bytes, st); }
 
   // which kernel runs a layer: 2 = FISRnet's persistent fp32 Winograd kernel (stride 1, Cout >= 32, any dilation), 4 = its fp16
+  // fp32 engines: 6 = the two-channel layers without activation (flow heads, dc_conv7) as pointwise map + 9-tap gather;
   // LDS-DMA kernel (stride 1, Cout >= 16, any dilation), 3 = its direct kernel (stride 1, dilation 1: the 2-channel flow heads;
   // fp32 engine: also the 16-channel level-1 features), 1 = the generic implicit GEMM (stride 2, the residual dc_conv7)
   int conv_route(const std::string& name, int n, int h, int w, int in_cs, int out_cs, bool out_f32, int stride, int dil, float slope, bool has_add) {
@@ -275,6 +300,8 @@ struct PwcRunner {
       return 1;
     }
     (void)n;
+    // (6: two output channels, no activation -- pointwise map to tap x output channels + gather; reads its input once)
+    if (pc.d_wp && stride == 1 && dil == 1 && slope == 1.f && in_cs % 4 == 0) return 6;
     // (5: the F(4x4) kernel, where it is the faster of the two -- the size rule of the FISRnet engine on the SUB-image of a dilated layer)
     if (pc.d_wu4 && stride == 1 && !has_add && act_ok && wf4_fits_general(h, w, pc.cin_buf, in_cs, out_cs) &&
         wf4_wins((h + dil - 1) / dil, (w + dil - 1) / dil, pc.cin_buf)) return 5;
@@ -285,10 +312,26 @@ struct PwcRunner {
   // out: TE (out_f32 = false) or float32 (out_f32 = true: the flow heads and dc_conv7); add: float32
   void conv(const std::string& name, const TE* in, int in_cs, int in_co, void* out, bool out_f32, int out_cs, int out_co,
             int n, int h, int w, int stride, int dil, float slope, const float* add = nullptr, int add_cs = 0, int add_co = 0) {
-    if (rc || ar.dry) return;
+    if (rc) return;
     if (!HALF) out_f32 = true;
     const PwcConv& pc = ctx->convs[name];
     const int route = conv_route(name, n, h, w, in_cs, out_cs, HALF ? out_f32 : false, stride, dil, slope, add != nullptr);
+    if (route == 6) {
+      // T lives until the gather has run (stream order): the arena hands its bytes to the next allocation
+      const size_t keep = ar.off;
+      float* T = falloc((size_t)n * h * w * 20);
+      ar.off = keep;
+      if (ar.dry) return;
+      if (in_co % 4) { rc = pfail(ctx, FISR_EINVAL, name + ": channel offset of a pointwise layer must be a multiple of 4"); return; }
+      PointwiseArgs pa;
+      pa.in = (const float*)in; pa.in_cs = in_cs; pa.in_co = in_co; pa.Cin = pc.cin_buf; pa.w = pc.d_wp; pa.out = T; pa.npix = (size_t)n * h * w;
+      hipLaunchKernelGGL(pwc_pointwise_f32_kernel<20>, dim3((unsigned)((pa.npix + PW_PX - 1) / PW_PX)), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL(pwc_conv3_combine_kernel, dim3(grid_for(pa.npix)), dim3(256), 0, st, T, pc.d_b, add, add_cs, add_co, (float*)out, out_cs,
+                         out_co, n, h, w);
+      check(name.c_str());
+      return;
+    }
+    if (ar.dry) return;
     ConvArgs a;
     a.in0 = in + in_co; a.in1 = nullptr; a.bias = pc.d_b; a.res = nullptr; a.out = out;
     a.N = n; a.H = h; a.W = w; a.Cout = pc.cout;
@@ -370,6 +413,20 @@ struct PwcRunner {
       hipError_t e = launch_conv_dma(a, st, 1);
       if (e != hipSuccess && rc == 0) { rc = pfail(ctx, FISR_EHIP, name + " (lds-dma): " + hipGetErrorString(e)); return; }
       hipLaunchKernelGGL(pwc_deconv_combine_kernel<TE>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, out, out_cs, out_co, n, h, w);
+      check(name.c_str());
+      return;
+    }
+    if (!HALF && std::is_same<TI, float>::value && pd.d_wp && in_cs % 4 == 0 && in_co % 4 == 0) {
+      // wide input, fp32 engines: the 16 taps x 2 outputs as a pointwise map (the input is read once), then the 2x2 gather
+      const size_t keep = ar.off;
+      float* P = falloc((size_t)n * h * w * 32);
+      ar.off = keep;
+      if (rc || ar.dry) return;
+      PointwiseArgs pa;
+      pa.in = (const float*)in; pa.in_cs = in_cs; pa.in_co = in_co; pa.Cin = pd.cin4; pa.w = pd.d_wp; pa.out = P; pa.npix = (size_t)n * h * w;
+      hipLaunchKernelGGL(pwc_pointwise_f32_kernel<32>, dim3((unsigned)((pa.npix + PW_PX - 1) / PW_PX)), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL(pwc_deconv_combine_kernel<float>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, (float*)out, out_cs,
+                         out_co, n, h, w);
       check(name.c_str());
       return;
     }
@@ -560,12 +617,14 @@ static void pwc_release_packed(fisr_pwc* c) {
     PwcConv& pc = kv.second;
     if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd);
     if (pc.d_wu4) (void)hipFree(pc.d_wu4);
+    if (pc.d_wp) (void)hipFree(pc.d_wp);
     delete pc.w1a; pc.w1a = nullptr;
     if (pc.dw.d_w) (void)hipFree(pc.dw.d_w); if (pc.dw.d_b) (void)hipFree(pc.dw.d_b);
   }
   for (auto& kv : c->deconvs) {
     if (kv.second.d_w) (void)hipFree(kv.second.d_w); if (kv.second.d_b) (void)hipFree(kv.second.d_b);
     if (kv.second.d_wd) (void)hipFree(kv.second.d_wd); if (kv.second.d_bz) (void)hipFree(kv.second.d_bz);
+    if (kv.second.d_wp) (void)hipFree(kv.second.d_wp);
   }
   c->convs.clear(); c->deconvs.clear();
 }
@@ -743,7 +802,8 @@ int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, 
 // of a buffer with pixel stride out_cs.  w_host: TF HWIO [3,3,ci,cout]; chmap (nullable = identity, then ci == cin_buf):
 // buffer channel, relative to in_co, of TF input channel j (the dense blocks' padded channel groups).  route 0: the
 // network's own choice, 1: generic implicit GEMM, 2: fp32 Winograd F(2x2), 3: FISRnet's direct kernel, 4: fp16 LDS-DMA kernel, 5: fp32
-// Winograd F(4x4) (FISR_PREC_F32W4 only) (2 - 5: error if the layer is not eligible).  Returns the route taken (1 .. 5) or a negative error.
+// Winograd F(4x4) (FISR_PREC_F32W4 only), 6: fp32 pointwise map + 9-tap gather (two output channels, no activation, cin_buf % 32 == 0)
+// (2 - 6: error if the layer is not eligible).  Returns the route taken (1 .. 6) or a negative error.
 int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
                      const int* chmap, void* out, int out_f32, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
                      int stride, int dil, float slope, int route, int precision, void* stream) {
@@ -765,14 +825,24 @@ int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const fl
   for (int c : m) if (c < 0 || c >= cin_buf) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: chmap entry out of range");
   int rc = pwc_pack_conv(&tmp, "op", m, cin_buf, tmp.convs["op"], route != 1);
   if (rc) { pwc_release_packed(&tmp); return rc; }
+  if (route >= 1 && route != 6 && tmp.convs["op"].d_wp) {      // (a forced other kernel: the pointwise route would win the choice)
+    (void)hipFree(tmp.convs["op"].d_wp); tmp.convs["op"].d_wp = nullptr;
+  }
   int took = 0;
   rc = with_pwc_elem(&tmp, [&](auto tag) {
     typedef decltype(tag) TE;
     PwcRunner<TE> r; r.ctx = &tmp; r.st = (hipStream_t)stream;
     took = r.conv_route("op", n, h, w, in_cs, out_cs, out_f32 != 0 && std::is_same<TE, _Float16>::value, stride, dil, slope, add != nullptr);
     if (route >= 2 && took != route) return pfail(nullptr, FISR_EINVAL, "fisr_pwc_op_conv: the requested kernel does not take this layer");
+    void* scratch = nullptr;
+    if (took == 6) {     // (the pointwise route stages its 20 tap sums per pixel in the runner's arena)
+      const size_t sbytes = (size_t)n * h * w * 20 * sizeof(float) + 512;
+      if (hipMalloc(&scratch, sbytes) != hipSuccess) return pfail(nullptr, FISR_EHIP, "fisr_pwc_op_conv: hipMalloc");
+      r.ar.base = (char*)scratch; r.ar.cap = sbytes;
+    }
     r.conv("op", (const TE*)in, in_cs, in_co, out, out_f32 != 0, out_cs, out_co, n, h, w, stride, dil, slope, add, add_cs, add_co);
     hipError_t e = hipStreamSynchronize(r.st);
+    if (scratch) (void)hipFree(scratch);
     if (r.rc) return r.rc;
     return e != hipSuccess ? pfail(nullptr, FISR_EHIP, std::string("fisr_pwc_op_conv: ") + hipGetErrorString(e)) : 0;
   });

@@ -240,6 +240,128 @@ __global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float*
   }
 }
 
+// ---- fp32 engine: the layers with TWO output channels (the flow heads predict_flow/flow{l}, the context network's dc_conv{l}7, the
+// up_feat deconvolutions) as a pointwise map + a gather ----
+// out[p][o] = sum_tap sum_c x[p + tap][c] w[tap][c][o] = sum_tap T[p + tap][tap][o] with T[q][tap][o] = sum_c x[q][c] w[tap][c][o]:
+// T is a 1x1 convolution to 9 x 2 (3x3 conv) or 16 x 2 (4x4 stride-2 deconvolution) channels -- it reads every input pixel exactly ONCE,
+// in whole 128-byte pieces, no halo -- and the taps are gathered from the 80- / 128-byte records of T by a second, tiny kernel.  These
+// layers read 450 - 670 channels per pixel to produce 2: they are bound by that read (9.6 GB for the level-2 flow head of a 5-frame
+// stack), which the 16-row matrix kernel (14 of 16 MFMA rows padding: compute-bound on padded work, 5.2 ms), the eight-lanes-per-
+// output-pixel deconvolution (4.3 ms for 2.4 GB) and the 64-wide generic kernel (dc_conv7: 2.3 ms for 0.5 GB) all missed by 2.5 - 8 x.
+// Arithmetic: T^T [32 x pixels] = W^T [32 x Cin] * X^T [Cin x pixels] on v_mfma_f32_32x32x2_f32 -- the weights are the ROW operand (one
+// register per K step, fetched once per 32-channel chunk and wave with four coalesced 16-byte loads of a host-packed array), the pixels
+// the columns: lane (n, half) reads the 16-byte pieces 2 s + half of its own pixel's 144-byte LDS record (conflict-free) and holds 16
+// sums of that pixel, four consecutive output channels per register quad -> 16-byte stores.  (A first version on the vector ALU with
+// the weights in scalar registers, as head_conv.h has them, ran 25 k cycles per chunk: 46 - 74 KB of weights do not fit the 16 KB
+// scalar cache, every s_load went to L2 with a handful in flight.)
+struct PointwiseArgs {
+  const float* in; int in_cs, in_co, Cin;    // channels [in_co, in_co + Cin) of an [npix, in_cs] buffer; Cin % 32 == 0, in_co % 4 == 0, in_cs % 4 == 0
+  const float* w;                            // pack_pointwise(): [Cin / 32][4][64 lanes][4]
+  float* out;                                // [npix][NJ]
+  size_t npix;
+};
+constexpr int PW_PX = 256, PW_CH = 32, PW_REC = PW_CH * 4 + 16;
+
+// w[c][j], j < nj <= 32 -> the kernel's row-operand order: K step (chunk, s, e) pairs channel chunk * 32 + 8 s + 4 half + e with lane (j, half)
+inline void pack_pointwise(const float* w, int cin, int nj, std::vector<float>& out) {
+  out.assign((size_t)cin * 32, 0.f);
+  for (int c = 0; c < cin; ++c)
+    for (int j = 0; j < nj; ++j) {
+      const int chunk = c / 32, cc = c % 32, s_ = cc / 8, half = (cc % 8) / 4, e = cc % 4;
+      out[(((size_t)chunk * 4 + s_) * 64 + half * 32 + j) * 4 + e] = w[(size_t)c * nj + j];
+    }
+}
+
+template <int NJ>      // stored channels per pixel: 20 (3x3: 9 taps x 2, 2 padding) or 32 (4x4 deconvolution: 16 taps x 2)
+__global__ __launch_bounds__(256) void pwc_pointwise_f32_kernel(const PointwiseArgs p) {
+  __shared__ __attribute__((aligned(16))) char hs[PW_PX * PW_REC];
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, half = lane >> 5;
+  const size_t p0 = (size_t)blockIdx.x * PW_PX;
+  f32x16 acc[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[g][k] = 0.f;
+  // loader: unit u = tid + 256 * i -> pixel u / 8 of the tile, 16-byte slot u % 8: eight consecutive lanes fetch one 128-byte piece
+  constexpr int NU = PW_PX * (PW_CH / 4) / 256;
+  const int slot = tid & 7;
+  const float* src[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const size_t px = p0 + (tid >> 3) + 32 * i;
+    src[i] = px < p.npix ? p.in + px * (size_t)p.in_cs + p.in_co + 4 * slot : nullptr;
+  }
+  f32x4 r[NU], wr[4];
+  auto load = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      r[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (src[i]) r[i] = *reinterpret_cast<const f32x4*>(src[i] + c0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) wr[s_] = *reinterpret_cast<const f32x4*>(p.w + (((size_t)(c0 / PW_CH) * 4 + s_) * 64 + lane) * 4);
+  };
+  load(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += PW_CH) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(hs + ((tid >> 3) + 32 * i) * PW_REC + slot * 16) = r[i];
+    f32x4 wc[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) wc[s_] = wr[s_];
+    __syncthreads();
+    if (c0 + PW_CH < p.Cin) load(c0 + PW_CH);               // the next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const char* rec = hs + (wave * 64 + g * 32 + n) * PW_REC + half * 16;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(rec + s_ * 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[s_][e], x[e], acc[g], 0, 0, 0);
+      }
+    }
+  }
+  // D[i][j]: column j = lane % 32 (the pixel), rows i = 8 (k / 4) + 4 half + k % 4 in register k
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const size_t px = p0 + wave * 64 + g * 32 + n;
+    if (px >= p.npix) continue;
+    float* ob = p.out + px * (size_t)NJ;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (8 * q + 4 * half < NJ) *reinterpret_cast<f32x4*>(ob + 8 * q + 4 * half) = f32x4{acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]};
+  }
+}
+
+// the nine taps of a 3x3 'same' convolution to two channels, gathered from T [N, H, W, 20] (channel (ky * 3 + kx) * 2 + o; 18, 19:
+// padding), + bias (+ add): tf.layers.conv2d without activation (model_pwcnet.py:1447, :1519-1521)
+__global__ void pwc_conv3_combine_kernel(const float* __restrict__ T, const float* __restrict__ bias, const float* __restrict__ add, int add_cs,
+                                         int add_co, float* __restrict__ out, int out_cs, int out_co, int N, int H, int W) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const size_t total = (size_t)N * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = x + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const f2 q = *reinterpret_cast<const f2*>(T + (i + (size_t)((ky - 1) * W + (kx - 1))) * 20 + (ky * 3 + kx) * 2);
+        a0 += q.x; a1 += q.y;
+      }
+    }
+    a0 += bias[0]; a1 += bias[1];
+    if (add) { a0 += add[i * add_cs + add_co]; a1 += add[i * add_cs + add_co + 1]; }
+    out[i * out_cs + out_co] = a0; out[i * out_cs + out_co + 1] = a1;
+  }
+}
+
 // zero the channel range [c0, c0 + nc) of every pixel (the padding channels of a decoder buffer: everything else is written
 // before it is read, so a memset of the whole 608-channel buffer -- 5 GB at level 2 of a 5-frame stack -- is not needed)
 template <typename TE>

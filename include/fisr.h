@@ -278,8 +278,10 @@ FISR_API int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, i
  * linear) (+ add) of model_pwcnet.py:1092-1097, 1426-1449, 1506-1521 on the channel range [in_co, in_co + cin_buf) of a buffer
  * with pixel stride in_cs, written to the range [out_co, out_co + cout) of a buffer with pixel stride out_cs; w_host TF HWIO
  * [3,3,ci,cout]; chmap (nullable = identity): buffer channel, relative to in_co, of TF input channel j.  route 0 = the
- * network's own choice, 1 = generic implicit GEMM, 2 = persistent fp32 Winograd kernel, 3 = FISRnet's direct kernel, 4 = its
- * fp16 LDS-DMA kernel (2 - 4: error if the layer is not eligible).  Returns the route taken (1..4) or a negative error.
+ * network's own choice, 1 = generic implicit GEMM, 2 = persistent fp32 Winograd kernel F(2x2), 3 = FISRnet's direct kernel, 4 = its
+ * fp16 LDS-DMA kernel, 5 = fp32 Winograd F(4x4) (FISR_PREC_F32W4), 6 = fp32 pointwise map to tap x output channels + 9-tap gather
+ * (two output channels, linear, cin_buf % 32 == 0: the flow heads and dc_conv7) (2 - 6: error if the layer is not eligible).
+ * Returns the route taken (1..6) or a negative error.
  * Synchronises the stream.
  * fisr_pwc_op_deconv = tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196), w_host [4,4,2,ci];
  * fisr_pwc_op_costvol = core_costvol.cost_volume + leaky relu (:1277), 81 channels; fisr_pwc_op_warp = core_warp.dense_image_warp

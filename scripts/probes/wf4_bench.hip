@@ -72,11 +72,14 @@ int main(int argc, char** argv) {
   while (pos < shapes.size()) {
     size_t e = shapes.find(';', pos);
     if (e == std::string::npos) e = shapes.size();
-    int n, h, w, ci, co, fl, rs;
-    if (sscanf(shapes.substr(pos, e - pos).c_str(), "%d,%d,%d,%d,%d,%d,%d", &n, &h, &w, &ci, &co, &fl, &rs) != 7) break;
+    int n, h, w, ci, co, fl, rs, ics = 0, ocs = 0, dil = 1;
+    // (optional: pixel stride of the input buffer, of the output buffer (channels), dilation -> the GENERAL instantiation; timing only)
+    if (sscanf(shapes.substr(pos, e - pos).c_str(), "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", &n, &h, &w, &ci, &co, &fl, &rs, &ics, &ocs, &dil) < 7) break;
+    if (ics < ci) ics = ci;
+    if (ocs < co) ocs = co;
     pos = e + 1;
     const bool ups = fl & 8;            // flags bit 3: the input is the half-resolution map (fused x2 bilinear)
-    const size_t in_e = (size_t)n * h * w * ci / (ups ? 4 : 1), out_e = (size_t)n * h * w * co;
+    const size_t in_e = (size_t)n * h * w * ics / (ups ? 4 : 1), out_e = (size_t)n * h * w * ocs;
     std::vector<float> hw((size_t)9 * ci * co), hb(co), hin(in_e), hres(rs ? out_e : 0);
     uint32_t st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((int)(st >> 9) % 2001 - 1000) * 1e-3f; };
@@ -97,7 +100,7 @@ int main(int argc, char** argv) {
     memset(&a, 0, sizeof a);
     a.in0 = d_in; a.wpk = d_wp; a.bias = d_b; a.res = d_res; a.out = d_out;
     a.C0 = ci; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = co; a.CoutPad = co;
-    a.in0_cs = ci; a.rec_cs = co; a.dil = 1;
+    a.in0_cs = ics; a.rec_cs = ocs; a.dil = dil;
     a.relu_in = fl & 1; a.relu_out = (fl >> 1) & 1; a.d2s = 0; a.ups = ups;
     const int items = ((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n * (co / F4_BN);
     unsigned long long* d_tr;

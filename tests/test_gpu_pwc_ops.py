@@ -209,11 +209,15 @@ def test_generic_kernel_residual_add_and_dilation_vs_oracle():
     flow = (rng.standard_normal((1, h, wd, 4)) * 2).astype(np.float32)
     ob = torch.zeros((1, h, wd, 4), dtype=torch.float32, device="cuda")
     xb, fb = torch.from_numpy(x).cuda(), torch.from_numpy(flow).cuda()
-    took = _run_conv(xb, 0, cin, w, b, None, ob, 0, 1, h, wd, 1, 1, 1.0, 0, add_buf=fb)
-    assert took == 1
     exp = _oracle_conv(x, w, b, 1, 1, 1.0, add=flow[..., :2])
-    err = np.abs(ob.cpu().numpy()[..., :2] - exp).max()
-    assert err < 2e-5, err
+    for route, expect in ((1, 1), (0, 6)):       # the generic kernel forced; the engine's own choice (r04): pointwise map + gather
+        ob.zero_()
+        took = _run_conv(xb, 0, cin, w, b, None, ob, 0, 1, h, wd, 1, 1, 1.0, route, add_buf=fb)
+        assert took == expect
+        err = np.abs(ob.cpu().numpy()[..., :2] - exp).max()
+        print(f"dc_conv7 + flow, route {took}: max|err| {err:.2e}")
+        assert err < 2e-5, err
+        assert not ob.cpu().numpy()[..., 2:].any()
     w2 = (rng.standard_normal((3, 3, cin, 64)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
     b2 = (rng.standard_normal(64) * 0.05).astype(np.float32)
     ob2 = torch.zeros((1, h, wd, 64), dtype=torch.float32, device="cuda")
@@ -237,13 +241,39 @@ def test_flow_head_direct_kernel_vs_oracle():
     b = (rng.standard_normal(2) * 0.05).astype(np.float32)
     ob = torch.zeros((1, h, wd, 4), dtype=torch.float32, device="cuda")
     xb = torch.from_numpy(x).cuda()
-    took = _run_conv(xb, 0, cin_buf, w, b, chmap, ob, 0, 1, h, wd, 1, 1, 1.0, 0)
-    assert took == 3
     exp = _oracle_conv(x[..., chmap], w, b, 1, 1, 1.0)
-    got = ob.cpu().numpy()
-    err = np.abs(got[..., :2] - exp).max()
-    print(f"flow head on the direct kernel: max|err| {err:.2e}")
-    assert err < 2e-5 and not got[..., 2:].any()
+    for route, expect in ((3, 3), (0, 6)):       # the direct kernel forced; the engine's own choice (r04): pointwise map + gather
+        ob.zero_()
+        took = _run_conv(xb, 0, cin_buf, w, b, chmap, ob, 0, 1, h, wd, 1, 1, 1.0, route)
+        assert took == expect
+        got = ob.cpu().numpy()
+        err = np.abs(got[..., :2] - exp).max()
+        print(f"flow head, route {took}: max|err| {err:.2e}")
+        assert err < 2e-5 and not got[..., 2:].any()
+
+
+@pytest.mark.parametrize("shape", [(2, 67, 119), (1, 9, 13), (3, 16, 16)])
+def test_pointwise_two_channel_layers_ragged_sizes_vs_oracle(shape):
+    """pwc_pointwise_f32_kernel<20> + pwc_conv3_combine_kernel (route 6) on pixel counts that are not multiples of the 256-pixel
+    tile, a channel range in the middle of a wider buffer, batch > 1 (the gather must not cross image borders), with and without
+    the added flow."""
+    n, h, wd = shape
+    rng = np.random.default_rng(n * 1000 + h)
+    cin_buf, in_co, in_cs = 64, 32, 128
+    x = (rng.standard_normal((n, h, wd, in_cs)) * 0.5).astype(np.float32)
+    chmap = [c for c in range(cin_buf) if c % 7 != 3]
+    w = (rng.standard_normal((3, 3, len(chmap), 2)) * 0.05).astype(np.float32)
+    b = (rng.standard_normal(2) * 0.05).astype(np.float32)
+    flow = (rng.standard_normal((n, h, wd, 4)) * 2).astype(np.float32)
+    xb, fb = torch.from_numpy(x).cuda(), torch.from_numpy(flow).cuda()
+    xin = x[..., in_co:in_co + cin_buf][..., chmap]
+    for add in (None, fb):
+        ob = torch.zeros((n, h, wd, 4), dtype=torch.float32, device="cuda")
+        took = _run_conv(xb, in_co, cin_buf, w, b, chmap, ob, 0, n, h, wd, 1, 1, 1.0, 6, add_buf=add)
+        assert took == 6
+        exp = _oracle_conv(xin, w, b, 1, 1, 1.0, add=None if add is None else flow[..., :2])
+        err = np.abs(ob.cpu().numpy()[..., :2] - exp).max()
+        assert err < 2e-5, (shape, err)
 
 
 @pytest.mark.parametrize("shape", [(136, 240), (67, 119)])
