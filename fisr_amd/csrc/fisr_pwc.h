@@ -425,7 +425,7 @@ struct PwcRunner {
       PointwiseArgs pa;
       pa.in = (const float*)in; pa.in_cs = in_cs; pa.in_co = in_co; pa.Cin = pd.cin4; pa.w = pd.d_wp; pa.out = P; pa.npix = (size_t)n * h * w;
       hipLaunchKernelGGL(pwc_pointwise_f32_kernel<32>, dim3((unsigned)((pa.npix + PW_PX - 1) / PW_PX)), dim3(256), 0, st, pa);
-      hipLaunchKernelGGL(pwc_deconv_combine_kernel<float>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, (float*)out, out_cs,
+      hipLaunchKernelGGL((pwc_deconv_combine_kernel<float, true>), dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, (float*)out, out_cs,
                          out_co, n, h, w);
       check(name.c_str());
       return;

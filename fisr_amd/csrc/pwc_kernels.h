@@ -215,7 +215,7 @@ __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_c
 // only non-zero tap is the centre on the LDS-DMA kernel (conv3x3_dma.h), so the matrix pipe shares every weight fragment among 32
 // pixels -- and this kernel gathers the four taps that reach an output pixel: out[2i + k - 1] += P[i][k].  (Eight lanes per output
 // pixel re-read the 78 KB of weights from L2 for every pixel: 4.1 ms on the 608-channel level-2 buffer of a 5-frame stack.)
-template <typename TE>
+template <typename TE, bool PLANAR = false>      // PLANAR: P [tap][N, H, W][2] (the fp32 pointwise kernel) instead of [N, H, W][32]
 __global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float* __restrict__ bias, TE* __restrict__ out, int out_cs, int out_co,
                                           int N, int H, int W) {
   const int OH = 2 * H, OW = 2 * W;
@@ -231,7 +231,8 @@ __global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float*
       for (int tx = 0; tx < 2; ++tx) {
         const int kx = ((ox + 1) & 1) + 2 * tx, ix = (ox + 1 - kx) / 2;
         if ((ox + 1 - kx) < 0 || ix >= W) continue;
-        const TE* q = P + ((size_t)(n * H + iy) * W + ix) * 32 + (ky * 4 + kx) * 2;
+        const TE* q = PLANAR ? P + ((size_t)(ky * 4 + kx) * N * H * W + (size_t)(n * H + iy) * W + ix) * 2
+                             : P + ((size_t)(n * H + iy) * W + ix) * 32 + (ky * 4 + kx) * 2;
         a0 += (float)q[0]; a1 += (float)q[1];
       }
     }
@@ -257,7 +258,7 @@ __global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float*
 struct PointwiseArgs {
   const float* in; int in_cs, in_co, Cin;    // channels [in_co, in_co + Cin) of an [npix, in_cs] buffer; Cin % 32 == 0, in_co % 4 == 0, in_cs % 4 == 0
   const float* w;                            // pack_pointwise(): [Cin / 32][4][64 lanes][4]
-  float* out;                                // [npix][NJ]
+  float* out;                                // [NJ / 2 taps][npix][2]
   size_t npix;
 };
 constexpr int PW_PX = 256, PW_CH = 32, PW_REC = PW_CH * 4 + 16;
@@ -276,6 +277,7 @@ template <int NJ>      // stored channels per pixel: 20 (3x3: 9 taps x 2, 2 padd
 __global__ __launch_bounds__(256) void pwc_pointwise_f32_kernel(const PointwiseArgs p) {
   __shared__ __attribute__((aligned(16))) char hs[PW_PX * PW_REC];
   typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, half = lane >> 5;
   const size_t p0 = (size_t)blockIdx.x * PW_PX;
   f32x16 acc[2];
@@ -323,19 +325,23 @@ __global__ __launch_bounds__(256) void pwc_pointwise_f32_kernel(const PointwiseA
       }
     }
   }
-  // D[i][j]: column j = lane % 32 (the pixel), rows i = 8 (k / 4) + 4 half + k % 4 in register k
+  // D[i][j]: column j = lane % 32 (the pixel), rows i = 8 (k / 4) + 4 half + k % 4 in register k.  Stored PLANAR -- out[i / 2][pixel][i % 2],
+  // one plane of output pairs per tap -- so that 32 lanes write 256 contiguous bytes and the gather kernels read whole lines
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const size_t px = p0 + wave * 64 + g * 32 + n;
     if (px >= p.npix) continue;
-    float* ob = p.out + px * (size_t)NJ;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (8 * q + 4 * half < NJ) *reinterpret_cast<f32x4*>(ob + 8 * q + 4 * half) = f32x4{acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]};
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int tap = (8 * q + 4 * half) / 2 + t2;
+        if (2 * tap < NJ) *reinterpret_cast<f2*>(p.out + ((size_t)tap * p.npix + px) * 2) = f2{acc[g][4 * q + 2 * t2], acc[g][4 * q + 2 * t2 + 1]};
+      }
   }
 }
 
-// the nine taps of a 3x3 'same' convolution to two channels, gathered from T [N, H, W, 20] (channel (ky * 3 + kx) * 2 + o; 18, 19:
+// the nine taps of a 3x3 'same' convolution to two channels, gathered from the planes T [tap = ky * 3 + kx][N, H, W][2] (a tenth plane is
 // padding), + bias (+ add): tf.layers.conv2d without activation (model_pwcnet.py:1447, :1519-1521)
 __global__ void pwc_conv3_combine_kernel(const float* __restrict__ T, const float* __restrict__ bias, const float* __restrict__ add, int add_cs,
                                          int add_co, float* __restrict__ out, int out_cs, int out_co, int N, int H, int W) {
@@ -352,7 +358,7 @@ __global__ void pwc_conv3_combine_kernel(const float* __restrict__ T, const floa
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = x + kx - 1;
         if (ix < 0 || ix >= W) continue;
-        const f2 q = *reinterpret_cast<const f2*>(T + (i + (size_t)((ky - 1) * W + (kx - 1))) * 20 + (ky * 3 + kx) * 2);
+        const f2 q = *reinterpret_cast<const f2*>(T + ((size_t)(ky * 3 + kx) * total + i + (size_t)((ky - 1) * W + (kx - 1))) * 2);
         a0 += q.x; a1 += q.y;
       }
     }
