@@ -109,7 +109,18 @@ constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; 
 #ifndef FISR_F4_U_AUX
 #define FISR_F4_U_AUX ""         // cache-policy bits of the weight copies (A/B hook: " nt", " sc1", " sc0 sc1")
 #endif
-#define FISR_F4_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen lds\n\t"
+#ifndef FISR_F4_R_AUX              // ... of the raw copies (A/B hook, -DFISR_F4_R_AUXN=1 nt, 2 sc1, 3 sc0 sc1)
+#if FISR_F4_R_AUXN == 1
+#define FISR_F4_R_AUX " nt"
+#elif FISR_F4_R_AUXN == 2
+#define FISR_F4_R_AUX " sc1"
+#elif FISR_F4_R_AUXN == 3
+#define FISR_F4_R_AUX " sc0 sc1"
+#else
+#define FISR_F4_R_AUX ""
+#endif
+#endif
+#define FISR_F4_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen" FISR_F4_R_AUX " lds\n\t"
 #define FISR_F4_COPYU(OFF, RS, SO) "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen" FISR_F4_U_AUX " lds\n\t"
 #define FISR_F4_END(KEEP)          "s_mov_b32 m0, %[" #KEEP "]"
 

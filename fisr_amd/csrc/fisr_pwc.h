@@ -294,6 +294,8 @@ struct PwcRunner {
   int conv_route(const std::string& name, int n, int h, int w, int in_cs, int out_cs, bool out_f32, int stride, int dil, float slope, bool has_add) {
     const PwcConv& pc = ctx->convs[name];
     const bool act_ok = slope == 1.f || (slope > 0.f && slope < 1.f);
+    // (both engines -- 7: conv1a -- 3 (4) -> 16 channels, stride 2, even sizes: one MFMA per tap)
+    if (pc.w1a && stride == 2 && dil == 1 && !has_add && in_cs == 4 && out_cs == 16 && !(h & 1) && !(w & 1) && slope != 1.f && act_ok) return 7;
     if (HALF) {
       if (pc.d_wd && stride == 1 && !has_add && !out_f32 && act_ok && dma_fits(h, w, pc.cin_buf, 0, in_cs, 0)) return 4;
       if (pc.have_dw && stride == 1 && dil == 1 && out_f32 && act_ok && pc.dw.nt == 0) return 3;     // (with or without the float32 add)
@@ -332,6 +334,12 @@ struct PwcRunner {
       return;
     }
     if (ar.dry) return;
+    if (route == 7) {
+      if (in_co || out_co) { rc = pfail(ctx, FISR_EINVAL, name + ": conv1a reads and writes whole buffers"); return; }
+      hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * 4)), dim3(256), 0, st, in, *pc.w1a, (TE*)out, n, h, w, slope);
+      check(name.c_str());
+      return;
+    }
     ConvArgs a;
     a.in0 = in + in_co; a.in1 = nullptr; a.bias = pc.d_b; a.res = nullptr; a.out = out;
     a.N = n; a.H = h; a.W = w; a.Cout = pc.cout;
@@ -452,14 +460,7 @@ struct PwcRunner {
       const size_t keep = ar.off;
       TE* A = ealloc(px * PWC_CH[l]); TE* B = ealloc(px * PWC_CH[l]);
       const std::string p = "pwcnet/featpyr/conv" + std::to_string(l);
-      const PwcConv& pa = ctx->convs[p + "a"];
-      if (l == 1 && pa.w1a) {
-        if (!rc && !ar.dry) {
-          hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for(px)), dim3(256), 0, st, F[0], *pa.w1a, A, nf, hh[0], ww[0], 0.1f);
-          check("conv1a");
-        }
-      } else
-        conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, false, PWC_CH[l], 0, nf, hh[l - 1], ww[l - 1], 2, 1, 0.1f);
+      conv(p + "a", F[l - 1], PWC_CH[l - 1], 0, A, false, PWC_CH[l], 0, nf, hh[l - 1], ww[l - 1], 2, 1, 0.1f);     // (l == 1: route 7)
       conv(p + "aa", A, PWC_CH[l], 0, B, false, PWC_CH[l], 0, nf, hh[l], ww[l], 1, 1, 0.1f);
       conv(p + "b", B, PWC_CH[l], 0, F[l], false, PWC_CH[l], 0, nf, hh[l], ww[l], 1, 1, 0.1f);
       (void)mark;
@@ -803,7 +804,8 @@ int fisr_pwc_flow_pair(fisr_pwc* c, const uint8_t* yuv_a, const uint8_t* yuv_b, 
 // buffer channel, relative to in_co, of TF input channel j (the dense blocks' padded channel groups).  route 0: the
 // network's own choice, 1: generic implicit GEMM, 2: fp32 Winograd F(2x2), 3: FISRnet's direct kernel, 4: fp16 LDS-DMA kernel, 5: fp32
 // Winograd F(4x4) (FISR_PREC_F32W4 only), 6: fp32 pointwise map + 9-tap gather (two output channels, no activation, cin_buf % 32 == 0)
-// (2 - 6: error if the layer is not eligible).  Returns the route taken (1 .. 6) or a negative error.
+// 7: conv1a (3 -> 16 channels in a 4-wide buffer, stride 2, even sizes)
+// (2 - 7: error if the layer is not eligible).  Returns the route taken (1 .. 7) or a negative error.
 int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const float* w_host, const float* b_host, int ci, int cout,
                      const int* chmap, void* out, int out_f32, int out_cs, int out_co, const float* add, int add_cs, int add_co, int n, int h, int w,
                      int stride, int dil, float slope, int route, int precision, void* stream) {
@@ -828,6 +830,7 @@ int fisr_pwc_op_conv(const void* in, int in_cs, int in_co, int cin_buf, const fl
   if (route >= 1 && route != 6 && tmp.convs["op"].d_wp) {      // (a forced other kernel: the pointwise route would win the choice)
     (void)hipFree(tmp.convs["op"].d_wp); tmp.convs["op"].d_wp = nullptr;
   }
+  if (route >= 1 && route != 7 && tmp.convs["op"].w1a) { delete tmp.convs["op"].w1a; tmp.convs["op"].w1a = nullptr; }
   int took = 0;
   rc = with_pwc_elem(&tmp, [&](auto tag) {
     typedef decltype(tag) TE;

@@ -378,43 +378,46 @@ __global__ void pwc_zero_channels_kernel(TE* __restrict__ buf, int cs, int c0, i
 }
 
 // conv1a of the feature pyramid (model_pwcnet.py:1092: 3 -> 16 channels, stride 2, 'same' = pad (0, 1) on the even sizes the
-// network runs on, leaky relu) on the vector ALU: [N, H, W, 4] -> [N, H/2, W/2, 16].  432 FMAs per output pixel, weights
-// [9][4][16] + bias [16] passed BY VALUE (kernel-argument memory: scalar loads, no vector load per lane and weight); the 64-wide
-// generic MFMA kernel spent 2 ms on it per 5-frame stack.
-struct Conv1aWeights { float w[9 * 64]; float bias[16]; };      // by value: kernel-argument memory, read with scalar loads
+// network runs on, leaky relu): [N, H, W, 4] -> [N, H/2, W/2, 16] on v_mfma_f32_16x16x4_f32 -- rows = the 16 output channels, columns =
+// 16 output pixels, K = the 4 channels of ONE input pixel, so a tap is one MFMA whose row operand (w[tap][k][o] at lane o + 16 k) is
+// loaded once per wave and whose column operand is channel lane / 16 of input pixel (2 ox + kx, 2 oy + ky): nine 4-byte loads and nine
+// MFMAs per 16 output pixels, the 16 sums of a pixel in four lanes' register quads -> 16-byte stores.  Weights [9][4][16] + bias [16]
+// by value.  (r03's vector-ALU version took 1.0 ms per 5-frame stack: the compiler hoisted the 592 scalar weight loads out of the
+// pixel loop and spilled them to vector lanes -- 3057 v_readlane per pixel for 150 packed FMAs; with the weights in LDS 0.82 ms, bound
+// by 108 uniform 16-byte LDS reads per pixel.)
+struct Conv1aWeights { float w[9 * 64]; float bias[16]; };      // by value: kernel-argument memory
 template <typename TE>
 __global__ __launch_bounds__(256) void pwc_conv1a_kernel(const TE* __restrict__ in, const Conv1aWeights cw, TE* __restrict__ out, int N, int H,
                                                          int W, float slope) {
-  const float* const w = cw.w;
-  const float* const bias = cw.bias;
+  const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+  float wa[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wa[t] = cw.w[t * 64 + kq * 16 + col];          // row operand: lane (o = col, k = kq)
+  f32x4 b4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b4[e] = cw.bias[4 * kq + e];                   // result register e of lane (pixel col, quad kq) = output 4 kq + e
   const int OH = H / 2, OW = W / 2;
-  const size_t total = (size_t)N * OH * OW;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((size_t)OW * OH));
-    float acc[16];
+  const size_t total = (size_t)N * OH * OW, groups = (total + 15) / 16;
+  const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t g = wave0; g < groups; g += nwaves) {
+    const size_t i = g * 16 + col;
+    const bool live = i < total;
+    const size_t ii = live ? i : total - 1;
+    const int ox = (int)(ii % OW), oy = (int)((ii / OW) % OH), n = (int)(ii / ((size_t)OW * OH));
+    float x[9];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = bias[o];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = 2 * oy + ky;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int ix = 2 * ox + kx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy < H && ix < W) v = PwcElem<TE>::ld4(in + ((size_t)(n * H + iy) * W + ix) * 4);
-        const float* wt = w + (ky * 3 + kx) * 64;
-#pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] += v.x * wt[o] + v.y * wt[16 + o] + v.z * wt[32 + o];
+        const int iy = 2 * oy + ky, ix = 2 * ox + kx;
+        x[ky * 3 + kx] = (iy < H && ix < W) ? (float)in[((size_t)(n * H + iy) * W + ix) * 4 + kq] : 0.f;
       }
-    }
-    TE* ob = out + i * 16;
+    f32x4 acc = b4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 r;
+    for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], x[t], acc, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float t = acc[4 * q + e]; r[e] = t >= 0.f ? t : t * slope; }
-      PwcElem<TE>::st4(ob + 4 * q, r);
-    }
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] >= 0.f ? acc[e] : acc[e] * slope;
+    if (live) PwcElem<TE>::st4(out + i * 16 + 4 * kq, acc);
   }
 }
 

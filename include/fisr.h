@@ -280,8 +280,9 @@ FISR_API int fisr_pwc_flow_out(const float* flow2, int FH, int FW, float* out, i
  * [3,3,ci,cout]; chmap (nullable = identity): buffer channel, relative to in_co, of TF input channel j.  route 0 = the
  * network's own choice, 1 = generic implicit GEMM, 2 = persistent fp32 Winograd kernel F(2x2), 3 = FISRnet's direct kernel, 4 = its
  * fp16 LDS-DMA kernel, 5 = fp32 Winograd F(4x4) (FISR_PREC_F32W4), 6 = fp32 pointwise map to tap x output channels + 9-tap gather
- * (two output channels, linear, cin_buf % 32 == 0: the flow heads and dc_conv7) (2 - 6: error if the layer is not eligible).
- * Returns the route taken (1..6) or a negative error.
+ * (two output channels, linear, cin_buf % 32 == 0: the flow heads and dc_conv7), 7 = conv1a (3 -> 16 channels read from a 4-wide
+ * buffer, stride 2, even sizes: one fp32 MFMA per tap) (2 - 7: error if the layer is not eligible).
+ * Returns the route taken (1..7) or a negative error.
  * Synchronises the stream.
  * fisr_pwc_op_deconv = tf.layers.conv2d_transpose(x, 2, 4, 2, 'same') (:1196), w_host [4,4,2,ci];
  * fisr_pwc_op_costvol = core_costvol.cost_volume + leaky relu (:1277), 81 channels; fisr_pwc_op_warp = core_warp.dense_image_warp

@@ -197,6 +197,30 @@ def test_stride2_generic_kernel_vs_oracle(shape):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_conv1a_mfma_kernel_vs_oracle(prec):
+    """pwc_conv1a_kernel (route 7; model_pwcnet.py:1092: 3 -> 16 channels, stride 2, leaky relu) on one fp32 MFMA per tap: a pixel count
+    that is not a multiple of the 16-pixel MFMA group, batch 3, the unused fourth channel of the input holding garbage."""
+    n, h, wd = 3, 26, 38
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((n, h, wd, 4)) * 0.5).astype(np.float32)
+    x[..., 3] = 1e3
+    w = (rng.standard_normal((3, 3, 3, 16)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(16) * 0.05).astype(np.float32)
+    dt = torch.float32 if prec == "fp32" else torch.float16
+    xb = torch.from_numpy(x).cuda().to(dt)
+    ob = torch.zeros((n, h // 2, wd // 2, 16), dtype=dt, device="cuda")
+    took = _run_conv(xb, 0, 4, w, b, None, ob, 0, n, h, wd, 2, 1, 0.1, 0, prec=prec)
+    assert took == 7
+    exp = _oracle_conv(_host(xb)[..., :3], w, b, 2, 1, 0.1)
+    err = np.abs(_host(ob) - exp).max()
+    print(f"conv1a {prec}: max|err| {err:.2e}")
+    assert err < (2e-5 if prec == "fp32" else 4e-3)
+    ob2 = torch.zeros_like(ob)
+    assert _run_conv(xb, 0, 4, w, b, None, ob2, 0, n, h, wd, 2, 1, 0.1, 1, prec=prec) == 1      # the generic kernel agrees
+    assert np.abs(_host(ob2) - _host(ob)).max() < (2e-5 if prec == "fp32" else 4e-3)
+
+
 def test_generic_kernel_residual_add_and_dilation_vs_oracle():
     """dc_conv7 (2 channels, linear, + the predicted flow: refine_flow model_pwcnet.py:1519-1521) and a dilated layer forced
     through the generic kernel (the Winograd path's fall-back), 272x480."""
