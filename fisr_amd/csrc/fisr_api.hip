@@ -476,9 +476,9 @@ hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st
   h.in = (const float*)a.in0; h.w = d_wh; h.bias = a.bias; h.out = (float*)a.out;
   h.N = a.N; h.H = a.H; h.W = a.W; h.Cin = a.C0; h.Cout = a.Cout; h.relu_in = a.relu_in; h.relu_out = a.relu_out;
   h.out_cstride = a.out_cstride; h.out_coff = a.out_coff; h.out_split = a.out_split; h.out_gap = a.out_gap;
-  const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H) * a.N;
-  if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(256), head_lds_bytes<2>(), st, h);
-  else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(256), head_lds_bytes<3>(), st, h);
+  const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + HEAD_TH - 1) / HEAD_TH) * a.N;
+  if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(HEAD_NTHR), head_lds_bytes<2>(), st, h);
+  else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(HEAD_NTHR), head_lds_bytes<3>(), st, h);
   return hipGetLastError();
 }
 

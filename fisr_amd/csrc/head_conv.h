@@ -29,25 +29,29 @@ struct HeadArgs {
 // 3 workgroups per CU) for the 3-channel head (2116 -> 1749 us), 16 channels (80-byte records, 5 workgroups per CU) for
 // the 6-channel one, whose longer FMA phases need the extra workgroups (2161 vs 2473 us with 32).
 // Both record sizes put the 16 lanes of a ds_read_b128 phase on 16 distinct bank groups.
+#ifndef FISR_HEAD_TH
+#define FISR_HEAD_TH 8            // tile height (A/B hook: 16 = 512 lanes, halo re-read 1.195 instead of 1.33, 16-channel chunks for both heads)
+#endif
+constexpr int HEAD_TH = FISR_HEAD_TH, HEAD_NTHR = 32 * HEAD_TH, HEAD_HALO_PIX = (HEAD_TH + 2) * HALO_W;
 template <int NPAIR> struct HeadCfg {
-  static constexpr int CH = NPAIR == 2 ? 32 : 16;     // channels per K chunk
+  static constexpr int CH = (NPAIR == 2 && HEAD_TH == 8) ? 32 : 16;     // channels per K chunk
   static constexpr int REC = CH * 4 + 16;             // LDS bytes per pixel record
   static constexpr int SLOTS = CH / 4;                // 16-byte slots per record
 };
 constexpr int HEAD_CH = 32;                           // the engine routes a conv here when Cin % HEAD_CH == 0
-template <int NPAIR> constexpr size_t head_lds_bytes() { return (size_t)HALO_PIX * HeadCfg<NPAIR>::REC; }
+template <int NPAIR> constexpr size_t head_lds_bytes() { return (size_t)HEAD_HALO_PIX * HeadCfg<NPAIR>::REC; }
 
 template <int NPAIR>   // output pairs: 3 (6 channels) or 2 (3 channels)
-__global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
+__global__ __launch_bounds__(HEAD_NTHR) void head_conv_f32_kernel(const HeadArgs p) {
   extern __shared__ __attribute__((aligned(16))) char hs[];
   typedef float f2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x;
-  const int tiles_x = (p.W + TILE_W - 1) / TILE_W, tiles_y = (p.H + TILE_H - 1) / TILE_H;
+  const int tiles_x = (p.W + TILE_W - 1) / TILE_W, tiles_y = (p.H + HEAD_TH - 1) / HEAD_TH;
   int t = blockIdx.x;
   const int tx_ = t % tiles_x; t /= tiles_x;
   const int ty_ = t % tiles_y;
   const int nb = t / tiles_y;
-  const int x0 = tx_ * TILE_W, y0 = ty_ * TILE_H;
+  const int x0 = tx_ * TILE_W, y0 = ty_ * HEAD_TH;
   const int px = tid & 31, py = tid >> 5;                   // this lane's pixel of the tile
   f2 acc[NPAIR];
 #pragma unroll
@@ -55,16 +59,16 @@ __global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
   // loader: unit u = tid + 256 * i -> halo pixel u / SLOTS, 16-byte slot u % SLOTS: consecutive lanes fetch the
   // contiguous bytes of one pixel's chunk
   constexpr int HCH = HeadCfg<NPAIR>::CH, HREC = HeadCfg<NPAIR>::REC, SLOTS = HeadCfg<NPAIR>::SLOTS;
-  constexpr int NU = (HALO_PIX * SLOTS + 255) / 256;
+  constexpr int NU = (HEAD_HALO_PIX * SLOTS + HEAD_NTHR - 1) / HEAD_NTHR;
   // (80-byte records: the records of a ds_write_b128 phase are spread over their block of 16 as in conv3x3.h)
   auto hp_of = [](int r) { return SLOTS == 4 ? ((r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3)) : r; };
   int src[NU];                                              // pixel index in the image, -1: padding / nothing
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
-    const int hp = hp_of(tid / SLOTS + (256 / SLOTS) * i);
+    const int hp = hp_of(tid / SLOTS + (HEAD_NTHR / SLOTS) * i);
     const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    src[i] = (hp < HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (nb * p.H + gy) * p.W + gx : -1;
+    src[i] = (hp < HEAD_HALO_PIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (nb * p.H + gy) * p.W + gx : -1;
   }
   const int slot = tid % SLOTS;
   f32x4 r[NU];
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(256) void head_conv_f32_kernel(const HeadArgs p) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      const int hp = hp_of(tid / SLOTS + (256 / SLOTS) * i);
-      if (hp < HALO_PIX) {
+      const int hp = hp_of(tid / SLOTS + (HEAD_NTHR / SLOTS) * i);
+      if (hp < HEAD_HALO_PIX) {
         f32x4 v = r[i];
         if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<f32x4*>(hs + hp * HREC + slot * 16) = v;
