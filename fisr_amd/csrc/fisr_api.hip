@@ -795,7 +795,11 @@ struct Runner {
     if (s == 1)      // (level 3: the staged variant; the strided levels read too sparsely for it)
       hipLaunchKernelGGL(prep_level_input_s1_kernel<T>, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, st, img, pred, out, (size_t)n * H * W, cpad);
     else
-      hipLaunchKernelGGL(prep_level_input_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, img, pred, out, n, H, W, s, cpad);
+      if (s == 2 || s == 4) {
+        const int spans = (W / s + 256 / s - 1) / (256 / s);
+        hipLaunchKernelGGL(prep_level_input_rows_kernel<T>, dim3(std::min(n * (H / s) * spans, 1 << 20)), dim3(256), 0, st, img, pred, out, n, H, W, s, cpad);
+      } else
+        hipLaunchKernelGGL(prep_level_input_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, img, pred, out, n, H, W, s, cpad);
     check(hipGetLastError(), "prep_level_input");
   }
 
@@ -1366,6 +1370,20 @@ int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int 
   });
   HIP_OK(nullptr, hipGetLastError());
   return 0;
+}
+
+// The input of a level's first convolution (FISRnet.py:81, 112-113, 144): img [n,h,w,29] sub-sampled by s (1 | 2 | 4: legacy BICUBIC at an
+// integer factor) ++ pred [n,h/s,w/s,9] (nullable) ++ zeros up to cpad channels, as float32 records -- the kernels Runner::prep launches
+int fisr_op_prep_level_input(const float* img, const float* pred, float* out, int n, int h, int w, int s, int cpad, void* stream) {
+  if (!img || !out || n < 1 || h < 1 || w < 1 || (s != 1 && s != 2 && s != 4) || h % s || w % s || cpad % 16 || cpad < (pred ? 38 : 29))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_prep_level_input: bad argument");
+  DeviceGuard guard(device_of(out));
+  HIP_OK(nullptr, guard.err);
+  Runner<float> r;
+  r.ctx = nullptr; r.st = (hipStream_t)stream;
+  r.prep(img, pred, out, n, h, w, s, cpad);
+  HIP_OK(nullptr, hipGetLastError());
+  return r.rc;
 }
 
 int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream) {

@@ -114,6 +114,58 @@ __global__ void prep_level_input_kernel(const float* __restrict__ img, const flo
   }
 }
 
+// s = 2 | 4 (levels 2 and 1), staged through LDS like the s = 1 kernel below (r04): a block owns 256 / s output pixels of one output row,
+// copies the 256 consecutive INPUT pixels they are sub-sampled from (one aligned span of 29.7 KB: at s = 2 every 128-byte line of it
+// holds bytes of a wanted pixel anyway) and the block's span of the prediction with 16-byte loads, then every thread assembles records
+// from LDS.  The one-thread-per-record kernel above issued 16 scalar loads per record: 0.22 of the HBM peak, 1.55 x its bytes.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_level_input_rows_kernel(const float* __restrict__ img, const float* __restrict__ pred,
+                                                                     T* __restrict__ out, int N, int H, int W, int s, int cpad) {
+  typedef Rec16<T> R16;
+  __shared__ __attribute__((aligned(16))) float s_img[256 * 29];
+  __shared__ __attribute__((aligned(16))) float s_pred[128 * 9 + 4];
+  const int tid = threadIdx.x;
+  const int oh = H / s, ow = W / s, groups = cpad / 16, span = 256 / s;       // output pixels per block
+  const int spans = (ow + span - 1) / span;
+  const int total = N * oh * spans;
+  for (int b = blockIdx.x; b < total; b += gridDim.x) {
+    const int sp = b % spans, y = (b / spans) % oh, n = b / (spans * oh);
+    const int x0 = sp * span, np = min(span, ow - x0);                          // outputs x0 .. x0 + np of row y
+    {
+      const float* g = img + (((size_t)n * H + (size_t)y * s) * W + (size_t)x0 * s) * 29;
+      const int nf = min(256, W - x0 * s) * 29, n4 = ((size_t)g & 15) == 0 ? nf >> 2 : 0;
+      for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(s_img)[j] = reinterpret_cast<const f32x4*>(g)[j];
+      for (int j = 4 * n4 + tid; j < nf; j += 256) s_img[j] = g[j];
+    }
+    const size_t opix0 = ((size_t)n * oh + y) * ow + x0;
+    if (pred != nullptr) {
+      const float* g = pred + opix0 * 9;
+      const int nf = np * 9, n4 = ((size_t)g & 15) == 0 ? nf >> 2 : 0;
+      for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(s_pred)[j] = reinterpret_cast<const f32x4*>(g)[j];
+      for (int j = 4 * n4 + tid; j < nf; j += 256) s_pred[j] = g[j];
+    }
+    __syncthreads();
+    for (int r = tid; r < np * groups; r += 256) {
+      const int pl = r / groups, g = r - pl * groups;
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int c = 16 * g + k;
+        float t = 0.f;
+        if (c < 29) t = s_img[pl * s * 29 + c];
+        else if (pred != nullptr && c < 38) t = s_pred[pl * 9 + (c - 29)];
+        v[k] = t;
+      }
+      uint4 q[R16::NV];
+      R16::encode(v, q);
+      uint4* ob = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + ((opix0 + pl) * cpad + 16 * g) * sizeof(T));
+#pragma unroll
+      for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
+    }
+    __syncthreads();
+  }
+}
+
 // The same for s = 1 (level 3: 97 % of the pixels of the three levels), staged through LDS: the 116-byte pixels of the
 // packed input and the 36-byte pixels of the prediction are not 16-byte aligned, so a thread that fetches "its" 16
 // channels issues 16 scalar loads; here a block copies the flat span of 256 pixels with aligned 16-byte loads, then

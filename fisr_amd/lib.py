@@ -23,7 +23,7 @@ EXPORTS = [
     "fisr_version", "fisr_create", "fisr_destroy", "fisr_last_error", "fisr_set_weight",
     "fisr_finalize_weights", "fisr_num_variables_set", "fisr_workspace_bytes", "fisr_forward",
     "fisr_profile_enable", "fisr_profile_reset", "fisr_profile_read", "fisr_warp", "fisr_pack_input",
-    "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_ssim_u8", "fisr_op_conv3x3", "fisr_op_conv3x3_pool", "fisr_op_maxpool2",
+    "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_ssim_u8", "fisr_op_conv3x3", "fisr_op_conv3x3_pool", "fisr_op_maxpool2", "fisr_op_prep_level_input",
     "fisr_op_upsample2", "fisr_bench_conv",
     "fisr_comm_unique_id", "fisr_comm_init", "fisr_comm_rank", "fisr_comm_size", "fisr_comm_allgather",
     "fisr_comm_sendrecv", "fisr_comm_destroy",
@@ -133,6 +133,7 @@ def lib():
                                        c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_op_maxpool2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_op_upsample2.argtypes = [vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    L.fisr_op_prep_level_input.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     L.fisr_ssim_u8.argtypes = [vp, vp, c_int, c_int, c_int, c_int, POINTER(c_double), vp]
     L.fisr_bench_conv.argtypes = [c_int] * 9 + [POINTER(c_double)]
     L.fisr_comm_unique_id.argtypes = [vp]

@@ -200,6 +200,10 @@ FISR_API int fisr_op_conv3x3_pool(const void* in0, int c0, const void* in1, int 
                          int cout, const void* res, void* out, void* pool_out, int n, int h, int w, int flags, int precision, void* stream);
 FISR_API int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
 FISR_API int fisr_op_upsample2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);
+/* The input of a level's first convolution (FISRnet.py:81, 112-113, 144): img [n,h,w,29] sub-sampled by s (1 | 2 | 4 = the legacy
+ * BICUBIC resize at an integer factor, x[:, ::s, ::s, :]) ++ pred [n,h/s,w/s,9] (nullable: level 1) ++ zeros up to cpad (% 16) channels,
+ * float32 [n,h/s,w/s,cpad]: the glue kernels of the engine's `prep` step, for bit-exact tests. */
+FISR_API int fisr_op_prep_level_input(const float* img, const float* pred, float* out, int n, int h, int w, int s, int cpad, void* stream);
 
 /* Micro-benchmark of one conv shape (diagnostics; not on the product path): runs `iters`
  * launches of the conv kernel on self-allocated buffers and returns the mean microseconds per

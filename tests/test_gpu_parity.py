@@ -944,6 +944,30 @@ def test_pack_unpack_stitch_bit_exact(net32, gold_dir):
     assert abs(sse - exp_sse) <= 1e-9 * exp_sse
 
 
+@pytest.mark.parametrize("s,shape,with_pred", [(1, (2, 6, 70), True), (2, (2, 12, 1000), True), (2, (1, 8, 520), True), (4, (3, 16, 2104), False),
+                                               (4, (1, 8, 24), False), (2, (1, 4, 6), False)])
+def test_prep_level_input_bit_exact(dev, s, shape, with_pred):
+    """The first convolution's input of a level (FISRnet.py:81, 112-113, 144): img[:, ::s, ::s] ++ pred ++ zero padding, through the
+    LDS-staged kernels (s = 1: flat spans; s = 2 | 4, r04: spans of one output row, sub-sampled in LDS) -- spans that end in the middle
+    of a row, rows shorter than a span, batch > 1."""
+    n, h, w = shape
+    rng = np.random.default_rng(s * 100 + w)
+    img = rng.standard_normal((n, h, w, 29)).astype(np.float32)
+    pred = rng.standard_normal((n, h // s, w // s, 9)).astype(np.float32) if with_pred else None
+    cpad = 48 if with_pred else 32
+    di = torch.from_numpy(img).cuda()
+    dp = torch.from_numpy(pred).cuda() if with_pred else None
+    out = torch.full((n, h // s, w // s, cpad), 7.0, dtype=torch.float32, device="cuda")
+    flib.check(flib.lib().fisr_op_prep_level_input(ctypes.c_void_p(di.data_ptr()), ctypes.c_void_p(dp.data_ptr()) if with_pred else None,
+                                                   ctypes.c_void_p(out.data_ptr()), n, h, w, s, cpad, _stream()))
+    torch.cuda.synchronize()
+    exp = np.zeros((n, h // s, w // s, cpad), np.float32)
+    exp[..., :29] = img[:, ::s, ::s]
+    if with_pred:
+        exp[..., 29:38] = pred
+    assert np.array_equal(out.cpu().numpy(), exp)
+
+
 @pytest.mark.parametrize("h,w", [(33, 47), (17, 300), (64, 96), (1, 5)])
 def test_pack_unpack_prep_ragged_sizes_bit_exact(net32, h, w):
     """The LDS-staged glue kernels (a block moves a 256-pixel span with aligned 16-byte vectors) on sizes whose spans end
