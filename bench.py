@@ -202,13 +202,21 @@ def _pmc_table_checked(running_library):
     return pmc, meta
 
 
-def _pmc_same_population(entry, meta, launches_per_step):
-    """the PMC run averaged `dispatches` launches over `steps_per_pass` steps: the same kernel NAME with another launch population
-    (r03: the two maxpool2 launches the fp32 engine has left vs the 18 of the other engines) is not this kernel's traffic"""
-    steps = meta.get("steps_per_pass") or 0
-    if not steps or not entry.get("dispatches"):
+def _pmc_same_population(entry, passes, launches_per_step):
+    """the PMC run averaged `dispatches` launches of this kernel NAME; it is this engine's kernel population only if that is `passes` x
+    this run's launches per step, `passes` = the whole number of forward passes the PMC run made with this engine, taken from the
+    engine's dominant kernel (r03: the two maxpool2 launches the fp32 engine has left vs the 18 of the other engines in the same table)"""
+    if not passes or not entry.get("dispatches") or not launches_per_step:
         return False
-    return abs(entry["dispatches"] / steps - launches_per_step) <= 0.1 * max(launches_per_step, 1)
+    return abs(entry["dispatches"] / launches_per_step - passes) <= 0.05
+
+
+def _pmc_passes(entry, launches_per_step):
+    """whole number of forward passes behind a table entry of an engine's dominant kernel, or 0 when it is not a whole number"""
+    if not entry or not entry.get("dispatches") or not launches_per_step:
+        return 0
+    r = entry["dispatches"] / launches_per_step
+    return round(r) if r >= 0.95 and abs(r - round(r)) <= 0.05 else 0
 
 
 def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, rank, weight_bytes):
@@ -266,10 +274,11 @@ def _pmc_key(name):
         return "conv3x3_dma_f16_kernel<false>"
     if name.startswith("conv3x3_wf4"):
         if "res+pool" in name:
-            return "conv3x3_wf4_kernel<false, true, true, false>"
+            return "conv3x3_wf4_kernel<false, true, true, false, false>"
         if "up2" in name:
-            return "conv3x3_wf4_kernel<false, false, false, true>"
-        return "conv3x3_wf4_kernel<%s, %s, false, false>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
+            return "conv3x3_wf4_kernel<false, false, false, true, false>"
+        # (5th parameter: the GENERAL instantiation of the flow network)
+        return "conv3x3_wf4_kernel<%s, %s, false, false, false>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
     tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
     if name.startswith("conv3x3_wino"):
         return "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
@@ -326,14 +335,24 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     lps = {p["name"]: p["launches"] / max(reps, 1) for p in prof}          # launches per step of this run, per kernel
     dropped = []
 
+    def pmc_raw(key):
+        hits = [v for k, v in pmc.items() if k.startswith(key)]
+        return max(hits, key=lambda v: v.get("dispatches", 0)) if hits else None
+
+    # forward passes the PMC run made with THIS engine: from the engine's dominant conv kernel
+    dom_name = max(convs, key=lambda p: p["ms"])["name"]
+    try:
+        pmc_passes = _pmc_passes(pmc_raw(_pmc_key(dom_name)), lps.get(dom_name, 0))
+    except (KeyError, IndexError, ValueError):
+        pmc_passes = 0
+
     def pmc_entry(key, name):
         """the PMC table's entry for kernel `name` (table key prefix `key`), or None (and a note) when its launch population differs"""
-        hits = [v for k, v in pmc.items() if k.startswith(key)]
-        if not hits:
+        e = pmc_raw(key)
+        if e is None:
             return None
-        e = max(hits, key=lambda v: v.get("dispatches", 0))
-        if not _pmc_same_population(e, pmc_meta, lps.get(name, 0)):
-            dropped.append("%s: %.1f launches per step in the PMC run, %.1f here" % (name, e.get("dispatches", 0) / max(pmc_meta.get("steps_per_pass") or 1, 1), lps.get(name, 0)))
+        if not _pmc_same_population(e, pmc_passes, lps.get(name, 0)):
+            dropped.append("%s: %s dispatches in the PMC run, %.1f launches per step here, %s passes of this engine" % (name, e.get("dispatches", 0), lps.get(name, 0), pmc_passes or "no whole number of"))
             return None
         return e
 
@@ -857,8 +876,13 @@ def main():
 
     for _ in range(args.warmup):
         wl.step(net)
+    # (the process's FIRST timing event costs tens of milliseconds -- the runtime sets up its profiling signals; r04: it sat inside
+    #  the timed region and added ~45 ms to it, 9 ms per step at --steps 5.  Untimed work, like the warmup steps.)
+    ev_w0, ev_w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_w0.record(); ev_w1.record()
     drain()
     sync()
+    _ = ev_w0.elapsed_time(ev_w1)
     if wl.gather is not None:
         wl.gather.gather_ms = 0.0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -970,6 +994,9 @@ def main():
             "metric": "2K->4K FISR output frames/sec per node (unique frames of 5-frame 1080p stacks)",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            # (the same steps by HIP events on this rank's compute stream: what the GPU spent, beside the wall clock `value` is built from)
+            "ms_per_step_hip_events": round(ev0.elapsed_time(ev1) / args.steps, 3),
+            "host_enqueue_ms_per_step": round(t_local / args.steps * 1e3, 3),     # (host time to enqueue the steps: far below ms_per_step unless the host is the bottleneck)
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {"workload": f"cfg2: 5-frame 1080x1920 stack -> 3 windows x {patch[0]}x{patch[1]} tiles of "
@@ -1005,4 +1032,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if os.environ.get("FISR_BENCH_CPROFILE"):
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        try:
+            pr.runcall(main)
+        finally:
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
+    else:
+        main()

@@ -262,3 +262,21 @@ def test_code_object_has_no_store_data_hazard():
     bad = "_Zfoo:\n\tbuffer_store_dwordx4 v[4:7], v1, s[0:3], s9 offen\n\tv_mul_f32_e32 v6, v2, v3\n\ts_endpgm\n"
     ok = "_Zfoo:\n\tbuffer_store_dwordx4 v[4:7], v1, s[0:3], s9 offen\n\ts_nop 0\n\tv_mul_f32_e32 v6, v2, v3\n\ts_endpgm\n"
     assert len(m.scan(bad)) == 1 and not m.scan(ok)
+
+
+def test_bench_counter_fields_need_the_same_launch_population():
+    """bench.py takes a counter-derived field from profiles/pmc_traffic.json only when the table's entry is THIS engine's launch
+    population: dispatches = a whole number of forward passes (read off the engine's dominant kernel) x this run's launches per step.
+    A kernel name shared with other engines of the same PMC run (r03: maxpool2, the F(2x2) kernel) fails that and is dropped."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b._pmc_passes({"dispatches": 188}, 47.0) == 4                      # the fp32 engine's dominant kernel: four passes
+    assert b._pmc_passes({"dispatches": 169}, 4.0) == 0                       # 42.25: another engine's launches are in there
+    assert b._pmc_passes({}, 47.0) == 0 and b._pmc_passes({"dispatches": 10}, 0) == 0
+    assert b._pmc_same_population({"dispatches": 132}, 4, 33.0)               # residual instantiation: 33 per step x 4
+    assert not b._pmc_same_population({"dispatches": 58}, 4, 1.0)             # maxpool2 of all engines against the one launch left here
+    assert not b._pmc_same_population({"dispatches": 132}, 0, 33.0)
+    assert b._pmc_key("conv3x3_wf4<f32w4,relu_in,nores>") == "conv3x3_wf4_kernel<true, false, false, false, false>"
+    assert b._pmc_key("conv3x3_wf4<f32w4,plain,res+pool>") == "conv3x3_wf4_kernel<false, true, true, false, false>"
