@@ -70,7 +70,7 @@ DTYPE = {"fp32": "f32", "fp32d": "f32", "fp32w": "f32", "fp32w4": "f32",
          "fp16": "f16 (f32 accumulate)",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
          "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)",
-         "mixed": "mixed (f16f8 at the full and half resolution of level 3 -- first two encoder levels, last two decoder levels, heads --, f16 elsewhere; f32 accumulate)"}
+         "mixed": "mixed (f16f8 at the full and half resolution of level 3 -- first two encoder levels, last two decoder levels, the SR head --, f16 elsewhere incl. the FI-SR head, r04; f32 accumulate)"}
 UNIQUE_PER_STACK = 7                # 3 windows x 3 frames, overlaps counted once (FISRnet.py:913-920)
 
 

@@ -203,7 +203,7 @@ inline bool prec_ok(int precision) {
 // full-size window --, this plan by 0.004 dB.)
 inline bool mixed_layer_is_hi(const std::string& name) {
   static const char* const hi[] = {"FISRnet/level_3/enc/level_0/", "FISRnet/level_3/enc/level_1/", "FISRnet/level_3/dec/level_1/",
-                                   "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/FI-SR/", "FISRnet/level_3/SR/"};
+                                   "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/SR/"};
   for (const char* h : hi)
     if (name.compare(0, strlen(h), h) == 0) return true;
   return false;
@@ -852,22 +852,25 @@ struct Runner {
     rb(d + "/res_block/1", X, A, c, n, h, w, true);
     return X;
   }
+  // one head FISRnet.py:95-100 (hd = 0: FI-SR) / :101-106 (hd = 1: SR): cur [n,h,w,64] -> its channels of pred float32 [n,2h,2w,9];
+  // Hx, A: [n,h,w,64] scratch, S: [n,2h,2w,64] scratch
+  void head(const std::string& P, int hd, const T* cur, int n, int h, int w, float* pred, T* Hx, T* A, T* S) {
+    const std::string p = P + (hd == 0 ? "/FI-SR" : "/SR");
+    conv(p + "/conv/0", cur, 64, nullptr, 0, nullptr, Hx, n, h, w, 0);
+    rb(p + "/res_block/0", Hx, A, 64, n, h, w, false);
+    conv(p + "/conv/1", Hx, 64, nullptr, 0, nullptr, S, n, h, w,
+         FISR_CONV_RELU_IN | FISR_CONV_RELU_OUT | FISR_CONV_D2S);
+    // pred = concat([fr1, SR, fr2]): FI-SR channels 0-2 -> 0-2, 3-5 -> 6-8; SR -> 3-5
+    if (hd == 0) conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 0, 3, 3);
+    else         conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 3);
+  }
   // heads FISRnet.py:95-108: cur [n,h,w,64] -> pred float32 [n,2h,2w,9]
   void heads(const std::string& P, const T* cur, int n, int h, int w, float* pred) {
     const size_t px = (size_t)n * h * w;
     T* Hx = talloc(px * 64);
     T* A = talloc(px * 64);
     T* S = talloc(px * 4 * 64);
-    for (int hd = 0; hd < 2; ++hd) {
-      const std::string p = P + (hd == 0 ? "/FI-SR" : "/SR");
-      conv(p + "/conv/0", cur, 64, nullptr, 0, nullptr, Hx, n, h, w, 0);
-      rb(p + "/res_block/0", Hx, A, 64, n, h, w, false);
-      conv(p + "/conv/1", Hx, 64, nullptr, 0, nullptr, S, n, h, w,
-           FISR_CONV_RELU_IN | FISR_CONV_RELU_OUT | FISR_CONV_D2S);
-      // pred = concat([fr1, SR, fr2]): FI-SR channels 0-2 -> 0-2, 3-5 -> 6-8; SR -> 3-5
-      if (hd == 0) conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 0, 3, 3);
-      else         conv(p + "/conv/2", S, 64, nullptr, 0, nullptr, pred, n, 2 * h, 2 * w, 0, true, 9, 3);
-    }
+    for (int hd = 0; hd < 2; ++hd) head(P, hd, cur, n, h, w, pred, Hx, A, S);
   }
 
   // One U-Net + the two heads at working resolution rh x rw (FISRnet.py:83-108).
@@ -975,9 +978,25 @@ struct MixedRunner {
     convert(hi, cur, curb, px4 * 256);
     const THi* top = hi.dec_level(P, 1, curb, 256, skiph[1], n, h / 4, w / 4);   // -> 128 channels at h/2 x w/2
     top = hi.dec_level(P, 0, top, 128, skiph[0], n, h / 2, w / 2);
-    hi.heads(P, top, n, h, w, l3);
+    // r04: the FI-SR branch (FISRnet.py:157-162) in fp16 -- its frames sit at the 37.86 dB operating point (README.md:97), where the
+    // branch's fp16 rounding shifts the PSNR by a tenth of what it would on the 48.07 dB SR frame, and nothing of it reaches the SR
+    // branch; the decoder output is converted once (2 B per channel for the branch's five convs instead of 4)
+    const size_t px = (size_t)n * h * w;
+    THi* Hx = hi.talloc(px * 64);
+    THi* A = hi.talloc(px * 64);
+    THi* S = hi.talloc(px * 4 * 64);
+    hi.head(P, 1, top, n, h, w, l3, Hx, A, S);
+    if (hi.rc) return hi.rc;
     lo.ar = hi.ar;
-    return hi.rc;
+    // (the fp16 branch works inside the SR branch's scratch: S is dead once SR/conv/2 has been enqueued on the same stream)
+    _Float16* s16 = (_Float16*)S;                  // px * 4 * 64 fsplit = 8 x px x 64 fp16
+    _Float16* top16 = s16;                         // [px, 64]
+    _Float16* Hx16 = s16 + px * 64;
+    _Float16* A16 = s16 + px * 128;
+    _Float16* S16 = s16 + px * 192;                // [4 px, 64] -> ends at px * 448 <= px * 512
+    convert(lo, top, top16, px * 64);
+    lo.head(P, 0, top16, n, h, w, l3, Hx16, A16, S16);
+    return lo.rc;
   }
 };
 
