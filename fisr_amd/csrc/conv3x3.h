@@ -423,8 +423,9 @@ struct ConvArgs {
   int dil;              // Winograd kernel only: dilation (1 otherwise)
   // diagnostics (fisr_bench_conv only): per-workgroup {start, main-loop end, end, HW_ID} timestamps
   unsigned long long* trace;
-  // conv3x3_wf4.h only: when not NULL, the 2x2 max pooling of the output ([N,H/2,W/2,Cout], ops.py:54) as a second store of the
-  // epilogue -- a Winograd tile holds whole pooling windows (H, W even; not with depth_to_space)
+  // conv3x3_wf4.h, and r04 the split-format record store of conv3x3_mfma_kernel<bsplit | fsplit, NT >= 1, false, MR = 2>: when not NULL,
+  // the 2x2 max pooling of the output ([N,H/2,W/2,Cout], ops.py:54) as a second store of the epilogue -- a Winograd tile / a wave's row
+  // pair holds whole pooling windows (H, W even; not with depth_to_space)
   void* pool_out = nullptr;
   int ups = 0;              // conv3x3_wf4.h: in0 is [N, H/2, W/2, C0] and enters through the legacy x2 bilinear (ops.py:69) on its way into LDS
 };
@@ -942,6 +943,31 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         for (int r = 0; r < 16; ++r) sacc += acc[m][j][r];
     if (sacc == 12345.678f) ((float*)p.out)[0] = sacc;
   } else {
+    // ---- ops.py:54 as a second store (r04, the split formats; the F(4x4) kernel has its own): a wave owns the row pair
+    // (y0 + 2 wave, + 1) and neighbouring lanes neighbouring columns, so a 2x2 pooling window is two accumulator rows of a lane pair --
+    // max over m in registers, over the lane pair through DPP, and the even lane stores the record of pixel (y / 2, x / 2).  H, W even.
+    if constexpr (MR == 2 && (std::is_same<T, fsplit>::value || std::is_same<T, bsplit>::value)) {
+      if (p.pool_out) {
+        const int yp = (y0 + wave * MR) >> 1;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int c0 = n0 + 32 * j + 16 * kh;
+          float pv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a_ = fmaxf(act(acc[0][j][r]), act(acc[1][j][r]));
+            pv[r] = fmaxf(a_, __uint_as_float(dpp_quad_xor1(__float_as_uint(a_))));
+          }
+          if (!(li & 1) && y0 + wave * MR < p.H && x < p.W && c0 < p.Cout) {
+            uint4 q[R16::NV];
+            R16::encode(pv, q);
+            uint4* ob = reinterpret_cast<uint4*>((char*)p.pool_out + (((size_t)(nb * (p.H >> 1) + yp) * (p.W >> 1) + (x >> 1)) * p.Cout + c0) * sizeof(T));
+#pragma unroll
+            for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
+          }
+        }
+      }
+    }
     // ---- record store straight from the accumulators: relu, convert, 16-byte stores ----
     // (quad-transposed when a record is four 16-byte units, so four lanes fill one record per instruction)
     const int cq_shift = p.d2s_shift;

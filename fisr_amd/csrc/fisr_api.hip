@@ -430,6 +430,10 @@ template <typename T> inline int conv_mr() {
   return std::is_same<T, float>::value ? 1 : 2;
 }
 
+// ops.py:54 as a second store of the direct kernel's record epilogue: the split formats on two-row waves (conv3x3.h)
+template <typename T> inline bool split_pool_ok() {
+  return (std::is_same<T, fsplit>::value || std::is_same<T, bsplit>::value) && conv_mr<T>() == 2;
+}
 template <typename T, int NT, bool OUT_F32, int MR>
 hipError_t launch_conv_variant(const ConvArgs& a, hipStream_t st) {
   static bool attr_done[64] = {};   // per device: one process may drive several GPUs (one ctx each)
@@ -701,12 +705,14 @@ struct Runner {
   //  F(4x4) Winograd kernel)
   bool pool_fuses(const std::string& name, int c, int h, int w) {
     auto it = ctx->convs.find(name);
+    // (r04: the split formats' direct kernel stores the pooled map too -- conv3x3.h, MR = 2 record store)
+    if (split_pool_ok<T>()) return it != ctx->convs.end() && it->second.nt >= 1 && !(h & 1) && !(w & 1);
     return std::is_same<T, float>::value && ctx->wf4 && it != ctx->convs.end() && it->second.d_wu4 && wf4_fits(h, w, c, 0, it->second.co) &&
            wf4_wins(h, w, c) && !(h & 1) && !(w & 1);
   }
   // (ups: in0 is the half-resolution map and the x2 bilinear of ops.py:69 happens on the conv's way into LDS -- only when up_fuses()
   //  says this conv runs on the F(4x4) Winograd kernel; h, w are the ENLARGED map's)
-  bool up_fuses(const std::string& name, int c, int h, int w) { return pool_fuses(name, c, h, w); }      // (the same conditions)
+  bool up_fuses(const std::string& name, int c, int h, int w) { return std::is_same<T, float>::value && pool_fuses(name, c, h, w); }      // (the same conditions)
   void conv(const std::string& name, const T* in0, int c0, const T* in1, int c1, const T* res, void* out,
             int n, int h, int w, int flags, bool out_f32 = false, int cstride = 0, int coff = 0,
             int split = 1 << 30, int gap = 0, void* pool_out = nullptr, bool ups = false) {
@@ -739,7 +745,10 @@ struct Runner {
     const bool use_wf4 = std::is_same<T, float>::value && ctx->wf4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cw.co) && wf4_wins(h, w, c0 + c1);
     if (use_wf4) a.wpk = cw.d_wu4;
     if (pool_out) {
-      if (!use_wf4) { rc = fail(ctx, FISR_ESTATE, name + ": fused pooling asked of a conv that does not run on the F(4x4) kernel"); return; }
+      if (!use_wf4 && !(split_pool_ok<T>() && cw.nt >= 1 && !out_f32 && !a.d2s && !(h & 1) && !(w & 1))) {
+        rc = fail(ctx, FISR_ESTATE, name + ": fused pooling asked of a conv that runs on neither the F(4x4) kernel nor the split formats' record store");
+        return;
+      }
       a.pool_out = pool_out;
     }
     if (ups) {
@@ -1298,7 +1307,11 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
                            int out_f32, void* stream) {
   if (!in0 || !w_host || !b_host || !out || n < 1 || h < 1 || w < 1 || cout < 1)
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: bad argument");
-  if (pool_out && (precision != FISR_PREC_F32W4 || out_f32 || !res || (h & 1) || (w & 1) || (flags & (FISR_CONV_RELU_IN | FISR_CONV_D2S | FISR_CONV_UP2_IN)) ||
+  // (r04: the split formats' direct kernel has the pooled second store too -- any flags but d2s / fused bilinear, residual optional)
+  const bool pool_split = precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8;
+  if (pool_out && pool_split && (out_f32 || (h & 1) || (w & 1) || (flags & (FISR_CONV_D2S | FISR_CONV_UP2_IN)) || cout % CONV_REC))
+    return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3_pool: on the split formats the pooled second store needs even h / w, whole 16-channel records, no d2s / fused bilinear");
+  if (pool_out && !pool_split && (precision != FISR_PREC_F32W4 || out_f32 || !res || (h & 1) || (w & 1) || (flags & (FISR_CONV_RELU_IN | FISR_CONV_D2S | FISR_CONV_UP2_IN)) ||
                    !wf4_fits(h, w, c0, c1, cout)))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3_pool: the pooled second store exists on the F(4x4) kernel only (FISR_PREC_F32W4, even h / w, "
                                       "a residual input, no relu-on-load / d2s / fused bilinear; ops.py:52-54)");

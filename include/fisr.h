@@ -193,9 +193,11 @@ FISR_API int fisr_op_conv3x3(const void* in0, int c0, const void* in1, int c1, c
                     const float* b_host, int cout, const void* res, void* out, int n, int h,
                     int w, int flags, int precision, int out_f32, void* stream);
 /* The last convolution of an encoder level with tf.nn.max_pool(2x2, stride 2) (ops.py:52-54, Enc_level_res) as a SECOND store of its
- * epilogue: out [n,h,w,cout] as fisr_op_conv3x3 writes it, pool_out [n,h/2,w/2,cout] = its 2x2 maxima.  FISR_PREC_F32W4 only (the
- * F(4x4) Winograd kernel: a 4x4 tile holds whole pooling windows); needs a residual input, even h / w, no relu-on-load / d2s /
- * fused bilinear; anything else is FISR_EINVAL. */
+ * epilogue: out [n,h,w,cout] as fisr_op_conv3x3 writes it, pool_out [n,h/2,w/2,cout] = its 2x2 maxima.  FISR_PREC_F32W4 (the
+ * F(4x4) Winograd kernel: a 4x4 tile holds whole pooling windows; needs a residual input, even h / w, no relu-on-load / d2s /
+ * fused bilinear) and, r04, FISR_PREC_BF16X3 / FISR_PREC_F16F8 (the direct kernel's record store: a wave's row pair x a lane pair is
+ * a pooling window; even h / w, cout % 16 == 0, no d2s / fused bilinear; residual and relu-on-load optional); anything else is
+ * FISR_EINVAL. */
 FISR_API int fisr_op_conv3x3_pool(const void* in0, int c0, const void* in1, int c1, const float* w_host, const float* b_host,
                          int cout, const void* res, void* out, void* pool_out, int n, int h, int w, int flags, int precision, void* stream);
 FISR_API int fisr_op_maxpool2(const void* in, void* out, int n, int h, int w, int c, int precision, void* stream);

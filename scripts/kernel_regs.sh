@@ -12,6 +12,6 @@ for m in re.finditer(r'\.name:\s+(\S+)(.*?)(?=\.name:\s+_Z|\Z)', txt, re.S):
     if '$pat' not in name: continue
     body=m.group(2)
     g=lambda k:(re.search(k+r':\s+(\d+)',body) or [0,'?'])[1]
-    print(name[:110], 'vgpr',g(r'\.vgpr_count'),'spill',g(r'\.vgpr_spill_count'),'scratch',g(r'\.private_segment_fixed_size'),'lds',g(r'\.group_segment_fixed_size'))
+    print(name[:110], 'vgpr',g(r'\.vgpr_count'),'spill',g(r'\.vgpr_spill_count'),'scratch',g(r'\.private_segment_fixed_size'))
 " | sort
 rm -rf $d

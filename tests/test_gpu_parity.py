@@ -395,6 +395,55 @@ def test_conv3x3_fp32_winograd_f4_pooled_second_store_vs_oracle(dev, shape):
     assert np.array_equal(got, hip_conv(x0, wt, b, x1, res, flags, prec="fp32w4"))
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 6e-5), ("f16f8", 6e-4)])
+@pytest.mark.parametrize("shape", [
+    # n, h, w, c0, c1, cout, flags, use_res
+    (1, 8, 32, 64, 0, 64, 2, True),             # one tile: four row pairs x sixteen lane pairs
+    (2, 40, 100, 64, 0, 64, 2, True),           # ragged right / bottom tiles: windows on the map's edge, masked lanes beside them
+    (1, 34, 62, 128, 0, 128, 2, True),          # two N blocks
+    (1, 18, 46, 32, 32, 96, 3, False),          # concat source, relu-on-load, no residual, a 32-channel N block of padding
+    (1, 6, 10, 16, 0, 16, 0, False),            # smaller than a tile, NT = 1, negative values survive the maximum
+])
+def test_conv3x3_split_formats_pooled_second_store_vs_oracle(dev, prec, tol, shape):
+    """r04: tf.nn.max_pool 2x2 / 2 (ops.py:54) as a second store of the split formats' direct kernel (a wave's row pair x a lane
+    pair = one pooling window): the full-resolution map against the fp64 oracle and equal to what fisr_op_conv3x3 writes, the pooled
+    map against the oracle's max_pool2 and VALUE for value equal to the 2x2 maxima of the stored full-resolution map (max commutes
+    with the formats' monotone rounding) and to fisr_op_maxpool2 of it."""
+    n, h, w, c0, c1, cout, flags, use_res = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31) + 23)
+    x0 = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    x1 = rng.standard_normal((n, h, w, c1)).astype(np.float32) if c1 else None
+    wt = (rng.standard_normal((3, 3, c0 + c1, cout)) * np.sqrt(2.0 / (9 * (c0 + c1)))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((n, h, w, cout)).astype(np.float32) if use_res else None
+    L = flib.lib()
+    vp = ctypes.c_void_p
+    d0 = to_dev(x0, prec)
+    d1 = to_dev(x1, prec) if c1 else None
+    dr = to_dev(res, prec) if use_res else None
+    out = empty_dev((n, h, w, cout), prec)
+    pool = empty_dev((n, h // 2, w // 2, cout), prec)
+    flib.check(L.fisr_op_conv3x3_pool(vp(d0.data_ptr()), c0, vp(d1.data_ptr() if c1 else 0), c1, _fp(wt), _fp(b), cout,
+                                      vp(dr.data_ptr() if use_res else 0), vp(out.data_ptr()), vp(pool.data_ptr()),
+                                      n, h, w, flags, PREC_ID[prec], _stream()))
+    torch.cuda.synchronize()
+    got = from_dev(out, prec, (n, h, w, cout))
+    gpool = from_dev(pool, prec, (n, h // 2, w // 2, cout))
+    xs0 = from_dev(d0, prec, x0.shape)
+    xs1 = from_dev(d1, prec, x1.shape) if c1 else None
+    rs = from_dev(dr, prec, res.shape) if use_res else None
+    exp = ref_conv(xs0, wt, b, xs1, rs, flags)
+    for g_, e_, what in ((got, exp, "full-resolution map"), (gpool, O.max_pool2(exp), "pooled map")):
+        err = np.abs(g_.astype(np.float64) - e_)
+        assert not np.isnan(g_).any() and (err <= tol * (1 + np.abs(e_) / 4)).all(), f"{prec} {shape} {what}: max err {err.max():.3e}"
+    assert np.array_equal(gpool, O.max_pool2(got.astype(np.float64)).astype(np.float32)), "pooled map != 2x2 maxima of the stored full-resolution map"
+    assert np.array_equal(got, hip_conv(x0, wt, b, x1, res, flags, prec=prec)), "the full-resolution store changed with the second store"
+    mp = empty_dev((n, h // 2, w // 2, cout), prec)
+    flib.check(L.fisr_op_maxpool2(vp(out.data_ptr()), vp(mp.data_ptr()), n, h, w, cout, PREC_ID[prec], _stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(gpool, from_dev(mp, prec, (n, h // 2, w // 2, cout))), "pooled store != fisr_op_maxpool2 of the stored map"
+
+
 def test_conv3x3_pooled_store_is_refused_where_it_is_not_implemented(dev):
     """fisr_op_conv3x3_pool outside the POOL instantiation's reach (odd maps, no residual, relu-on-load, d2s, another engine, a
     NULL pooled pointer): FISR_EINVAL with a message, never a partial store."""
