@@ -111,6 +111,9 @@ class Workload:
             self.gather = fdist.AsyncGather(tuple(self.yuv.shape), torch.uint8, dev, dst=0)
         self.step_index = 0
         self.glue_events = None       # instrumented pass: {kernel: [(ev0, ev1, launches)]}
+        # "fused": input assembly + tile cut + level inputs in one kernel per level (fisr_forward_frames; bit-identical);
+        # "packed": fisr_pack_input -> [3,h,w,29] -> tile slices -> fisr_forward, the reference's sequence of steps
+        self.input_path = "fused"
 
     def premake_warps(self, net):
         # pre-made warps (cfg2): produced once with the warp kernel, outside the timed region
@@ -138,7 +141,10 @@ class Workload:
         torch, h, w = self.torch, self.h, self.w
         fr, fl, wp = self.frames, self.flows, self.warps
         pack = lambda s, out=None: self._timed("pack_input", 1, lambda: net.pack_input(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4], h, w, out=out))
-        if self.batch == "stack":
+        if self.batch == "stack" and self.input_path == "fused":
+            # the 3 windows x 4 tiles as the 12 items of one fisr_forward_frames call: the packed tensor is never written
+            net.forward_tiled_frames([(fr[s:s + 3], fl[2 * s:2 * s + 4], wp[2 * s:2 * s + 4]) for s in range(3)], h, w, self.patch, full=self.full)
+        elif self.batch == "stack":
             # the 3 sliding windows (FISRnet.py:799) x 4 tiles (:847) are independent -> one batched forward; every
             # window is packed straight into its slot of the batch
             if getattr(self, "inp3", None) is None:
@@ -781,6 +787,9 @@ def main():
     ap.add_argument("--batch", default="stack", choices=["stack", "window", "tile"],
                     help="how many independent tiles go through one forward: the whole 5-frame stack "
                          "(3 windows x 4 tiles), one window (4 tiles) or one tile (the reference's schedule)")
+    ap.add_argument("--input-path", default="fused", choices=["fused", "packed"],
+                    help="fused: level inputs assembled straight from the frames / flows / warps (fisr_forward_frames, with --batch stack); "
+                         "packed: fisr_pack_input -> tile slices -> fisr_forward")
     ap.add_argument("--layer-profile", default=None, help="write a per-layer timing table (JSON) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -863,6 +872,7 @@ def main():
     wl = Workload(torch, dev, stack_id, patch, args.batch, parallelism, topo, group,
                   gather_group_world=world if (parallelism == "frame" and not args.no_gather) else 1)
     wl.premake_warps(net)
+    wl.input_path = args.input_path
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -1004,6 +1014,9 @@ def main():
                                    "pre-made flow+warp resident in HBM; synthetic seeded weights",
                        "engine": net.engine_description(),
                        "parallelism": par,
+                       "input_path": ("fused: frames/flows/warps -> level inputs in one kernel per level (fisr_forward_frames)"
+                                      if (args.input_path == "fused" and args.batch == "stack" and parallelism != "tile")
+                                      else "packed: fisr_pack_input -> tile slices -> fisr_forward"),
                        "tiles_per_forward": 3 if parallelism == "tile" else {"stack": 3 * len(wl.tiles), "window": len(wl.tiles), "tile": 1}[args.batch],
                        "tflop_per_step": round(wl.flop_per_stack / 1e12, 3),
                        "raw_fps": round(stacks * 9 * args.steps / elapsed, 3),

@@ -797,9 +797,20 @@ struct Runner {
     hipLaunchKernelGGL(upsample2_kernel<T>, dim3(grid_for(work)), dim3(256), 0, st, in, out, n, h, w, c);
     check(hipGetLastError(), "upsample2");
   }
+  // fisr_forward_frames: the level inputs come straight from the windows' source planes (prep_level_frames_kernel); img is unused
+  const FrameItems* fsrc = nullptr;
   void prep(const float* img, const float* pred, T* out, int n, int H, int W, int s, int cpad) {
     if (rc || ar.dry) return;
     const size_t work = (size_t)n * (H / s) * (W / s) * (cpad / 16);   // one thread per 16-channel record
+    if (fsrc) {
+      // bytes: 9 u8 + 4 x 8 + 4 x 12 source bytes per output pixel, the prediction, the records
+      const double opx = (double)n * (H / s) * (W / s);
+      ProfScope ps(ctx, st, "prep_level_frames", 0, opx * (89.0 + (pred ? 36.0 : 0.0) + (double)cpad * sizeof(T)));
+      const int spans = (W / s + 255) / 256;
+      hipLaunchKernelGGL(prep_level_frames_kernel<T>, dim3(std::min(n * (H / s) * spans, 1 << 20)), dim3(256), 0, st, *fsrc, pred, out, n, H, W, s, cpad);
+      check(hipGetLastError(), "prep_level_frames");
+      return;
+    }
     ProfScope ps(ctx, st, s == 1 ? "prep_level_input_s1" : "prep_level_input", 0, (double)work * 16 * (4 + sizeof(T)));
     if (s == 1)      // (level 3: the staged variant; the strided levels read too sparsely for it)
       hipLaunchKernelGGL(prep_level_input_s1_kernel<T>, dim3(grid_for((size_t)n * H * W)), dim3(256), 0, st, img, pred, out, (size_t)n * H * W, cpad);
@@ -1169,6 +1180,58 @@ int fisr_forward(fisr_ctx* ctx, const float* in, int n, int h, int w, float* out
     r.lo.ctx = r.hi.ctx = ctx; r.lo.st = r.hi.st = st;
     r.lo.ar.base = (char*)workspace; r.lo.ar.cap = workspace_bytes;
     return r.forward(in, n, h, w, out_l3, out_l2, out_l1);
+  }
+  return with_prec(ctx->precision, run);
+}
+
+int fisr_forward_frames(fisr_ctx* ctx, const fisr_src_item* items, int n, int h0, int w0, int h, int w, float* out_l3, float* out_l2,
+                        float* out_l1, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_forward_frames: ctx is NULL");
+  if (!ctx->finalized) return fail(ctx, FISR_ESTATE, "fisr_forward_frames: weights not finalized");
+  if (!items || !out_l3 || !workspace) return fail(ctx, FISR_EINVAL, "fisr_forward_frames: null argument");
+  if (n < 1 || n > FISR_MAX_SRC_ITEMS)
+    return fail(ctx, FISR_EINVAL, "fisr_forward_frames: 1 <= n <= FISR_MAX_SRC_ITEMS (" + std::to_string(FISR_MAX_SRC_ITEMS) + ") items per call");
+  if (h < 32 || w < 32 || h % 32 || w % 32)
+    return fail(ctx, FISR_EINVAL, "fisr_forward_frames: h and w must be positive multiples of 32 (FISRnet.py:820-824)");
+  static_assert(SRC_MAX_ITEMS == FISR_MAX_SRC_ITEMS, "the kernel-argument item table and the header's limit");
+  FrameItems fi;
+  memset(&fi, 0, sizeof(fi));
+  fi.W0 = w0;
+  for (int i = 0; i < n; ++i) {
+    const fisr_src_item& it = items[i];
+    if (it.y0 < 0 || it.x0 < 0 || it.y0 + h > h0 || it.x0 + w > w0)
+      return fail(ctx, FISR_EINVAL, "fisr_forward_frames: item " + std::to_string(i) + " does not lie inside the " + std::to_string(h0) + " x " +
+                                        std::to_string(w0) + " frame");
+    for (int k = 0; k < 3; ++k) {
+      if (!it.frames[k]) return fail(ctx, FISR_EINVAL, "fisr_forward_frames: null frame pointer");
+      fi.pp[i].fr[k] = it.frames[k];
+    }
+    for (int k = 0; k < 4; ++k) {
+      if (!it.flows[k] || !it.warps[k] || ((size_t)it.flows[k] & 7) || ((size_t)it.warps[k] & 3))
+        return fail(ctx, FISR_EINVAL, "fisr_forward_frames: flow planes must be non-null and 8-byte aligned, warp planes 4-byte aligned");
+      fi.pp[i].fl[k] = it.flows[k];
+      fi.pp[i].wp[k] = it.warps[k];
+    }
+    fi.y0[i] = it.y0; fi.x0[i] = it.x0;
+  }
+  const size_t need = fisr_workspace_bytes(ctx, n, h, w);
+  if (workspace_bytes < need)
+    return fail(ctx, FISR_ENOMEM, "fisr_forward_frames: workspace " + std::to_string(workspace_bytes) + " < " + std::to_string(need));
+  DeviceGuard guard(ctx->dev);
+  HIP_OK(ctx, guard.err);
+  hipStream_t st = (hipStream_t)stream;
+  auto run = [&](auto tag) -> int {
+    typedef decltype(tag) T;
+    Runner<T> r;
+    r.ctx = ctx; r.st = st; r.fsrc = &fi;
+    r.ar.base = (char*)workspace; r.ar.cap = workspace_bytes;
+    return r.forward(nullptr, n, h, w, out_l3, out_l2, out_l1);
+  };
+  if (prec_mixed(ctx->precision)) {
+    MixedRunner r;
+    r.lo.ctx = r.hi.ctx = ctx; r.lo.st = r.hi.st = st; r.lo.fsrc = r.hi.fsrc = &fi;
+    r.lo.ar.base = (char*)workspace; r.lo.ar.cap = workspace_bytes;
+    return r.forward(nullptr, n, h, w, out_l3, out_l2, out_l1);
   }
   return with_prec(ctx->precision, run);
 }

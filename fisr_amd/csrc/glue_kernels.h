@@ -425,6 +425,85 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackPtrs pp, int 
   }
 }
 
+// ---- input assembly + tile cut + level input in ONE pass (r04; SURVEY 2.2: "pack -> prep as one kernel") ----
+// FISRnet.py:828-843 (normalise, channel order), :853-857 (the tile's rectangle of the packed frame), :81,112-113,144 (x[:, ::s, ::s, :]
+// and the concat with the previous level's prediction): item `it` of the batch is the h x w rectangle at (y0, x0) of the window whose
+// eleven source planes are pp[it].  The [1,h,w,29] float32 tensor of the graph seam, its per-tile copies and the read-back of both are
+// never materialised: a block reads the source pixels of 256 output pixels of one output row of one item, normalises them exactly as
+// pack_input_kernel does (same operations in the same types: the level inputs are bit-identical to pack_input -> slice ->
+// prep_level_input), stages them in LDS at the odd stride of 29 floats and writes 16-channel records with 16-byte stores.  Kernel
+// arguments carry the items by value (16 x 11 pointers: 1.6 KB); the item index is block-uniform, so its pointers arrive by scalar loads.
+constexpr int SRC_MAX_ITEMS = 16;                 // == FISR_MAX_SRC_ITEMS (include/fisr.h)
+struct FrameItems {
+  PackPtrs pp[SRC_MAX_ITEMS];
+  int y0[SRC_MAX_ITEMS], x0[SRC_MAX_ITEMS];
+  int W0;                                         // row pitch of every source plane, in pixels
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_level_frames_kernel(const FrameItems fi, const float* __restrict__ pred, T* __restrict__ out,
+                                                                 int N, int H, int W, int s, int cpad) {
+  typedef Rec16<T> R16;
+  __shared__ __attribute__((aligned(16))) float s_img[256 * 29];
+  __shared__ __attribute__((aligned(16))) float s_pred[256 * 9 + 4];
+  const int tid = threadIdx.x;
+  const int oh = H / s, ow = W / s, groups = cpad / 16;
+  const int spans = (ow + 255) / 256;
+  const int total = N * oh * spans;
+  for (int b = blockIdx.x; b < total; b += gridDim.x) {
+    const int sp = b % spans, y = (b / spans) % oh, it = b / (spans * oh);
+    const int x0 = sp * 256, np = min(256, ow - x0);                          // outputs x0 .. x0 + np of row y of item it
+    if (tid < np) {
+      const PackPtrs& pp = fi.pp[it];
+      const size_t si = (size_t)(fi.y0[it] + y * s) * fi.W0 + (size_t)(fi.x0[it] + (x0 + tid) * s);
+      float* o = s_img + tid * 29;
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double v = (double)pp.fr[f][si * 3 + c] / 255.0;              // FISRnet.py:828-830 (as pack_input_kernel)
+          o[f * 3 + c] = (float)fmin(fmax(v, 0.0), 1.0);
+        }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const float2 fl = *reinterpret_cast<const float2*>(pp.fl[f] + si * 2);
+        o[9 + f * 2 + 0] = fminf(fmaxf(__fdiv_rn(__fdiv_rn(fl.x, 96.f), 2.f), -1.f), 1.f);     // FISRnet.py:835-836
+        o[9 + f * 2 + 1] = fminf(fmaxf(__fdiv_rn(__fdiv_rn(fl.y, 96.f), 2.f), -1.f), 1.f);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[17 + f * 3 + c] = fminf(fmaxf(__fdiv_rn(pp.wp[f][si * 3 + c], 255.f), 0.f), 1.f);   // utils.py:51, FISRnet.py:840
+    }
+    const size_t opix0 = ((size_t)it * oh + y) * ow + x0;
+    if (pred != nullptr) {
+      const float* g = pred + opix0 * 9;
+      const int nf = np * 9, n4 = ((size_t)g & 15) == 0 ? nf >> 2 : 0;
+      for (int j = tid; j < n4; j += 256) reinterpret_cast<f32x4*>(s_pred)[j] = reinterpret_cast<const f32x4*>(g)[j];
+      for (int j = 4 * n4 + tid; j < nf; j += 256) s_pred[j] = g[j];
+    }
+    __syncthreads();
+    for (int r = tid; r < np * groups; r += 256) {
+      const int pl = r / groups, g = r - pl * groups;
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int c = 16 * g + k;
+        float t = 0.f;
+        if (c < 29) t = s_img[pl * 29 + c];
+        else if (pred != nullptr && c < 38) t = s_pred[pl * 9 + (c - 29)];
+        v[k] = t;
+      }
+      uint4 q[R16::NV];
+      R16::encode(v, q);
+      uint4* ob = reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + ((opix0 + pl) * cpad + 16 * g) * sizeof(T));
+#pragma unroll
+      for (int k = 0; k < R16::NV; ++k) ob[k] = q[k];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- output post-processing: FISRnet.py:883, 903-909; utils.py:106-115 ----
 // Staged through LDS like pack_input: 36-byte pixels in, 9-byte (YUV) and 3 x 3-byte (RGB planes) pixels out, all moved
 // as aligned 16-byte vectors of a block's 256-pixel span (the byte streams of a span are 16-byte aligned when

@@ -347,6 +347,62 @@ class FISRnet:
                                                    _stream(self.device)))
         return full[0] if squeeze else full
 
+    def forward_tiled_frames(self, windows, h: int, w: int, num_patch: Tuple[int, int] = (2, 2),
+                             tiles: Optional[Sequence[int]] = None, full=None):
+        """forward_tiled(pack_input(...)) without the packed tensor: `windows` is a list of B (frames3, flows4, warps4) tuples as
+        pack_input takes them (device tensors of one common frame size), h x w the crop (FISRnet.py:820-824).  Every (tile, window)
+        pair becomes one item of fisr_forward_frames, whose level inputs are assembled straight from the source planes
+        (FISRnet.py:828-843 + :853-857 + :81,112-113,144 in one kernel per level) -- bit-identical to the two-step path, which stays
+        the graph seam.  Returns the stitched prediction [B,2h,2w,9] float32 ([2h,2w,9] when B == 1 and `full` is None)."""
+        torch = _torch()
+        if not self._finalized:
+            raise FisrError("weights not loaded: call load() or set_weights() first")
+        B, sf = len(windows), self.scale_factor
+        prepared, h0, w0 = [], None, None
+        for frames_u8, flows, warps in windows:
+            fr = [f.to(device=self.device, dtype=torch.uint8).contiguous() for f in frames_u8]
+            fl = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in flows]
+            wp = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in warps]
+            if len(fr) != 3 or len(fl) != 4 or len(wp) != 4:
+                raise ValueError("forward_tiled_frames: every window needs 3 frames, 4 flows, 4 warps")
+            fr, fl, wp, a, b = fit_pack_inputs(fr, fl, wp, h, w)
+            if h0 is not None and (a, b) != (h0, w0):
+                raise ValueError("forward_tiled_frames: all windows must share one frame size")
+            h0, w0 = a, b
+            prepared.append((fr, fl, wp))
+        plan = [t for t in tiling.plan_tiles(h, w, tuple(num_patch), sf) if tiles is None or t.index in tiles]
+        squeeze = full is None and B == 1
+        if full is None:
+            full = torch.zeros((B, h * sf, w * sf, 9), dtype=torch.float32, device=self.device)
+        fullv = full if full.dim() == 4 else full.unsqueeze(0)
+        groups = {}
+        for t in plan:
+            groups.setdefault((t.in_h, t.in_w), []).append(t)
+        for (th, tw), grp in groups.items():
+            if th % 32 or tw % 32:
+                raise ValueError("tile sizes must be multiples of 32 (FISRnet.py:820-824)")
+            pairs = [(t, b) for t in grp for b in range(B)]
+            for k in range(0, len(pairs), _lib.MAX_SRC_ITEMS):
+                chunk = pairs[k:k + _lib.MAX_SRC_ITEMS]
+                n = len(chunk)
+                items = (_lib.SrcItem * n)()
+                for i, (t, b) in enumerate(chunk):
+                    fr, fl, wp = prepared[b]
+                    for j in range(3):
+                        items[i].frames[j] = fr[j].data_ptr()
+                    for j in range(4):
+                        items[i].flows[j] = fl[j].data_ptr()
+                        items[i].warps[j] = wp[j].data_ptr()
+                    items[i].y0, items[i].x0 = t.h_lo, t.w_lo
+                pred = torch.empty((n, th * sf, tw * sf, 9), dtype=torch.float32, device=self.device)
+                ws = self._workspace(n, th, tw)
+                _lib.check(self._L.fisr_forward_frames(self._ctx, items, n, h0, w0, th, tw, _ptr(pred), None, None, _ptr(ws),
+                                                       ws.numel(), _stream(self.device)), self._ctx)
+                for i, (t, b) in enumerate(chunk):
+                    _lib.check(self._L.fisr_stitch(_ptr(pred[i]), t.in_h * sf, t.in_w * sf, t.src_y, t.src_x, t.out_h, t.out_w,
+                                                   _ptr(fullv[b]), h * sf, w * sf, t.dst_y, t.dst_x, _stream(self.device)))
+        return full[0] if squeeze else full
+
     # ------------------------------------------------------------------ harnesses
     def test(self):
         from .harness import run_test

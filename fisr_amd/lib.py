@@ -21,7 +21,7 @@ CONV_RELU_IN, CONV_RELU_OUT, CONV_D2S, CONV_UP2_IN = 1, 2, 4, 8
 
 EXPORTS = [
     "fisr_version", "fisr_create", "fisr_destroy", "fisr_last_error", "fisr_set_weight",
-    "fisr_finalize_weights", "fisr_num_variables_set", "fisr_workspace_bytes", "fisr_forward",
+    "fisr_finalize_weights", "fisr_num_variables_set", "fisr_workspace_bytes", "fisr_forward", "fisr_forward_frames",
     "fisr_profile_enable", "fisr_profile_reset", "fisr_profile_read", "fisr_warp", "fisr_pack_input",
     "fisr_unpack_output", "fisr_stitch", "fisr_sse_vs_u8", "fisr_ssim_u8", "fisr_op_conv3x3", "fisr_op_conv3x3_pool", "fisr_op_maxpool2", "fisr_op_prep_level_input",
     "fisr_op_upsample2", "fisr_bench_conv",
@@ -93,6 +93,14 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, define
     return target
 
 
+MAX_SRC_ITEMS = 16          # FISR_MAX_SRC_ITEMS (include/fisr.h)
+
+
+class SrcItem(ctypes.Structure):
+    """fisr_src_item (include/fisr.h): one tile of one window for fisr_forward_frames."""
+    _fields_ = [("frames", c_void_p * 3), ("flows", c_void_p * 4), ("warps", c_void_p * 4), ("y0", c_int), ("x0", c_int)]
+
+
 _lib = None
 
 
@@ -118,6 +126,7 @@ def lib():
     L.fisr_workspace_bytes.argtypes = [vp, c_int, c_int, c_int]
     L.fisr_workspace_bytes.restype = c_size_t
     L.fisr_forward.argtypes = [vp, vp, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
+    L.fisr_forward_frames.argtypes = [vp, POINTER(SrcItem), c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]
     L.fisr_profile_enable.argtypes = [vp, c_int]
     L.fisr_profile_reset.argtypes = [vp]
     L.fisr_profile_read.argtypes = [vp, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_int64),

@@ -126,6 +126,24 @@ FISR_API int fisr_forward(fisr_ctx* ctx, const float* in_nhwc29, int n, int h, i
                  float* out_l3, float* out_l2, float* out_l1,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* The graph seam with the input assembly folded in (r04): the same forward, but the level inputs are built straight from the
+ * windows' source planes -- FISRnet.py:828-843 (normalise + channel order), :853-857 (the tile's rectangle) and :81,112-113,144
+ * (sub-sample + concat) in one kernel per level; the [1,h,w,29] tensor of fisr_pack_input, its per-tile slices and their read-back
+ * are never written.  Item i is the h x w rectangle at (y0, x0) of a window given by its eleven planes (what fisr_pack_input
+ * takes): frames [h0,w0,3] uint8 YUV, flows [h0,w0,2] float32 px (8-byte aligned), warps [h0,w0,3] float32 0..255, all device
+ * pointers with row pitch w0.  Results are bit-identical to fisr_pack_input -> slice -> fisr_forward on the same n tiles;
+ * n <= FISR_MAX_SRC_ITEMS per call (the items travel as kernel arguments); workspace as for fisr_forward(n, h, w). */
+#define FISR_MAX_SRC_ITEMS 16
+typedef struct fisr_src_item {
+  const uint8_t* frames[3];
+  const float* flows[4];
+  const float* warps[4];
+  int y0, x0;
+} fisr_src_item;
+FISR_API int fisr_forward_frames(fisr_ctx* ctx, const fisr_src_item* items, int n, int h0, int w0, int h, int w,
+                        float* out_l3, float* out_l2, float* out_l1,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-kernel timing (HIP events on `stream` around every launch of the next forwards).
  * Off by default; bench.py uses it for the roofline figure of the dominant kernel. */
 FISR_API int fisr_profile_enable(fisr_ctx* ctx, int on);
