@@ -158,9 +158,11 @@ class Workload:
         rgb = None
         use_gather = self.gather is not None and self.gather_world > 1
         dst = self.gather.buffer(self.step_index) if use_gather else self.yuv     # (waits on the stream for the gather that last read it)
+        if getattr(self, "rgb", None) is None:
+            self.rgb = torch.empty((3, self.h * 2, self.w * 2, 3), dtype=torch.uint8, device=self.dev)
         for s in range(3):
-            yuv, rgb = self._timed("unpack_output", 1, lambda: net.unpack_output(self.full[s]))   # FISRnet.py:883, 903-909
-            dst[s] = yuv
+            # FISRnet.py:883, 903-909, written straight into the frame's slot of the output / send buffer
+            yuv, rgb = self._timed("unpack_output", 1, lambda: net.unpack_output(self.full[s], out_yuv=dst[s], out_rgb=self.rgb))
         if use_gather:
             self.gather.submit(self.step_index)
         self.step_index += 1

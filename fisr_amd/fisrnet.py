@@ -263,12 +263,16 @@ class FISRnet:
         _lib.check(self._L.fisr_pack_input(a, b, c, h0, w0, h, w, _ptr(out), _stream(self.device)))
         return out
 
-    def unpack_output(self, pred_hw9, want_rgb: bool = True):
-        """FISRnet.py:883,903-909: -> (yuv_u8 [h,w,9], rgb_u8 [3,h,w,3])."""
+    def unpack_output(self, pred_hw9, want_rgb: bool = True, out_yuv=None, out_rgb=None):
+        """FISRnet.py:883,903-909: -> (yuv_u8 [h,w,9], rgb_u8 [3,h,w,3]).  `out_yuv` / `out_rgb`: existing contiguous uint8 device
+        tensors of those shapes to fill instead of new ones (e.g. a frame's slot of a send buffer)."""
         torch = _torch()
         h, w = pred_hw9.shape[:2]
-        yuv = torch.empty((h, w, 9), dtype=torch.uint8, device=self.device)
-        rgb = torch.empty((3, h, w, 3), dtype=torch.uint8, device=self.device) if want_rgb else None
+        for t, shp, what in ((out_yuv, (h, w, 9), "out_yuv"), (out_rgb, (3, h, w, 3), "out_rgb")):
+            if t is not None and (tuple(t.shape) != shp or t.dtype != torch.uint8 or not t.is_contiguous() or t.device != self.device):
+                raise ValueError(f"unpack_output: `{what}` must be a contiguous uint8 {list(shp)} tensor on the engine's device")
+        yuv = out_yuv if out_yuv is not None else torch.empty((h, w, 9), dtype=torch.uint8, device=self.device)
+        rgb = out_rgb if out_rgb is not None else (torch.empty((3, h, w, 3), dtype=torch.uint8, device=self.device) if want_rgb else None)
         _lib.check(self._L.fisr_unpack_output(_ptr(pred_hw9.contiguous()), h, w, _ptr(yuv), _ptr(rgb), _stream(self.device)))
         return yuv, rgb
 

@@ -143,3 +143,28 @@ def test_level3_input_of_the_fused_kernel_vs_oracle_assembly(dev, syn_weights):
         assert torch.equal(o3, ref)
     finally:
         net.close()
+
+
+def test_forward_frames_full_size_stack_bit_identical(dev, syn_weights):
+    """cfg2's own shape: 3 windows of 1080x1920 frames cropped to 1024x1920, 2x2 tiles of 544x992 -> the 12 items of one call (what
+    bench.py's step runs), f16f8 engine; and unpack_output writing into caller-owned slots."""
+    net = FISRnet(device="cuda:0", precision="f16f8")
+    net.set_weights(syn_weights)
+    try:
+        h, w = 1024, 1920
+        wins = _sources(35, 1080, 1920, windows=3)
+        inp = torch.cat([net.pack_input(fr, fl, wp, h, w) for fr, fl, wp in wins], dim=0)
+        ref = net.forward_tiled(inp, (2, 2))
+        del inp
+        got = net.forward_tiled_frames(wins, h, w, (2, 2))
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        yuv0, rgb0 = net.unpack_output(ref[0])
+        slot = torch.zeros((2, 2 * h, 2 * w, 9), dtype=torch.uint8, device="cuda")
+        rgbb = torch.zeros((3, 2 * h, 2 * w, 3), dtype=torch.uint8, device="cuda")
+        y1, r1 = net.unpack_output(got[0], out_yuv=slot[1], out_rgb=rgbb)
+        assert y1.data_ptr() == slot[1].data_ptr() and torch.equal(slot[1], yuv0) and torch.equal(rgbb, rgb0) and not bool(slot[0].any())
+        with pytest.raises(ValueError):
+            net.unpack_output(got[0], out_yuv=slot[:, :, :, :3])
+    finally:
+        net.close()
