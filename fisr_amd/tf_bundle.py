@@ -50,11 +50,60 @@ def _crc_table():
     return _CRC_TABLE
 
 
-def crc32c(data: bytes, crc: int = 0) -> int:
+def _crc32c_bytewise(data, c: int) -> int:
+    """the table-driven register update over `data`, from register state c to register state (no init / final xor here)"""
     t = _crc_table()
-    c = crc ^ 0xFFFFFFFF
     for b in data:
         c = t[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c
+
+
+_CRC_LANES = 1 << 16           # the big-buffer path runs this many register states in lock-step through numpy
+_CRC_BIG = 1 << 20             # ... for buffers of at least this many bytes (a checkpoint's tensors: 580 MB with the Adam slots)
+
+
+def _crc32c_lanes(buf, c: int) -> int:
+    """The same register update for a big buffer.  The update is linear over GF(2) in (state, data) jointly, so the buffer is cut
+    into _CRC_LANES chunks of L bytes that advance side by side (one numpy gather per byte position: L steps instead of
+    len(buf)), lane 0 starting from the incoming state and the others from 0; the lanes are then folded left to right,
+    state <- Z^L(state) ^ lane_k, with Z^L (L zero bytes pushed through the register) as four 256-entry tables.  Bytes behind the
+    last whole chunk go through the byte-wise loop."""
+    import numpy as np
+    a = np.frombuffer(buf, dtype=np.uint8)
+    K = _CRC_LANES
+    L = a.size // K
+    tab = np.asarray(_crc_table(), dtype=np.uint32)
+    state = np.zeros(K, dtype=np.uint32)
+    state[0] = c
+    cols = a[:K * L].reshape(K, L)
+    step = 2048                                             # transpose a slab of byte positions at a time (bounded extra memory)
+    for j0 in range(0, L, step):
+        slab = np.ascontiguousarray(cols[:, j0:j0 + step].T).astype(np.uint32)
+        for row in slab:
+            state = tab[(state ^ row) & 0xFF] ^ (state >> 8)
+    # Z^L on the 32 basis vectors, all at once
+    z = (np.uint32(1) << np.arange(32, dtype=np.uint32)).astype(np.uint32)
+    for _ in range(L):
+        z = tab[z & 0xFF] ^ (z >> 8)
+    zt = []
+    for byte in range(4):                                   # zt[byte][v] = Z^L(v << 8 * byte)
+        col = [0] * 256
+        for v in range(256):
+            acc = 0
+            for bit in range(8):
+                if v >> bit & 1:
+                    acc ^= int(z[8 * byte + bit])
+            col[v] = acc
+        zt.append(col)
+    s = int(state[0])
+    for k in state[1:].tolist():
+        s = zt[0][s & 0xFF] ^ zt[1][(s >> 8) & 0xFF] ^ zt[2][(s >> 16) & 0xFF] ^ zt[3][s >> 24] ^ k
+    return _crc32c_bytewise(a[K * L:].tobytes(), s)
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    c = crc ^ 0xFFFFFFFF
+    c = _crc32c_lanes(data, c) if len(data) >= _CRC_BIG else _crc32c_bytewise(data, c)
     return c ^ 0xFFFFFFFF
 
 

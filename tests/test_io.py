@@ -305,3 +305,17 @@ def test_table_reader_vs_hand_assembled_leveldb_table(gold_dir):
             f.write(bytes(raw))
         with pytest.raises(ValueError):
             tf_bundle.read_index(os.path.join(d, "bad.index"), verify=True)
+
+
+def test_crc32c_lockstep_path_equals_the_bytewise_register():
+    """tf_bundle.crc32c runs buffers >= 1 MiB as 65 536 register states in lock-step and folds them with Z^L (a checkpoint with its
+    Adam slots is 580 MB: 46 s byte by byte in Python); same value as the byte-wise table loop, incl. a running crc and a tail
+    that is not a whole number of lanes; the check value of the polynomial pins both."""
+    from fisr_amd import tf_bundle as t
+    assert t.crc32c(b"123456789") == 0xE3069283
+    rng = np.random.default_rng(5)
+    for n, seed in ((t._CRC_BIG, 0), (t._CRC_BIG + 77_777, 0xDEADBEEF), (3 * t._CRC_BIG + 1, 1)):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert t.crc32c(b, seed) == t._crc32c_bytewise(b, seed ^ 0xFFFFFFFF) ^ 0xFFFFFFFF
+    b = rng.integers(0, 256, t._CRC_BIG + 5, dtype=np.uint8).tobytes()
+    assert t.crc32c(b[400_000:], t.crc32c(b[:400_000])) == t.crc32c(b)          # (running crc across the two paths)
