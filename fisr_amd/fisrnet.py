@@ -352,12 +352,13 @@ class FISRnet:
         return full[0] if squeeze else full
 
     def forward_tiled_frames(self, windows, h: int, w: int, num_patch: Tuple[int, int] = (2, 2),
-                             tiles: Optional[Sequence[int]] = None, full=None):
+                             tiles: Optional[Sequence[int]] = None, full=None, timed: bool = False):
         """forward_tiled(pack_input(...)) without the packed tensor: `windows` is a list of B (frames3, flows4, warps4) tuples as
         pack_input takes them (device tensors of one common frame size), h x w the crop (FISRnet.py:820-824).  Every (tile, window)
         pair becomes one item of fisr_forward_frames, whose level inputs are assembled straight from the source planes
         (FISRnet.py:828-843 + :853-857 + :81,112-113,144 in one kernel per level) -- bit-identical to the two-step path, which stays
-        the graph seam.  Returns the stitched prediction [B,2h,2w,9] float32 ([2h,2w,9] when B == 1 and `full` is None)."""
+        the graph seam.  Returns the stitched prediction [B,2h,2w,9] float32 ([2h,2w,9] when B == 1 and `full` is None).
+        `timed` appends every tile's share of its call's wall time to self.inf_time, as forward_tiled does."""
         torch = _torch()
         if not self._finalized:
             raise FisrError("weights not loaded: call load() or set_weights() first")
@@ -386,8 +387,10 @@ class FISRnet:
             if th % 32 or tw % 32:
                 raise ValueError("tile sizes must be multiples of 32 (FISRnet.py:820-824)")
             pairs = [(t, b) for t in grp for b in range(B)]
-            for k in range(0, len(pairs), _lib.MAX_SRC_ITEMS):
-                chunk = pairs[k:k + _lib.MAX_SRC_ITEMS]
+            per_call = _lib.MAX_SRC_ITEMS if self.batch_tiles else 1      # (batch_tiles=False: the reference's one tile per forward)
+            work = [pairs[k:k + per_call] for k in range(0, len(pairs), per_call)]
+            while work:
+                chunk = work.pop(0)
                 n = len(chunk)
                 items = (_lib.SrcItem * n)()
                 for i, (t, b) in enumerate(chunk):
@@ -398,10 +401,25 @@ class FISRnet:
                         items[i].flows[j] = fl[j].data_ptr()
                         items[i].warps[j] = wp[j].data_ptr()
                     items[i].y0, items[i].x0 = t.h_lo, t.w_lo
-                pred = torch.empty((n, th * sf, tw * sf, 9), dtype=torch.float32, device=self.device)
-                ws = self._workspace(n, th, tw)
+                try:
+                    pred = torch.empty((n, th * sf, tw * sf, 9), dtype=torch.float32, device=self.device)
+                    ws = self._workspace(n, th, tw)
+                except getattr(torch, "OutOfMemoryError", torch.cuda.OutOfMemoryError):
+                    if n == 1:
+                        raise
+                    # the batched workspace does not fit (the reference tiles because memory is limited): one tile per call instead
+                    self._ws = None
+                    torch.cuda.empty_cache()
+                    work = [[c] for c in chunk] + work
+                    continue
+                if timed:
+                    torch.cuda.synchronize(self.device)
+                    t0 = time.time()
                 _lib.check(self._L.fisr_forward_frames(self._ctx, items, n, h0, w0, th, tw, _ptr(pred), None, None, _ptr(ws),
                                                        ws.numel(), _stream(self.device)), self._ctx)
+                if timed:      # (as forward_tiled: the time of one tile's forward, FISRnet.py:868-874 -- here incl. its input assembly)
+                    torch.cuda.synchronize(self.device)
+                    self.inf_time.extend([(time.time() - t0) / n] * n)
                 for i, (t, b) in enumerate(chunk):
                     _lib.check(self._L.fisr_stitch(_ptr(pred[i]), t.in_h * sf, t.in_w * sf, t.src_y, t.src_x, t.out_h, t.out_w,
                                                    _ptr(fullv[b]), h * sf, w * sf, t.dst_y, t.dst_x, _stream(self.device)))

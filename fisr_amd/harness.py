@@ -141,7 +141,8 @@ def compute_flow(net, args, rank: int = 0, world: int = 1, return_array: bool = 
 
 
 def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_test_in_seq, H, W, num_patch):
-    """Device tensors for one 3-frame window (FISRnet.py:803-843)."""
+    """Device tensors for one 3-frame window (FISRnet.py:803-843): (frames, flows, warps) as pack_input / forward_tiled_frames take
+    them, and the crop size."""
     import torch
     h, w = tiling.crop_hw(H, W, num_patch)
     frames = [torch.from_numpy(fio.read_png(frame_paths[scene_i * n_test_in_seq + sample_i + k])).to(net.device)
@@ -149,7 +150,7 @@ def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_te
     # flow[scene, :, :, 4*s : 4*s+8] = flow sequence entries 2s..2s+3; warp likewise (6s..6s+12)
     flows = [torch.from_numpy(np.ascontiguousarray(flow_seq[scene_i, 2 * sample_i + k])).to(net.device) for k in range(4)]
     warps = [torch.from_numpy(np.ascontiguousarray(warp_seq[scene_i, 2 * sample_i + k])).to(net.device) for k in range(4)]
-    return net.pack_input(frames, flows, warps, h, w), h, w
+    return (frames, flows, warps), h, w
 
 
 def run_test(net):
@@ -178,8 +179,10 @@ def run_test(net):
     n_scenes = len(data_paths) // n_test_in_seq
     for scene_i in range(n_scenes):
         for sample_i in range(n_test_in_seq - n_in_seq + 1):
-            inp, h, w = _window_inputs(net, data_paths, flow, warp, scene_i, sample_i, n_test_in_seq, H, W, num_patch)
-            full = net.forward_tiled(inp, num_patch, timed=True)
+            src, h, w = _window_inputs(net, data_paths, flow, warp, scene_i, sample_i, n_test_in_seq, H, W, num_patch)
+            # input assembly (FISRnet.py:828-843), the tile loop (:847-880) and the forward in one call per group of equal tiles:
+            # bit-identical to pack_input -> forward_tiled (tests/test_gpu_frames.py)
+            full = net.forward_tiled_frames([src], h, w, num_patch, timed=True)
             yuv_u8, rgb_u8 = net.unpack_output(full)
             have_gt = len(label_paths) >= (scene_i + 1) * n_test_label_seq
             psnr, ssim, psnr_y = [float("nan")] * 3, [float("nan")] * 3, [float("nan")] * 3
@@ -325,8 +328,7 @@ def run_fisr_for_video(net, flow_file_name, warp_file_name, parallel=None):
             net.inf_time.append(time.time() - t0)
             next_t = window_tensors(my_windows[wi + 2]) if wi + 2 < len(my_windows) else None
         else:
-            inp = net.pack_input(frames, flows, warps, h, w)
-            full = net.forward_tiled(inp, num_patch, timed=True)
+            full = net.forward_tiled_frames([(frames, flows, warps)], h, w, num_patch, timed=True)
             yuv_u8, rgb_u8 = net.unpack_output(full)
         if writer:
             yuv_host = yuv_u8.cpu().numpy()
