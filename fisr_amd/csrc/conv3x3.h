@@ -902,6 +902,13 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
         const int xc = x0 + ct * 16 + l16;
         if (xc >= p.W) continue;
         float* ob = (float*)p.out + ((size_t)(nb * p.H + y) * p.W + xc) * (size_t)p.out_cstride;
+        // (dense 16-byte pieces: a whole quad of channels in front of the split, 16-byte aligned -- PWC-Net's 16-channel level-1
+        //  features; the heads' 3 / 6 / 2 channels take the scalar stores below)
+        if (!p.res && n0 + 4 * kg + 3 < min(p.Cout, p.out_split) && !((p.out_cstride | p.out_coff) & 3) && !((size_t)p.out & 15)) {
+          *reinterpret_cast<f32x4*>(ob + n0 + 4 * kg + p.out_coff) =
+              f32x4{act(acc4[m][ct][0]), act(acc4[m][ct][1]), act(acc4[m][ct][2]), act(acc4[m][ct][3])};
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = n0 + 4 * kg + r;

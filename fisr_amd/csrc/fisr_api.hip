@@ -349,7 +349,7 @@ inline bool dma_fits(int h, int w, int c0, int c1, int cs0, int cs1) {
   return c0 % D_CH == 0 && c1 % D_CH == 0 && c0 > 0 && (c1 == 0 || cs0 == cs1) && (double)h * w * cs0 * 2.0 < 2147483648.0;
 }
 
-// N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16,
+// N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16, fp32 also Cout = 16;
 // always fp32 output; FISR_DIAG builds: FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
 #ifdef FISR_DIAG
@@ -358,6 +358,8 @@ template <typename T> inline int nt_for(int co) {
   constexpr bool head16 = true;
 #endif
   if (co < 16 && head16) return 0;
+  // (fp32: a 16-channel conv -- PWC-Net's level-1 features -- fills the 16 rows exactly; NT = 1 would compute 32)
+  if (co == 16 && head16 && std::is_same<T, float>::value) return 0;
   return co <= 32 ? 1 : 2;
 }
 
