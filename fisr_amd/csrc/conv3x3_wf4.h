@@ -103,6 +103,9 @@ constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; 
 #ifndef FISR_F4_RAWEARLY
 #define FISR_F4_RAWEARLY 0
 #endif
+#ifndef FISR_F4_PADSKIP
+#define FISR_F4_PADSKIP 1      // GENERAL: padding waves of a <= 32-channel layer skip their MFMAs (A/B hook: 0)
+#endif
 #ifndef FISR_F4_UALL
 #define FISR_F4_UALL 1
 #endif
@@ -556,7 +559,21 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   };
 
   // =========================== MFMA side (all waves) ===========================
-  const int cq = wave & 3, th = wave >> 2;        // 16-channel quarter, 16-tile half
+  // 16-channel quarter, 16-tile half.  GENERAL: the quarters of the second tile half are rotated by two, so that the two waves of a
+  // SIMD (w and w + 4) own quarters {q, q ^ 2} -- in a layer with at most 32 output channels (one N block, half of it padding:
+  // PWC-Net's last dense convolutions and dc_conv6) every SIMD then hosts exactly ONE wave with work for the matrix pipe.
+  const int th = wave >> 2, cq = (GENERAL && FISR_F4_PADSKIP) ? ((wave & 3) ^ (th << 1)) : (wave & 3);
+  // GENERAL: a wave ALL of whose items lie in the padding of the 64-channel block (zero weights, nothing stored) runs the item loop
+  // without fragment reads, MFMAs and epilogue -- it keeps its copy / transform duties and the barriers.  The fp32 MFMA holds its
+  // wave's issue slot, so the lone MFMA wave of a SIMD runs its 36 MFMAs per chunk without a partner to wait for.  (Decided once
+  // per wave, outside the item loop: the two loops share no live accumulators.  A per-item decision -- the second N block of a
+  // 96-channel layer -- was built first: the accumulators became values merged at every branch, 170-380 spilled registers.)
+  // (Tried as well: the second N block of a 96-channel layer -- with gridDim.x / 8 a multiple of the N blocks all items of a
+  //  workgroup lie in one block, so the decision is still per wave.  Same-box A/B: 1.6 ms per stack SLOWER -- the items are dealt
+  //  round-robin, so the workgroups of the half-empty block only finish early, and running ahead of their neighbours they no longer
+  //  share the input tile with them in L2.)
+  const bool pad_wave = GENERAL && FISR_F4_PADSKIP && p.CoutPad == F4_BN && cq * 16 >= p.Cout;
+  constexpr bool MMA_HERE = true;                  // (shadowed inside run_items by its mma_tag)
   const char* const fu = sU + cq * 1024 + lane * 16;
   const char* const fv = sV + th * 1024 + ((lane & 0x30) | ((lane & 15) ^ ((lane >> 4) << 1))) * 16;
   f32x4 acc[36];
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   f32x4 bias4 = zero4;                             // bias of this lane's four channels (of the current item)
   static_assert(wf4_slot(1, 1) == 8, "the bias rides in accumulator 8 (quad 2, element 0)");
 #define FISR_F4_MMA4C(Q, A, B, C0_, C1_, C2_, C3_)                                                  \
-  if (!(FISR_F4ABL & 16)) {                                                                         \
+  if constexpr (MMA_HERE && !(FISR_F4ABL & 16)) {                                                     \
   acc[4 * (Q)]     = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, C0_, 0, 0, 0);              \
   acc[4 * (Q) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, C1_, 0, 0, 0);              \
   acc[4 * (Q) + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, C2_, 0, 0, 0);              \
@@ -630,7 +647,8 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   typedef std::integral_constant<bool, false> rest_t;
   typedef std::integral_constant<bool, true> odd_t;
   typedef std::integral_constant<bool, false> even_t;
-  auto k_iter = [&](auto role_tag, auto first_tag, auto odd_tag, int k) __attribute__((always_inline)) {
+  auto k_iter = [&](auto role_tag, auto first_tag, auto odd_tag, auto mma_tag, int k) __attribute__((always_inline)) {
+    constexpr bool MMA_HERE = decltype(mma_tag)::value;    // false: a padding wave's iteration (GENERAL) -- copies, transform, barrier only
     constexpr int ROLE = decltype(role_tag)::value;        // 0 / 1: transform wave of rows 0-2 / 3-5; 2: copy wave
     constexpr bool FIRST = decltype(first_tag)::value;     // first chunk of an item
     constexpr bool ODD = decltype(odd_tag)::value;         // k odd
@@ -643,10 +661,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     const int ku = u_here ? k + 1 : (has_next ? 0 : nch - 1);
     const int nblk_cur = cur.nblk, nblk_nxt = nxt.nblk;       // (values first: a conditional between the captured structs' fields is a
     const int u_nblk = u_here || !has_next ? nblk_cur : nblk_nxt;     //  select of ADDRESSES into the closure, which then cannot be promoted to registers)
-    ra[0] = *reinterpret_cast<const f32x4*>(ub);
-    rb[0] = *reinterpret_cast<const f32x4*>(vb);
-    ra[1] = *reinterpret_cast<const f32x4*>(ub + 4096);
-    rb[1] = *reinterpret_cast<const f32x4*>(vb + 2048);
+    if constexpr (MMA_HERE) {
+      ra[0] = *reinterpret_cast<const f32x4*>(ub);
+      rb[0] = *reinterpret_cast<const f32x4*>(vb);
+      ra[1] = *reinterpret_cast<const f32x4*>(ub + 4096);
+      rb[1] = *reinterpret_cast<const f32x4*>(vb + 2048);
+    }
     if (ROLE < 2 && !(FISR_F4ABL & 4)) tr_read(pbt, ODD ? 0 : 1);
     // odd iterations request the raw pair (k + 3) / 2: of this item, of the next one (its geometry from k = nch - 3 on), or a repeat
     int pc = 0;
@@ -669,15 +689,17 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       if (redo) raw_offsets(rfirst);
     }
     if constexpr (FIRST) {
+      if constexpr (MMA_HERE) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[32 + r] = zero4;
+        for (int r = 0; r < 4; ++r) acc[32 + r] = zero4;
+      }
     } else {
       FISR_F4_MMA4(8, ra[2], rb[2])
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      if (q < 7) {
+      if (MMA_HERE && q < 7) {
         ra[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(ub + (q + 2) * 4096);
         rb[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(vb + (q + 2) * 2048);
       }
@@ -746,17 +768,19 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   typedef std::integral_constant<int, 2> role2_t;
   unsigned long long t2[6] = {0, 0, 0, 0, 0, 0};   // timeline of the workgroup's SECOND item (steady state), trace runs only
   int n_done = 0;
-  auto k_loop = [&](auto role_tag) __attribute__((always_inline)) {
+  auto k_loop = [&](auto role_tag, auto mma_tag) __attribute__((always_inline)) {
     const bool tr2 = FISR_F4_TRACE && p.trace && n_done == 1;
     if (tr2) t2[0] = __builtin_readcyclecounter();
-    k_iter(role_tag, first_t{}, even_t{}, 0);
+    k_iter(role_tag, first_t{}, even_t{}, mma_tag, 0);
     if (tr2) t2[1] = __builtin_readcyclecounter();
-    k_iter(role_tag, rest_t{}, odd_t{}, 1);
+    k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, 1);
     if (tr2) t2[2] = __builtin_readcyclecounter();
-    for (int k = 2; k < nch; k += 2) { k_iter(role_tag, rest_t{}, even_t{}, k); k_iter(role_tag, rest_t{}, odd_t{}, k + 1); }
+    for (int k = 2; k < nch; k += 2) { k_iter(role_tag, rest_t{}, even_t{}, mma_tag, k); k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, k + 1); }
     if (tr2) t2[3] = __builtin_readcyclecounter();
   };
 
+  auto run_items = [&](auto mma_tag) __attribute__((always_inline)) {
+  constexpr bool MMA_HERE = decltype(mma_tag)::value;
   for (;;) {                                       // ---- work items of this workgroup ----
     {
       int l = lane;
@@ -764,9 +788,9 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       const int c0 = cur.nblk * F4_BN + cq * 16 + 4 * (l >> 4);
       bias4 = *reinterpret_cast<const f32x4*>(p.bias + (c0 < p.Cout ? c0 : 0));
     }
-    if (wave < 2) k_loop(role0_t{});
-    else if (wave < 4) k_loop(role1_t{});
-    else k_loop(role2_t{});
+    if (wave < 2) k_loop(role0_t{}, mma_tag);
+    else if (wave < 4) k_loop(role1_t{}, mma_tag);
+    else k_loop(role2_t{}, mma_tag);
     FISR_F4_MMA4(8, ra[2], rb[2])                  // the last chunk's pending quad
     if (FISR_F4_TRACE && p.trace && n_done == 0) t_main = __builtin_readcyclecounter();
 
@@ -778,7 +802,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     //      loads as much again).  So the outputs are transposed across the lanes first (ds_bpermute_b32: the LDS crossbar, no LDS
     //      memory): lane l takes tile l >> 2, channel group l & 3 -- four neighbouring lanes move one 64-byte record, and the residual
     //      is loaded in that layout directly.
-    {
+    if constexpr (MMA_HERE) {
       int l = lane;
       asm volatile("" : "+v"(l));                  // (recomputed per item: see raw_geom)
       const int bp_addr = (((l & 3) << 4) | (l >> 2)) << 2;       // byte address of the SOURCE lane of the transposition
@@ -938,6 +962,13 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     cur = nxt;
     has_next = b_cur + (int)gridDim.x < n_items;
     nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
+  }
+  };
+  if constexpr (GENERAL) {
+    if (pad_wave) run_items(std::integral_constant<bool, false>{});
+    else run_items(std::integral_constant<bool, true>{});
+  } else {
+    run_items(std::integral_constant<bool, true>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the repeated copies behind the last item still write LDS)
 #undef FISR_F4_SOFF

@@ -52,6 +52,7 @@ struct ConvW {
   void* d_w = nullptr;
   float* d_b = nullptr;
   int cin_pad = 0, cout_pad = 0, nt = 2;
+  bool rows16 = false;    // fp32, Cout == 16: take the 16-row variant too (PWC-Net's level-1 features fill its rows exactly; NT = 1 computes 32)
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino_common.h), else NULL
   void* d_wu4 = nullptr;  // FISR_PREC_F32W4: U = G g G^T of F(4x4,3x3) in the LDS image of conv3x3_wf4.h, else NULL
@@ -349,7 +350,7 @@ inline bool dma_fits(int h, int w, int c0, int c1, int cs0, int cs1) {
   return c0 % D_CH == 0 && c1 % D_CH == 0 && c0 > 0 && (c1 == 0 || cs0 == cs1) && (double)h * w * cs0 * 2.0 < 2147483648.0;
 }
 
-// N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16, fp32 also Cout = 16;
+// N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16; ConvW::rows16: fp32 also Cout = 16;
 // always fp32 output; FISR_DIAG builds: FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
 #ifdef FISR_DIAG
@@ -358,15 +359,13 @@ template <typename T> inline int nt_for(int co) {
   constexpr bool head16 = true;
 #endif
   if (co < 16 && head16) return 0;
-  // (fp32: a 16-channel conv -- PWC-Net's level-1 features -- fills the 16 rows exactly; NT = 1 would compute 32)
-  if (co == 16 && head16 && std::is_same<T, float>::value) return 0;
   return co <= 32 ? 1 : 2;
 }
 
 template <typename T>
 int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, bool wf4 = false) {
   constexpr int CC = Prec<T>::CC;
-  cw.nt = nt_for<T>(cw.co);
+  cw.nt = (cw.rows16 && cw.co == 16 && std::is_same<T, float>::value) ? 0 : nt_for<T>(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
   cw.cout_pad = cw.nt == 0 ? 16 : round_up(cw.co, 32 * cw.nt);
   std::vector<char> wp;

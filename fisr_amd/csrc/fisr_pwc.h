@@ -196,6 +196,7 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
     }
   } else if (as_direct) {
     pc.dw.ci = cin_buf; pc.dw.co = co; pc.dw.w = std::move(dense); pc.dw.b = kb.v;
+    pc.dw.rows16 = true;
     int rc = upload_conv<float>(nullptr, pc.dw, false);
     if (rc) return rc;
     pc.have_dw = true;
