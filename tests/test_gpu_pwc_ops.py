@@ -153,6 +153,32 @@ def test_winograd_f4_general_batch_padded_groups_and_routing():
     assert _run_conv(x2, 0, 64, w2, b2, None, o2, 0, 1, 272, 480, 1, 1, 0.1, 0, prec="fp32") == 2        # FISR_PREC_F32W keeps F(2x2)
 
 
+def test_winograd_f4_general_padding_waves_idle_is_bit_identical():
+    """Late r04 (conv3x3_wf4.h, pad_wave): in a layer with at most 32 output channels the waves whose 16-channel quarter is padding run
+    without fragment reads, MFMAs and epilogue, and the quarters of the second tile half are rotated so that every SIMD keeps one
+    multiplying wave.  The multiplying waves must produce exactly what they produce when all eight waves multiply: the Cout = 32
+    launch against the leading channels of a Cout = 64 launch with the same weights zero-padded (ragged map, dilation 1 / 2,
+    channel-range output with untouched neighbours)."""
+    rng = np.random.default_rng(16)
+    h, wd, cin = 107, 150, 64            # (dilation 2: 54 x 75 sub-images, still the F(4x4) kernel's)
+    x = (rng.standard_normal((1, h, wd, cin)) * 0.5).astype(np.float32)
+    xb = torch.from_numpy(x).cuda()
+    for cout, dil in ((32, 1), (32, 2)):
+        w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+        b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+        w64 = np.zeros((3, 3, cin, 64), np.float32); w64[..., :cout] = w
+        b64 = np.zeros(64, np.float32); b64[:cout] = b
+        full = torch.zeros((1, h, wd, 64), dtype=torch.float32, device="cuda")
+        assert _run_conv(xb, 0, cin, w64, b64, None, full, 0, 1, h, wd, 1, dil, 0.1, 5, prec="fp32w4") == 5
+        part = torch.full((1, h, wd, 80), 7.25, dtype=torch.float32, device="cuda")
+        assert _run_conv(xb, 0, cin, w, b, None, part, 8, 1, h, wd, 1, dil, 0.1, 5, prec="fp32w4") == 5
+        got = part.cpu().numpy()
+        assert np.array_equal(got[..., 8:8 + cout], full.cpu().numpy()[..., :cout]), (cout, dil)
+        assert (got[..., :8] == 7.25).all() and (got[..., 8 + cout:] == 7.25).all()
+        exp = _oracle_conv(x, w, b, 1, dil, 0.1)
+        assert np.abs(got[..., 8:8 + cout] - exp).max() < 1.2e-4
+
+
 def test_winograd_general_batch_and_padded_groups_vs_oracle():
     """Two images (the two flow directions of the feature pyramid run as one batch), a dense block's input with zero-weight
     padding channels between its groups (chmap), Cout = 32 (half an N block)."""
