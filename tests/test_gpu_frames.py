@@ -168,3 +168,36 @@ def test_forward_frames_full_size_stack_bit_identical(dev, syn_weights):
             net.unpack_output(got[0], out_yuv=slot[:, :, :, :3])
     finally:
         net.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+def test_forward_is_hip_graph_capturable(dev, syn_weights, precision):
+    """fisr_forward only enqueues on the caller's stream -- no allocation, no synchronisation, no host read-back (the arena is the
+    caller's, kernel attributes are set on the first call): a forward can be captured into a HIP graph and replayed, with the
+    eager result bit for bit.  (scripts/probes/hipgraph_probe.py, late r04: the replay of the 12-tile forward takes what the eager
+    stream takes, 112.5 / 64.6 ms -- the step is not launch-bound; this pins the property, not a speed-up.)"""
+    net = FISRnet(device="cuda:0", precision=precision)
+    net.set_weights(syn_weights)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        x = torch.rand((2, 64, 96, 29), device="cuda", generator=g)
+        ref = net.model(x, want_all=False)[-1].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            net.model(x, want_all=False)
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = net.model(x, want_all=False)[-1]
+        out.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        x.copy_(torch.rand((2, 64, 96, 29), device="cuda", generator=g))      # the graph reads the same buffers: new input, new result
+        ref2 = net.model(x, want_all=False)[-1].clone()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref2) and not torch.equal(ref2, ref)
+    finally:
+        net.close()
