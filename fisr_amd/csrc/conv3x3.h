@@ -428,6 +428,11 @@ struct ConvArgs {
   // pair holds whole pooling windows (H, W even; not with depth_to_space)
   void* pool_out = nullptr;
   int ups = 0;              // conv3x3_wf4.h: in0 is [N, H/2, W/2, C0] and enters through the legacy x2 bilinear (ops.py:69) on its way into LDS
+  // conv3x3_wf4.h, r05 (SHARE instantiations): `share` consecutive N blocks of a pixel tile run as ONE run on one workgroup; the run's first
+  // item transforms the input (V = B^T d B) and also stores it to vscr, the others copy V from there by LDS-DMA and run no
+  // transform.  vscr: wf4_vscr_bytes() of device scratch (per workgroup: the V of one item's whole K); share 0 / 1: off
+  void* vscr = nullptr;
+  int share = 0;
 };
 
 template <typename T, int NT> constexpr size_t conv_lds_bytes() {

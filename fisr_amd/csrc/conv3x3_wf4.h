@@ -69,6 +69,7 @@ constexpr int F4_L_ROWS = 10, F4_L_COLS = 18, F4_L_PLANE = 3072, F4_L_BYTES = 2 
 constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; }
 
 // FISR_F4ABL: performance-diagnosis ablations (WRONG results; scripts/probes/wf4_bench.hip): 1 no weight copies in the K loop,
+// 8192 SHARE: no V stores, 16384 SHARE: no V copies, 32768 SHARE: the V scratch of a workgroup is four chunks (what an L2-resident V would cost),
 // 4 no input transform, 16 no MFMAs, 128 workgroups de-phased at start, 256 wait for the stores behind the epilogue, 1024 no barrier, 2048 no vmcnt wait at the end of an iteration, 512 one store
 // per lane instead of 16 (earlier versions: 2 no raw copies, 32 / 64 raw access patterns)
 #ifndef FISR_F4ABL
@@ -112,6 +113,13 @@ constexpr size_t wf4_lds_bytes_ups() { return wf4_lds_bytes() + 2 * F4_L_BYTES; 
 #ifndef FISR_F4_U_AUX
 #define FISR_F4_U_AUX ""         // cache-policy bits of the weight copies (A/B hook: " nt", " sc1", " sc0 sc1")
 #endif
+// SHARE: cache policy of the V stores (aux bits of the builtin: 1 sc0, 2 nt, 16 sc1) and of the V copies (A/B hooks)
+#ifndef FISR_F4_VST_AUX
+#define FISR_F4_VST_AUX 0
+#endif
+#ifndef FISR_F4_VLD_AUX
+#define FISR_F4_VLD_AUX " sc1"
+#endif
 #ifndef FISR_F4_R_AUX              // ... of the raw copies (A/B hook, -DFISR_F4_R_AUXN=1 nt, 2 sc1, 3 sc0 sc1)
 #if FISR_F4_R_AUXN == 1
 #define FISR_F4_R_AUX " nt"
@@ -149,8 +157,17 @@ __device__ __forceinline__ void wf4_at(float m0, float m1, float m2, float m3, f
 // VMEM reads it" wants 5 wait states that only the hazard recogniser inserts -- as inline asm the store went out one slot behind
 // its v_readlane and landed anywhere.  The two scheduling barriers keep everything else out from between store and s_nop.)
 typedef unsigned int wf4_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wf4_u32x2 __attribute__((ext_vector_type(2)));
+template <int AUX = 0>
 __device__ __forceinline__ void wf4_store16(wf4_u32x4 data, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(data, rs, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(data, rs, voff, soff, AUX);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 0" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void wf4_store8(wf4_u32x2 data, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(data, rs, voff, soff, AUX);
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 0" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -171,9 +188,31 @@ __device__ __forceinline__ void wf4_store16(wf4_u32x4 data, __amdgpu_buffer_rsrc
 // interleaved sub-images (pixel (y, x) belongs to sub-image (y % d, x % d)), zero padding included, so tiles and all tile
 // coordinates live in a sub-image and only the addresses are scaled back.  Its own instantiation: one source, no relu-on-load,
 // no residual, no pooled store, no fused bilinear, no depth_to_space.
-template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false, bool GENERAL = false>
+// SHARE (r05): the N blocks of a pixel tile stop redoing the input transform.  p.share consecutive N blocks of a tile form a RUN that
+// one workgroup walks item by item; the run's first item (the producer, "P") works as every item of the other instantiations does
+// and additionally stores each chunk's V = B^T d B -- the LDS image, 18 KB -- to its workgroup's slice of p.vscr; the other items
+// (consumers, "C") fetch V from there by LDS-DMA two iterations ahead and run neither raw copies nor relu pass nor transform.  Same
+// V, same MFMAs in the same order: the results are bit-identical to the plain instantiation's (asserted by the tests).
+//   * C items keep a ring of FOUR V buffers: chunk c lives in slot (c + 2) & 3, slots 0 / 1 = V[0] / V[1], slots 2 / 3 = the two raw
+//     pair buffers (idle in a C item) -- with whole quadruples of chunks per item (launcher: nch % 4 == 0, nch >= 8) the streams of
+//     consecutive items meet without a collision in all three transitions (P -> C, C -> C, C -> P; worked through at k_iter).
+//   * Who does what is decided per iteration by three uniform flags (tr_on: chunk k + 1 is transformed here; vc_on: chunk k + 2 is
+//     copied from p.vscr; rp_on: the raw stream -- requests in odd, relu pass in even iterations -- runs), each looking at the item
+//     its target chunk belongs to; all 36 weight copies of a chunk come from the copy waves (the UALL split), the V copies from
+//     the transform waves (pieces w + 4 j; 5 / 5 / 4 / 4), so every wave's counted wait sees one kind of copy.
+//   * p.vscr is written and read by the SAME workgroup only (write-through to L2, read back by copies that carry sc1, i.e. that
+//     do not trust the CU's vector cache), a run apart at least: an s_waitcnt of the storing wave and a barrier lie in between.
+// MEASURED AND NOT IN THE PRODUCT (profiles/r05_wf4_vshare_ab.txt): bit-identical on every shape, consumers 24 % faster
+// per chunk (2.9 k against 3.8 k cycles), and every layer SLOWER as a whole (64->256 at 544x992: +10..15 %; 128->128, 256->256:
+// +15..18 %): 18 KB of V per chunk and N block through the CU's memory pipeline -- 20 store and 18 copy instructions -- cost what
+// the transform they replace costs, even when V never leaves L2 (ablation 32768: break-even at best); with no V traffic at all
+// (ablations 8192 + 16384, wrong results) the same launches run 9-13 % faster than the product: that is all the redundant
+// transforms cost.  The instantiations are compiled into scripts/probes/wf4_bench (-DFISR_F4_SHARE, `WF4_SHARE=n wf4_bench check`)
+// and nowhere else.
+template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false, bool GENERAL = false, bool SHARE = false>
 __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
   static_assert(!GENERAL || (!RELU_IN && !HAS_RES && !POOL && !UPS), "GENERAL is the plain instantiation on channel ranges");
+  static_assert(!SHARE || (!UPS && !GENERAL), "V sharing: the plain / relu-on-load / residual / pooling instantiations");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sU = smem;
   char* const sV = smem + 2 * F4_U_BYTES;
@@ -194,14 +233,18 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   const int rec_cs = GENERAL ? p.rec_cs : p.Cout, rec_co = GENERAL ? p.rec_co : 0;
   const int tiles_x = ((p.W + dil - 1) / dil + F4_TW - 1) / F4_TW, tiles_y = ((p.H + dil - 1) / dil + F4_TH - 1) / F4_TH;
   const int nblocks = p.CoutPad / F4_BN;
+  // SHARE: the virtual ids are RUNS (share consecutive N blocks of a tile); item_of gives a run's first item
+  const int share = SHARE ? p.share : 1;
+  const int n_units = SHARE ? n_items / share : n_items;
+  const int upt = SHARE ? nblocks / share : nblocks;    // runs (items) per pixel tile
   struct Item { int x0, y0, nb, nblk, ry, rx; };        // (x0, y0): inside sub-image (ry, rx) of image nb
   auto item_of = [&](int b) __attribute__((always_inline)) {
-    const int q = n_items >> 3, r = n_items & 7;
+    const int q = n_units >> 3, r = n_units & 7;
     const int xcd = b & 7, loc = b >> 3;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    int t = v / nblocks;
+    int t = v / upt;
     Item it;
-    it.nblk = v - t * nblocks;
+    it.nblk = (v - t * upt) * share;
     const int tx = t % tiles_x; t /= tiles_x;
     it.x0 = tx * F4_TW;
     it.y0 = (t % tiles_y) * F4_TH;
@@ -218,8 +261,11 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   };
   int b_cur = blockIdx.x;
   Item cur = item_of(b_cur);
-  bool has_next = b_cur + (int)gridDim.x < n_items;
-  Item nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
+  int j_cur = 0;                                        // SHARE: position of the current item in its run (0: the producer)
+  bool has_next = SHARE ? true : b_cur + (int)gridDim.x < n_items;
+  bool nxt_p = !SHARE;                                  // SHARE: the next item opens a run (is a producer)
+  Item nxt = SHARE ? cur : has_next ? item_of(b_cur + gridDim.x) : cur;
+  if constexpr (SHARE) nxt.nblk = cur.nblk + 1;         // (share >= 2: the launcher's rule)
   const int nch0 = p.C0 / F4_CH, nch = (p.C0 + p.C1) / F4_CH;       // (the launcher guarantees nch >= 4)
 
   if (FISR_F4ABL & 128) { for (int i = 0; i < (int)((blockIdx.x * 7u) & 31u); ++i) __builtin_amdgcn_s_sleep(4); }     // ablation: de-phase the workgroups
@@ -227,7 +273,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   // network, same box, two rounds) and all 36 weight copies of the plain residual instantiation (0.8 %); on the relu-on-load and
   // plain instantiations the same costs 3.7 % / 4.7 %, and priority for the transform waves changes nothing anywhere.
 #ifndef FISR_F4_PRIO
-  if ((UPS || (FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL)) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if ((UPS || (FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL && !SHARE)) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 #ifdef FISR_F4_PRIO
   if (FISR_F4_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // A/B: static priority for the younger / the older half
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   //  residual layers: 3.4 % faster inside the network (same box, two rounds: 50.4 -> 48.7 ms per 66 launches).  With the relu pass
   //  on the copy waves it costs 2.4 % (87.8 -> 89.9 ms per 94 launches), with the blend of the fused bilinear 3-4 %, with the
   //  pooling epilogue 1 %, plain without residual nothing; splits that left the transform waves 2-5 copies each: +-1 %.)
-  constexpr bool UALL = FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL && !UPS;
+  constexpr bool UALL = (FISR_F4_UALL && HAS_RES && !RELU_IN && !POOL && !UPS) || SHARE;
   constexpr bool RAWE = FISR_F4_RAWEARLY && !UALL && !UPS;
   auto copy_u1 = [&](int nblk, int kc, int buf, int j) __attribute__((always_inline)) {
     unsigned c = (UALL ? (unsigned)(cw + 4 * j) : j < 4 ? (unsigned)(wave + 8 * j) : (unsigned)(28 + wave)) + u_rot;
@@ -360,6 +406,25 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     const unsigned lds = raw_lds0 + (unsigned)pb * (unsigned)(2 * F4_RAW_BYTES) + (unsigned)j * 4096u;
     const unsigned o = j == 0 ? ro[0] : j == 1 ? ro[1] : j == 2 ? ro[2] : j == 3 ? ro[3] : ro[4];
     if (first) FISR_F4_DMA1(rs0, o, so, lds); else FISR_F4_DMA1(rs1, o, so, lds);
+  };
+  // SHARE: this workgroup's slice of p.vscr holds the V of one item's whole K, chunk after chunk, each the 18 KB LDS image.
+  // V slot s of a consumer's ring: 0 / 1 = V[0] / V[1], 2 / 3 = the raw pair buffers.
+  const size_t vscr_bytes = (size_t)nch * F4_V_BYTES;
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
+      SHARE ? (void*)((char*)p.vscr + (size_t)blockIdx.x * vscr_bytes) : (void*)p.wpk, 0, (unsigned)vscr_bytes, 0x00020000);
+  auto ring_off = [](int s) { return s < 2 ? s * F4_V_BYTES : 2 * F4_V_BYTES + (s - 2) * (2 * F4_RAW_BYTES); };     // relative to sV
+  const unsigned v_lds0 = (unsigned)(size_t)(wf4_lds_ptr_t)sV;
+  // V piece (wave & 3) + 4 j (j = 0..3; j = 4: piece 16 + wave, waves 0-1) of chunk c into ring slot s  (transform waves)
+  auto copy_v1 = [&](int c, int slot, int j) __attribute__((always_inline)) {
+    const unsigned piece = j < 4 ? (unsigned)(wave + 4 * j) : (unsigned)(16 + wave);
+    const unsigned so = (unsigned)((FISR_F4ABL & 32768) ? c & 3 : c) * (unsigned)F4_V_BYTES + piece * 1024u;      // (ablation 32768: four chunks of scratch per workgroup -- V stays in L2)
+    const unsigned lds = v_lds0 + (unsigned)ring_off(slot) + piece * 1024u;
+    {
+      unsigned keep_;
+      if (!(FISR_F4ABL & 16384))
+      asm volatile(FISR_F4_BEGIN(keep, lds) "buffer_load_dwordx4 %[o], %[rs], %[so] offen" FISR_F4_VLD_AUX " lds\n\t" FISR_F4_END(keep)
+                   : [keep] "=&s"(keep_) : [rs] "s"(rsv), [lds] "s"(lds), [o] "v"(u_voff), [so] "s"(so) : "memory", "scc");
+    }
   };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -523,28 +588,38 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   };
   // the 18 slots 18 rh + 6 i + .. of this wave: four position quads and half of quad 4
   auto quad_of = [](f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); };
-  auto tr_write = [&](auto rh_tag, int vbuf, int i) __attribute__((always_inline)) {     // what row i (0..2) of this wave completes
+  // (SHARE: vchunk = the chunk's index in its item -- the same 16 / 8 bytes go to that chunk's image in p.vscr)
+  auto tr_write = [&](auto rh_tag, int vbuf, int i, int vchunk = 0) __attribute__((always_inline)) {     // what row i (0..2) of this wave completes
     constexpr int RH = decltype(rh_tag)::value;
     char* vb = sV + vbuf * F4_V_BYTES + t_voff;
+    const unsigned gso = (unsigned)((FISR_F4ABL & 32768) ? vchunk & 3 : vchunk) * (unsigned)F4_V_BYTES;
+    auto put4 = [&](int off, f32x4 v) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(vb + off) = v;
+      if constexpr (SHARE && !(FISR_F4ABL & 8192)) wf4_store16<FISR_F4_VST_AUX>(__builtin_bit_cast(wf4_u32x4, v), rsv, (unsigned)t_voff, gso + (unsigned)off);
+    };
+    auto put2 = [&](int off, f32x2 v) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x2*>(vb + off) = v;
+      if constexpr (SHARE && !(FISR_F4ABL & 8192)) wf4_store8<FISR_F4_VST_AUX>(__builtin_bit_cast(wf4_u32x2, v), rsv, (unsigned)t_voff, gso + (unsigned)off);
+    };
     if constexpr (RH == 0) {
-      if (i == 0) *reinterpret_cast<f32x4*>(vb) = quad_of(zp[0][0], zp[0][1]);
+      if (i == 0) put4(0, quad_of(zp[0][0], zp[0][1]));
       if (i == 1) {
-        *reinterpret_cast<f32x4*>(vb + 2048) = quad_of(zp[0][2], zp[1][0]);
-        *reinterpret_cast<f32x4*>(vb + 2 * 2048) = quad_of(zp[1][1], zp[1][2]);
+        put4(2048, quad_of(zp[0][2], zp[1][0]));
+        put4(2 * 2048, quad_of(zp[1][1], zp[1][2]));
       }
       if (i == 2) {
-        *reinterpret_cast<f32x4*>(vb + 3 * 2048) = quad_of(zp[2][0], zp[2][1]);
-        *reinterpret_cast<f32x2*>(vb + 4 * 2048) = zp[2][2];
+        put4(3 * 2048, quad_of(zp[2][0], zp[2][1]));
+        put2(4 * 2048, zp[2][2]);
       }
     } else {
       if (i == 0) {
-        *reinterpret_cast<f32x2*>(vb + 4 * 2048 + 8) = zp[0][0];
-        *reinterpret_cast<f32x4*>(vb + 5 * 2048) = quad_of(zp[0][1], zp[0][2]);
+        put2(4 * 2048 + 8, zp[0][0]);
+        put4(5 * 2048, quad_of(zp[0][1], zp[0][2]));
       }
-      if (i == 1) *reinterpret_cast<f32x4*>(vb + 6 * 2048) = quad_of(zp[1][0], zp[1][1]);
+      if (i == 1) put4(6 * 2048, quad_of(zp[1][0], zp[1][1]));
       if (i == 2) {
-        *reinterpret_cast<f32x4*>(vb + 7 * 2048) = quad_of(zp[1][2], zp[2][0]);
-        *reinterpret_cast<f32x4*>(vb + 8 * 2048) = quad_of(zp[2][1], zp[2][2]);
+        put4(7 * 2048, quad_of(zp[1][2], zp[2][0]));
+        put4(8 * 2048, quad_of(zp[2][1], zp[2][2]));
       }
     }
   };
@@ -647,7 +722,8 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   typedef std::integral_constant<bool, false> rest_t;
   typedef std::integral_constant<bool, true> odd_t;
   typedef std::integral_constant<bool, false> even_t;
-  auto k_iter = [&](auto role_tag, auto first_tag, auto odd_tag, auto mma_tag, int k) __attribute__((always_inline)) {
+  auto k_iter = [&](auto role_tag, auto first_tag, auto odd_tag, auto mma_tag, auto fl_tag, int k) __attribute__((always_inline)) {
+    constexpr int FL = decltype(fl_tag)::value;            // SHARE: bit 0 tr_on, bit 1 vc_on (transform waves), bit 2 rp_on (copy waves); else 7
     constexpr bool MMA_HERE = decltype(mma_tag)::value;    // false: a padding wave's iteration (GENERAL) -- copies, transform, barrier only
     constexpr int ROLE = decltype(role_tag)::value;        // 0 / 1: transform wave of rows 0-2 / 3-5; 2: copy wave
     constexpr bool FIRST = decltype(first_tag)::value;     // first chunk of an item
@@ -655,7 +731,22 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     typedef typename std::conditional<ROLE == 1, rh1_t, rh0_t>::type RH;
     const int buf = par;
     const char* ub = fu + buf * F4_U_BYTES;
-    const char* vb = fv + buf * F4_V_BYTES;
+    // SHARE: what this iteration's streams do is decided by the item their target chunk belongs to.
+    //   tr_on  chunk k + 1 is a producer's: transformed here (and stored to p.vscr)
+    //   vc_on  chunk k + 2 is a consumer's: copied from p.vscr into ring slot k & 3 (= (k + 2 + 2) & 3)
+    //   rp_on  the raw stream (pair (k + 3) / 2 requested in odd k, relu'd in the even k behind it) feeds a producer
+    // Transitions, with nch % 4 == 0 (pair buffers: pair m in RAW[m & 1]; P chunk c in V[c & 1]; C chunk c in ring slot (c + 2) & 3):
+    //   P -> C  chunk 0 / 1 of C go to RAW[0] / RAW[1] in k = nch - 2 / nch - 1: P's pair np - 2 (RAW[0]) was read for the last time
+    //           in k = nch - 4, pair np - 1 (RAW[1]) in k = nch - 2; chunks 2 / 3 go to V[0] / V[1] in C's k = 0 / 1, behind P's chunks
+    //           nch - 2 / nch - 1 (the pending last quad of a chunk lives in registers).
+    //   C -> P  pair 0 / 1 of P are requested into RAW[0] / RAW[1] in k = nch - 3 / nch - 1 -- ring slots 2 / 3, i.e. chunks
+    //           nch - 4 / nch - 3, both multiplied by then; chunk 0 of P is transformed into V[0] in k = nch - 1 while C's chunk
+    //           nch - 1 is read from slot 1; no V copy is issued in k >= nch - 2.
+    // (compile-time per iteration body -- FL, chosen by k_loop's dispatch: as run-time branches inside the body the flags cost
+    //  250-390 spilled registers)
+    const bool cur_p = SHARE ? j_cur == 0 : true;
+    constexpr bool tr_on = !SHARE || (FL & 1), vc_on = SHARE && (FL & 2), rp_on = !SHARE || (FL & 4);
+    const char* vb = fv + (SHARE && !cur_p ? ring_off((k + 2) & 3) : buf * F4_V_BYTES);
     // U(k+1): of this item, of the next item (chunk 0), or a repeated chunk behind the last item
     const bool u_here = k + 1 < nch;
     const int ku = u_here ? k + 1 : (has_next ? 0 : nch - 1);
@@ -667,7 +758,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       ra[1] = *reinterpret_cast<const f32x4*>(ub + 4096);
       rb[1] = *reinterpret_cast<const f32x4*>(vb + 2048);
     }
-    if (ROLE < 2 && !(FISR_F4ABL & 4)) tr_read(pbt, ODD ? 0 : 1);
+    if (ROLE < 2 && !(FISR_F4ABL & 4) && tr_on) tr_read(pbt, ODD ? 0 : 1);
     // odd iterations request the raw pair (k + 3) / 2: of this item, of the next one (its geometry from k = nch - 3 on), or a repeat
     int pc = 0;
     int ey0 = 0, ex0 = 0;
@@ -680,7 +771,7 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       const bool of_next = k + 2 >= nch;
       ey0 = of_next ? ny0 : cy0; ex0 = of_next ? nx0 : cx0;
     }
-    if constexpr (ROLE == 2 && ODD && !UPS) {
+    if (ROLE == 2 && ODD && !UPS && rp_on) {
       const int pp = (k + 3) >> 1, np = nch >> 1;
       pc = pp < np ? pp : (has_next ? pp - np : np - 1);
       const bool rfirst = 2 * pc < nch0;
@@ -718,9 +809,17 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         }
       } else if (!(FISR_F4ABL & 1) && q >= FISR_F4_UQ && q - FISR_F4_UQ < (ROLE == 2 ? 5 : 4)) copy_u1(u_nblk, ku, buf ^ 1, q - FISR_F4_UQ);
       if constexpr (ROLE < 2) {
-        if (!(FISR_F4ABL & 4)) {
+        if (!(FISR_F4ABL & 4) && tr_on) {
           if (q == FISR_F4_COLQ) { tr_col(RH{}, 0); tr_col(RH{}, 1); tr_col(RH{}, 2); }
-          if (q >= FISR_F4_ROWQ && q < FISR_F4_ROWQ + 3) { tr_row(q - FISR_F4_ROWQ); tr_write(RH{}, buf ^ 1, q - FISR_F4_ROWQ); }
+          if (q >= FISR_F4_ROWQ && q < FISR_F4_ROWQ + 3) { tr_row(q - FISR_F4_ROWQ); tr_write(RH{}, buf ^ 1, q - FISR_F4_ROWQ, k + 1 < nch ? k + 1 : 0); }
+        }
+        if constexpr (SHARE) {      // V(k + 2) of a consumer: behind the stores of this iteration (P's last but one has both)
+          if (vc_on) {
+            const int c2 = k + 2 < nch ? k + 2 : k + 2 - nch;
+            if (q == 5) { copy_v1(c2, k & 3, 0); copy_v1(c2, k & 3, 1); }
+            if (q == 6) { copy_v1(c2, k & 3, 2); copy_v1(c2, k & 3, 3); }
+            if (q == 7 && ROLE == 0) copy_v1(c2, k & 3, 4);
+          }
         }
       } else if constexpr (UPS) {
         if constexpr (!ODD) {
@@ -734,10 +833,12 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
         }
       } else if constexpr (ODD) {
         constexpr int Q0 = RAWE ? 0 : 5;            // (RAWEARLY: first thing in the iteration -- this wave has no weight copies in it)
-        if (q == Q0) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
-        if (q == Q0 + 1) { copy_pair1(pc, pbt ^ 1, 2); copy_pair1(pc, pbt ^ 1, 3); }
-        if (q == Q0 + 2) copy_pair1(pc, pbt ^ 1, 4);
-      } else if constexpr (RELU_IN) {
+        if (rp_on) {
+          if (q == Q0) { copy_pair1(pc, pbt ^ 1, 0); copy_pair1(pc, pbt ^ 1, 1); }
+          if (q == Q0 + 1) { copy_pair1(pc, pbt ^ 1, 2); copy_pair1(pc, pbt ^ 1, 3); }
+          if (q == Q0 + 2) copy_pair1(pc, pbt ^ 1, 4);
+        }
+      } else if (RELU_IN && rp_on) {
         // the pair requested an iteration ago is older than this iteration's weight copies so far (five; RAWEARLY: six, quads 0-4)
         if (q == 4) {
           if constexpr (UALL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -756,7 +857,16 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
       if (cw < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     } else if (RAWE && ROLE == 2 && ODD) { }                                  // RAWEARLY: only the raw pair is in flight, and it stays
     else if (RAWE && ROLE < 2 && !ODD) { }                                    // RAWEARLY: no copies of this wave in an even iteration
-    else if (ROLE == 2 && ODD && !UPS) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
+    else if (SHARE && ROLE < 2) {
+      // V(k + 1)'s copies (requested an iteration ago) landed, V(k + 2)'s -- the wave's last 5 / 4 memory instructions -- stay in
+      // flight; without V copies in this iteration: the stores of this iteration's transform may stay in flight (the older ones
+      // are through: a consumer reads them an item later at the earliest), otherwise everything is waited for.  (Loads return
+      // in order among themselves; no wait here assumes an order between loads and stores.)
+      if (vc_on) { if (ROLE == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else if (tr_on) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    else if (ROLE == 2 && ODD && !UPS && rp_on) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // U(g+1) landed; the raw pair stays in flight
     else if (ROLE < 2 && UALL) { }                                           // (nothing of this wave's to wait for)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // U(g+1) (and the raw pair of the iteration before) landed
     lds_barrier();
@@ -768,14 +878,50 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
   typedef std::integral_constant<int, 2> role2_t;
   unsigned long long t2[6] = {0, 0, 0, 0, 0, 0};   // timeline of the workgroup's SECOND item (steady state), trace runs only
   int n_done = 0;
+  typedef std::integral_constant<int, 7> fl_all_t;
   auto k_loop = [&](auto role_tag, auto mma_tag) __attribute__((always_inline)) {
     const bool tr2 = FISR_F4_TRACE && p.trace && n_done == 1;
     if (tr2) t2[0] = __builtin_readcyclecounter();
-    k_iter(role_tag, first_t{}, even_t{}, mma_tag, 0);
-    if (tr2) t2[1] = __builtin_readcyclecounter();
-    k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, 1);
-    if (tr2) t2[2] = __builtin_readcyclecounter();
-    for (int k = 2; k < nch; k += 2) { k_iter(role_tag, rest_t{}, even_t{}, mma_tag, k); k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, k + 1); }
+    if constexpr (!SHARE) {
+      k_iter(role_tag, first_t{}, even_t{}, mma_tag, fl_all_t{}, 0);
+      if (tr2) t2[1] = __builtin_readcyclecounter();
+      k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, fl_all_t{}, 1);
+      if (tr2) t2[2] = __builtin_readcyclecounter();
+      for (int k = 2; k < nch; k += 2) { k_iter(role_tag, rest_t{}, even_t{}, mma_tag, fl_all_t{}, k); k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, fl_all_t{}, k + 1); }
+    } else {
+      // SHARE: the item's iterations are straight-line sequences of bodies with compile-time flags -- one sequence per kind of
+      // item (P -> C, C -> C, C -> P, C -> nothing), picked ONCE per item like the wave's role (a choice per iteration, i.e. a
+      // switch inside the loop, merges the 144 accumulators at every arm: 1800 spilled registers).  Iterations 0 .. nch - 4 run the
+      // item's own kind of body (HF), the last three (T1 T2 T3) hand the streams over to the next item.
+      constexpr int ROLE = decltype(role_tag)::value;
+      auto seq = [&](auto hf, auto tl1, auto tl2, auto tl3) __attribute__((always_inline)) {
+        k_iter(role_tag, first_t{}, even_t{}, mma_tag, hf, 0);
+        if (tr2) t2[1] = __builtin_readcyclecounter();
+        k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, hf, 1);
+        if (tr2) t2[2] = __builtin_readcyclecounter();
+        for (int k = 2; k < nch - 4; k += 2) { k_iter(role_tag, rest_t{}, even_t{}, mma_tag, hf, k); k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, hf, k + 1); }
+        k_iter(role_tag, rest_t{}, even_t{}, mma_tag, hf, nch - 4);
+        k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, tl1, nch - 3);
+        k_iter(role_tag, rest_t{}, even_t{}, mma_tag, tl2, nch - 2);
+        k_iter(role_tag, rest_t{}, odd_t{}, mma_tag, tl3, nch - 1);
+      };
+      typedef std::integral_constant<int, 0> f0_t;
+      typedef std::integral_constant<int, 1> f1_t;      // transform
+      typedef std::integral_constant<int, 2> f2_t;      // V copy
+      typedef std::integral_constant<int, 3> f3_t;      // both (a producer's last but one iteration)
+      typedef std::integral_constant<int, 4> f4_t;      // raw stream
+      const bool cur_p = j_cur == 0, nx_p = has_next && nxt_p, nx_c = has_next && !nxt_p;
+      if constexpr (ROLE < 2) {
+        if (cur_p) seq(f1_t{}, f1_t{}, f3_t{}, f2_t{});                 // P -> C  (share >= 2: a producer is followed by a consumer)
+        else if (nx_c) seq(f2_t{}, f2_t{}, f2_t{}, f2_t{});             // C -> C
+        else if (nx_p) seq(f2_t{}, f2_t{}, f0_t{}, f1_t{});             // C -> P
+        else seq(f2_t{}, f2_t{}, f0_t{}, f0_t{});                       // C, the workgroup's last item
+      } else {
+        if (cur_p) seq(f4_t{}, f0_t{}, f0_t{}, f0_t{});
+        else if (nx_p) seq(f0_t{}, f4_t{}, f4_t{}, f4_t{});
+        else seq(f0_t{}, f0_t{}, f0_t{}, f0_t{});
+      }
+    }
     if (tr2) t2[3] = __builtin_readcyclecounter();
   };
 
@@ -958,10 +1104,21 @@ __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, cons
     if (FISR_F4_TRACE && p.trace && n_done == 1) t2[5] = __builtin_readcyclecounter();
     ++n_done;
     if (!has_next) break;
-    b_cur += gridDim.x;
-    cur = nxt;
-    has_next = b_cur + (int)gridDim.x < n_items;
-    nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
+    if constexpr (SHARE) {
+      cur = nxt;
+      if (nxt_p) { b_cur += gridDim.x; j_cur = 0; } else ++j_cur;
+      if (j_cur + 1 < share) { has_next = true; nxt_p = false; nxt.nblk = cur.nblk + 1; }
+      else {
+        has_next = b_cur + (int)gridDim.x < n_units;
+        nxt_p = true;
+        nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
+      }
+    } else {
+      b_cur += gridDim.x;
+      cur = nxt;
+      has_next = b_cur + (int)gridDim.x < n_items;
+      nxt = has_next ? item_of(b_cur + gridDim.x) : cur;
+    }
   }
   };
   if constexpr (GENERAL) {
@@ -1034,6 +1191,14 @@ inline bool wf4_fits_general(int h, int w, int c0, int in_cs, int out_cs) {
 // more of a small map than the 8 x 32 ones of conv3x3_wino8p.h -- but 1.04x / 1.4x on the 512-channel 34 x 62 / 17 x 31 maps,
 // where the K loop is long enough to pay for the padding)
 inline bool wf4_wins(int h, int w, int cin) { return (h >= 48 && w >= 64) || cin >= 512; }
+// SHARE instantiations (r05): `share` consecutive N blocks of a tile per run, whole quadruples of chunks per item (the consumers' ring),
+// one slice of V scratch per workgroup: wf4_vscr_bytes() for the largest grid the launcher uses
+inline bool wf4_share_fits(int c0, int c1, int cout, int share) {
+  const int nch = (c0 + c1) / F4_CH, nb = cout / F4_BN;
+  return share >= 2 && nch % 4 == 0 && nch >= 8 && cout % F4_BN == 0 && nb % share == 0;
+}
+constexpr int F4_MAX_GRID = 256;
+inline size_t wf4_vscr_bytes(int c0, int c1) { return (size_t)F4_MAX_GRID * ((c0 + c1) / F4_CH) * F4_V_BYTES; }
 
 // The F(4x4,3x3) Winograd kernel (conv3x3_wf4.h; fp32, FISRnet's dense layers only; a.wpk = the conv's d_wu4).
 inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
@@ -1087,6 +1252,37 @@ inline hipError_t launch_conv_wf4(const ConvArgs& a, hipStream_t st) {
   // one workgroup per CU (the kernel needs most of a CU's LDS and half its registers), a multiple of 8 so that the items of a
   // workgroup stay on one XCD
   const int grid = std::min(items, std::max(8, n_cu[dev] & ~7));
+#ifndef FISR_F4_SHARE
+  if (a.share >= 2) return hipErrorInvalidValue;      // (the SHARE instantiations are built into scripts/probes/wf4_bench only: see the kernel's header)
+#else
+  if (a.share >= 2) {
+    // V sharing: runs of a.share N blocks; the grid counts runs
+    if (!a.vscr || a.ups || !wf4_share_fits(a.C0, a.C1, a.Cout, a.share)) return hipErrorInvalidValue;
+    static bool sattr[64] = {};
+    if (!sattr[dev]) {
+      const void* sk[] = {reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, false, false, false, false, true>),
+                          reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true, false, false, false, true>),
+                          reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, false, false, false, false, true>),
+                          reinterpret_cast<const void*>(conv3x3_wf4_kernel<true, true, false, false, false, true>),
+                          reinterpret_cast<const void*>(conv3x3_wf4_kernel<false, true, true, false, false, true>)};
+      for (const void* k : sk) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      sattr[dev] = true;
+    }
+    const int sgrid = std::min(items / a.share, std::min(F4_MAX_GRID, std::max(8, n_cu[dev] & ~7)));
+    if (a.pool_out) hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true, true, false, false, true>), dim3(sgrid), dim3(512), lds, st, a, items);
+    else if (a.relu_in) {
+      if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<true, true, false, false, false, true>), dim3(sgrid), dim3(512), lds, st, a, items);
+      else hipLaunchKernelGGL((conv3x3_wf4_kernel<true, false, false, false, false, true>), dim3(sgrid), dim3(512), lds, st, a, items);
+    } else {
+      if (a.res) hipLaunchKernelGGL((conv3x3_wf4_kernel<false, true, false, false, false, true>), dim3(sgrid), dim3(512), lds, st, a, items);
+      else hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false, false, false, false, true>), dim3(sgrid), dim3(512), lds, st, a, items);
+    }
+    return hipGetLastError();
+  }
+#endif
   if (a.ups) {
     hipLaunchKernelGGL((conv3x3_wf4_kernel<false, false, false, true>), dim3(grid), dim3(512), wf4_lds_bytes_ups(), st, a, items);
   } else if (a.pool_out) {

@@ -31,6 +31,46 @@ from . import tiling
 PB = tiling.PATCH_BOUNDARY
 
 
+# xGMI on an MI355X node: a fully connected mesh, 7 links per GPU, ~153 GB/s per link counting both directions (the figure this
+# code base plans with; no link counter has been read on hardware yet) -> ~76 GB/s into one GPU from one peer.
+XGMI_LINK_GBPS_BIDIR = 153.0
+XGMI_LINKS_PER_GPU = 7
+
+
+def collective_plan(parallelism: str, num_patch: Tuple[int, int], world: int, rank: int, h: int, w: int, windows: int = 3,
+                    sf: int = 2, gather: bool = True, want_rgb: bool = True, pb: int = PB):
+    """What ONE step (one 5-frame stack: `windows` windows of the cropped h x w LR frame) puts on the links, for `rank`: a list of
+    {"collective", "group_size", "send_bytes", "recv_bytes", "link_ms_direct", "link_ms_ring"} -- bytes this rank sends / receives
+    per step and the time the slowest link is busy with them, for the two schedules RCCL may pick: every peer over its own
+    link at once ("direct": bytes of the largest single peer-to-peer piece / one direction of a link) and a ring
+    ((group_size - 1) hops of one piece each).  Pure arithmetic: `bench.py --dry-run` prints it next to the compute time, so the
+    first run on a node has a number to be compared with (FISRnet.py:798-799, 847-880 are the units being moved)."""
+    one_way = XGMI_LINK_GBPS_BIDIR / 2 * 1e9
+    out = []
+    if world <= 1:
+        return out
+    if parallelism == "frame":
+        if gather:
+            piece = windows * (h * sf) * (w * sf) * 9                   # the uint8 YUV frames of the rank's stack
+            out.append({"collective": "gather of the uint8 output frames to rank 0 (AsyncGather, side stream)", "group_size": world,
+                        "send_bytes": 0 if rank == 0 else piece, "recv_bytes": (world - 1) * piece if rank == 0 else 0,
+                        # every sender has its own link into rank 0: the links work side by side
+                        "link_ms_direct": round(piece / one_way * 1e3, 3), "link_ms_ring": round((world - 1) * piece / one_way * 1e3, 3),
+                        "note": "rank 0 takes %d x %.1f MB per step over %d of its %d links" % (world - 1, piece / 1e6, min(world - 1, XGMI_LINKS_PER_GPU), XGMI_LINKS_PER_GPU)})
+        return out
+    if parallelism != "tile":
+        raise ValueError("parallelism must be 'frame' or 'tile'")
+    T = num_patch[0] * num_patch[1]
+    sH, sW = h // num_patch[0], w // num_patch[1]
+    ring = windows * (2 * pb * sW + 2 * sH * pb) * 29 * 4               # border_ring() of the rank's cores, float32
+    tile = windows * (sH * sf) * (sW * sf) * (18 if want_rgb else 9)    # trimmed uint8 tile(s): YUV (+ RGB)
+    for name, piece in (("all-gather of the 32-px input halo rings inside the tile group (HaloPrefetcher, under the previous forward)", ring),
+                        ("all-gather of the trimmed uint8 output tiles inside the tile group", tile)):
+        out.append({"collective": name, "group_size": T, "send_bytes": piece, "recv_bytes": (T - 1) * piece,
+                    "link_ms_direct": round(piece / one_way * 1e3, 3), "link_ms_ring": round((T - 1) * piece / one_way * 1e3, 3)})
+    return out
+
+
 def shard_units(n_units: int, world: int, rank: int) -> List[int]:
     """Round-robin assignment of independent units (windows / stacks) to ranks."""
     if not 0 <= rank < world:

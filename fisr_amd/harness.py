@@ -3,6 +3,9 @@
   run_test            <-> FISRnet.test            (FISRnet.py:746-935)
   run_fisr_for_video  <-> FISRnet.FISR_for_video  (FISRnet.py:937-1084)
   warp_img            <-> FISR_for_video_Warp_Img (FISR_tfoptflow/FISR_for_video_warp_img_with_flo.py:97-151)
+  prepare_scene_set   <-> the two pre-processing scripts that make `--phase test`'s inputs for a folder of 5-frame scenes:
+                          FISR_tfoptflow/FISR_pwcnet_predict_from_img_test.py:84-147 (flow, [N_scenes, 8/ss, H, W, 2] .flo) and
+                          FISR_tfoptflow/FISR_warp_mat_with_flo.py:95-129 (warped frames, [N_scenes, 8/ss, H, W, 3] HDF5 .mat)
 
 Everything between "frames are on the GPU" and "uint8 predictions come back" runs in
 libfisr_hip.so kernels (pack -> tiled forward -> stitch -> clip/quantise/colour -> SSE).  PNG
@@ -98,12 +101,33 @@ def compute_flow(net, args, rank: int = 0, world: int = 1, return_array: bool = 
     the clip (the process group's watchdog would abort a long one), and nobody re-reads the file, so the ranks need no shared
     file system."""
     import torch
-    from . import pwcnet
     paths = sorted_pngs(args.frame_folder_path)
     h, w = args.FISR_input_size
     num_fr = args.frame_num
     if len(paths) < num_fr:
         raise FileNotFoundError(f"{args.frame_folder_path}: {len(paths)} frames, need {num_fr}")
+    pwc = open_pwc(net, args)
+    try:
+        if world <= 1:
+            frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[:num_fr]]
+            pred = pwc.compute_flow(frames).cpu().numpy()
+        else:
+            pred = _gather_pair_flows(pwc, paths, h, w, num_fr, rank, world, net.device)
+    finally:
+        pwc.close()
+    print(pred.shape)
+    name = flow_file_name(args)
+    if rank == 0:
+        tmp = name + ".tmp%d" % os.getpid()
+        fio.write_flow(pred, tmp)
+        os.replace(tmp, name)                  # atomic: a concurrent reader sees the old file or the whole new one
+    return (name, pred) if return_array else name
+
+
+def open_pwc(net, args):
+    """The flow estimator of the pre-processing scripts (ModelPWCNet(mode='test'), script :84-102) on net's device: weights from
+    `--pwc_ckpt` (TF bundle prefix or .npz) or seeded stand-ins with `--synthetic_weights`; the caller closes it."""
+    from . import pwcnet
     pwc = pwcnet.PWCNet(str(net.device), precision=getattr(args, "flow_precision", "fp32") or "fp32")
     try:
         if getattr(args, "synthetic_weights", None) is not None:
@@ -114,30 +138,106 @@ def compute_flow(net, args, rank: int = 0, world: int = 1, return_array: bool = 
                 raise FileNotFoundError(f"PWC-Net weights not found at {ck!r} (the reference downloads them separately, "
                                         "script :31); pass --pwc_ckpt, --flow_file or --synthetic_weights")
             pwc.load(ck)
-        if world <= 1:
-            frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[:num_fr]]
-            pred = pwc.compute_flow(frames).cpu().numpy()
-        else:
-            import torch.distributed as dist
-            mine = {}
-            for pair in range(rank, num_fr - 1, world):
-                fr = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[pair:pair + 2]]
-                mine[pair] = pwc.compute_flow(fr).cpu().numpy()[0]            # [2, h, w, 2]
-            parts = [None] * world
-            dist.all_gather_object(parts, mine)
-            allp = {}
-            for d in parts:
-                allp.update(d)
-            pred = np.stack([allp[p] for p in range(num_fr - 1)], axis=0)
-    finally:
+    except BaseException:
         pwc.close()
-    print(pred.shape)
-    name = flow_file_name(args)
-    if rank == 0:
-        tmp = name + ".tmp%d" % os.getpid()
-        fio.write_flow(pred, tmp)
-        os.replace(tmp, name)                  # atomic: a concurrent reader sees the old file or the whole new one
-    return (name, pred) if return_array else name
+        raise
+    return pwc
+
+
+def _gather_pair_flows(pwc, paths, h, w, num_fr, rank, world, device):
+    """Multi-rank flow of a clip: pair p is computed on rank p % world; every rank ends up with [num_fr-1, 2, h, w, 2].
+    The exchange is one float32 tensor per pair, broadcast from its owner into a preallocated array (no pickling, no
+    world x max_size staging buffer -- ADVICE r04), behind an all-reduced ok flag: a rank whose share failed (unreadable PNG,
+    out of memory) makes EVERY rank raise instead of leaving the others blocked in the collective."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = dist.get_backend() == "nccl"
+    comm_dev = device if on_gpu else torch.device("cpu")
+    mine, err = {}, None
+    try:
+        for pair in range(rank, num_fr - 1, world):
+            fr = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])) for p in paths[pair:pair + 2]]
+            mine[pair] = pwc.compute_flow(fr)[0]                              # [2, h, w, 2] on the device
+    except Exception as e:                                                    # noqa: BLE001 -- reported to every rank below
+        err = e
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=comm_dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        raise RuntimeError(f"compute_flow: rank {rank} " + (f"failed: {err!r}" if err is not None else "stops because another rank failed"))
+    pred = np.empty((num_fr - 1, 2, h, w, 2), np.float32)
+    buf = torch.empty((2, h, w, 2), dtype=torch.float32, device=comm_dev)
+    for pair in range(num_fr - 1):
+        owner = pair % world
+        if owner == rank:
+            buf.copy_(mine.pop(pair))
+        dist.broadcast(buf, src=owner)
+        pred[pair] = buf.cpu().numpy()
+    return pred
+
+
+def scene_set_pairs(n_seq: int, ss: int):
+    """The frame pairs one scene contributes at temporal stride ss (flow script :121-128, warp script :112-114):
+    seq = 0 .. n_seq - 2 ss, frames (ss seq, ss (seq + 1)); entry 2 seq is "1 -> 2", entry 2 seq + 1 is "2 -> 1"."""
+    if ss not in (1, 2):
+        raise ValueError("temporal stride ss must be 1 or 2 (main.py:38-44: the ss1 / ss2 files)")
+    return [(ss * seq, ss * (seq + 1)) for seq in range(n_seq - (ss * 2 - 1))]
+
+
+def prepare_scene_set(net, args, ss: int = 1, data_path=None, flow_path=None, warp_path=None, n_seq: int = 5, pwc=None,
+                      write: bool = True):
+    """The reference's two pre-processing scripts for a folder of `n_seq`-frame scenes (natural-sorted YUV PNGs, README.md:38-55),
+    both on the GPU:
+
+      flow  FISR_tfoptflow/FISR_pwcnet_predict_from_img_test.py:84-147: PWC-Net-large on the x2 up-resized RGB pair in both
+            directions, resized back with anti-aliasing and halved -> pred[num, 2 seq] (frame ss seq -> ss (seq + 1)) and
+            pred[num, 2 seq + 1] (the reverse), float32 [N_scenes, 8 / ss, h, w, 2], written by `write_flow` (script :57-81);
+      warp  FISR_tfoptflow/FISR_warp_mat_with_flo.py:95-129: pred[num, 2 seq] = RGB2YUV(remap(YUV2RGB(frame ss (seq + 1)),
+            0.5 flow[num, 2 seq])), pred[num, 2 seq + 1] = the same of frame ss seq with flow[num, 2 seq + 1], float32 0..255
+            [N_scenes, 8 / ss, h, w, 3], written as the MATLAB-compatible HDF5 `.mat` hdf5storage makes (script :131-136; `.npy` too).
+
+    The scripts' paths are edited by hand ("# check" marks); here they default to `--test_data_path`, `--test_flow_data_path` and
+    `--test_warped_data_path` (with `ss1` -> `ss2` in the two file names for ss = 2: main.py:36-44's naming).  Unlike the scripts'
+    unsorted `glob.glob` the file list is natural-sorted.  Returns (flow, warp, flow_path, warp_path); the arrays
+    are what was written, bit for bit."""
+    import torch
+    data_path = data_path or net.test_data_path
+    flow_path = flow_path or (net.test_flow_data_path if ss == 1 else net.test_flow_data_path.replace("ss1", "ss2"))
+    warp_path = warp_path or (net.test_warped_data_path if ss == 1 else net.test_warped_data_path.replace("ss1", "ss2"))
+    paths = sorted_pngs(data_path)
+    n_scenes = len(paths) // n_seq
+    if n_scenes == 0:
+        raise FileNotFoundError(f"{data_path}: {len(paths)} PNG frames, need at least one scene of {n_seq}")
+    h, w = net.test_input_size
+    pairs = scene_set_pairs(n_seq, ss)
+    flow = np.zeros((n_scenes, 2 * len(pairs), h, w, 2), np.float32)           # (script :117: 8 // ss entries)
+    warp = np.zeros((n_scenes, 2 * len(pairs), h, w, 3), np.float32)
+    own = pwc is None
+    if own:
+        pwc = open_pwc(net, args)
+    try:
+        for num in range(n_scenes):
+            scene = paths[num * n_seq:(num + 1) * n_seq]
+            frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])).to(net.device) for p in scene[::ss]]
+            if frames[0].shape[0] < h or frames[0].shape[1] < w:
+                raise ValueError(f"{scene[0]}: {tuple(frames[0].shape[:2])} is smaller than --test_input_size {h}x{w}")
+            f = pwc.compute_flow(frames[:len(pairs) + 1])                        # [pairs, 2, h, w, 2]: [seq, 0] = 1 -> 2, [seq, 1] = 2 -> 1
+            flow[num] = f.reshape(2 * len(pairs), h, w, 2).cpu().numpy()
+            for seq in range(len(pairs)):
+                warp[num, 2 * seq] = net.warp(frames[seq + 1], f[seq, 0]).cpu().numpy()
+                warp[num, 2 * seq + 1] = net.warp(frames[seq], f[seq, 1]).cpu().numpy()
+            print(num)                                                           # (script :139, warp script :125)
+    finally:
+        if own:
+            pwc.close()
+    print(flow.shape)
+    if write:
+        for name, arr, writer in ((flow_path, flow, lambda a, fn: fio.write_flow(a, fn)), (warp_path, warp, lambda a, fn: fio.write_warp_file(fn, a))):
+            os.makedirs(os.path.dirname(os.path.abspath(name)), exist_ok=True)
+            root, ext = os.path.splitext(name)
+            tmp = root + ".tmp%d" % os.getpid() + ext                            # (the extension picks the container)
+            writer(arr, tmp)
+            os.replace(tmp, name)
+    return flow, warp, flow_path, warp_path
 
 
 def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_test_in_seq, H, W, num_patch):
@@ -161,10 +261,18 @@ def run_test(net):
         raise FileNotFoundError(f"no checkpoint under {os.path.join(net.checkpoint_dir, net.model_dir)}")
     data_paths = sorted_pngs(net.test_data_path)
     label_paths = sorted_pngs(net.test_label_path)
-    print(" Start to read flow data (test).")
-    flow = fio.read_flo_file_5dim(net.test_flow_data_path)        # [N_scenes, 8, H, W, 2]
-    print(" Start to read warped data (test).")
-    warp = fio.read_warp_file(net.test_warped_data_path, "pred")  # [N_scenes, 8, H, W, 3] 0..255
+    prepare = getattr(net.args, "prepare", "auto")
+    neither = not os.path.isfile(net.test_flow_data_path) and not os.path.isfile(net.test_warped_data_path)
+    if prepare == "always" or (prepare == "auto" and neither):
+        # neither pre-made file exists (or --prepare always): make both on the GPU from the scene folder, as the reference's two
+        # pre-processing scripts do, and continue with the arrays that were written
+        print(" Start to make flow and warped data (test) on the GPU.")
+        flow, warp, _, _ = prepare_scene_set(net, net.args, ss=1)
+    else:
+        print(" Start to read flow data (test).")
+        flow = fio.read_flo_file_5dim(net.test_flow_data_path)        # [N_scenes, 8, H, W, 2]
+        print(" Start to read warped data (test).")
+        warp = fio.read_warp_file(net.test_warped_data_path, "pred")  # [N_scenes, 8, H, W, 3] 0..255
     num_patch = tuple(net.test_patch)
     H, W = net.test_input_size
     sf = net.scale_factor
@@ -222,6 +330,10 @@ def run_test(net):
     print("######### Test (average) test_SSIM: FISR %.8f, SR %.8f #########" % (res["FISR_SSIM"], res["SR_SSIM"]))
     print("######### (extra) Y-channel-only test_PSNR: FISR %.8f[dB], SR %.8f[dB]  #########" % (res["FISR_PSNR_Y"], res["SR_PSNR_Y"]))
     print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % res["inference_time_per_frame"])
+    # (what is timed differs from the reference's sess.run of ONE tile, FISRnet.py:868-874: here a tile's share of one batched
+    #  fisr_forward_frames call -- input assembly, tile cut and level inputs included -- times the tiles of a frame)
+    res["inference_time_is"] = "tile's share of a batched fisr_forward_frames call (input assembly included) x tiles per frame"
+    print("#########   (timed: %s)  #########" % res["inference_time_is"])
     return res
 
 

@@ -16,6 +16,9 @@ Differences from the reference, all deliberate:
     './models/pwcnet-lg-6-2-multisteps-chairsthingsmix/pwcnet.ckpt-595000') or seeded stand-ins with
     `--synthetic_weights`; the flow is written as the reference's 5-D `.flo` next to the frames.  `--flow_file` skips
     the estimator and uses a pre-computed file.  The frame warp (main.py:213) runs on the GPU too.
+  * `--phase test` makes its own `.flo` / `_warp.mat` when neither exists (`--prepare auto|always|never|only`, `--prepare_ss`):
+    the reference's two pre-processing scripts (FISR_pwcnet_predict_from_img_test.py:84-147, FISR_warp_mat_with_flo.py:95-129)
+    on the GPU, for the scene folder `--test_data_path`.
   * extra flags: `--precision {fp32,bf16x3,f16f8,fp16}` (default fp32, the reference's arithmetic),
     `--device`, `--synthetic_weights SEED`, `--no_batch_tiles` (one tile per forward, the reference's
     schedule: smallest workspace).
@@ -100,6 +103,11 @@ def parse_args(argv=None):
                    help="--phase test: compare the four averages with the figures the reference publishes for its pre-trained "
                         "weights on its 4K test set (README.md:97: PSNR 37.86 / 48.07 dB, SSIM 0.9743 / 0.9921) within the "
                         "tolerance of BASELINE.json (+-0.02 dB, 1e-3 SSIM); exit status 4 if any of them is outside")
+    p.add_argument("--prepare", type=str, default="auto", choices=["auto", "always", "never", "only"],
+                   help="--phase test: make --test_flow_data_path / --test_warped_data_path from the scene folder --test_data_path on the "
+                        "GPU (the reference's FISR_pwcnet_predict_from_img_test.py + FISR_warp_mat_with_flo.py): 'auto' = when neither "
+                        "file exists, 'always', 'never', 'only' = make the files (also the ss2 pair with --prepare_ss 2) and stop")
+    p.add_argument("--prepare_ss", type=int, default=1, choices=[1, 2], help="temporal stride of --prepare only (ss1 / ss2 files)")
     p.add_argument("--no_batch_tiles", dest="batch_tiles", action="store_false",
                    help="run the tiles of a window one forward at a time (reference schedule, smallest workspace)")
     p.add_argument("--device", type=str, default=None, help="default cuda:<LOCAL_RANK>")
@@ -192,6 +200,11 @@ def main(argv=None):
     if args.synthetic_weights is not None:
         net.set_weights(weights.synthetic_weights(args.synthetic_weights))
     if args.phase == "test":
+        if args.prepare == "only":
+            _, _, fp, wp = harness.prepare_scene_set(net, args, ss=args.prepare_ss)
+            print(" [*] Flow file saved: %s" % fp)
+            print(" [*] Warp file saved: %s" % wp)
+            return 0
         res = net.test()
         print(" [*] Test finished!")
         if getattr(args, "check_published", False):

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #define FISR_F4_TRACE 1
+#define FISR_F4_SHARE 1      // the V-sharing instantiations (r05: measured, not in the product)
 #define FISR_F4X_TRACE 1
 #include "conv3x3_wf4.h"
 #include "diag/conv3x3_wf4x.h"
@@ -102,6 +103,14 @@ int main(int argc, char** argv) {
     a.C0 = ci; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = co; a.CoutPad = co;
     a.in0_cs = ics; a.rec_cs = ocs; a.dil = dil;
     a.relu_in = fl & 1; a.relu_out = (fl >> 1) & 1; a.d2s = 0; a.ups = ups;
+    // WF4_SHARE=n: the V-sharing instantiations (runs of n N blocks; r05) where the shape takes them; `check` then also compares
+    // the output bit for bit with the plain instantiation's.  flags bit 2 (4): fused 2x2 pooling (needs res)
+    const int share_env = getenv("WF4_SHARE") ? atoi(getenv("WF4_SHARE")) : 0;
+    const int share = share_env >= 2 && !ups && wf4_share_fits(ci, 0, co, share_env) ? share_env : 0;
+    void* d_vscr = nullptr;
+    float* d_pool = nullptr;
+    if (share) { CK(hipMalloc(&d_vscr, wf4_vscr_bytes(ci, 0))); CK(hipMemset(d_vscr, 0xff, wf4_vscr_bytes(ci, 0))); a.vscr = d_vscr; a.share = share; }
+    if ((fl & 4) && rs) { CK(hipMalloc(&d_pool, out_e)); a.pool_out = d_pool; }
     const int items = ((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n * (co / F4_BN);
     unsigned long long* d_tr;
     const size_t tr_rows = (size_t)items + 256 * 9;
@@ -122,7 +131,30 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(r.data(), d_ref, out_e * 4, hipMemcpyDeviceToHost));
       double mx = 0, ss = 0; size_t bad = 0;
       for (size_t i = 0; i < out_e; ++i) { double d = fabs((double)o[i] - r[i]); if (!(d <= 1e-3)) ++bad; if (d > mx) mx = d; ss += d * d; }
-      printf("check %dx%dx%d %d->%d f%d r%d: max %.3e rms %.3e bad %zu %s\n", n, h, w, ci, co, fl, rs, mx, sqrt(ss / out_e), bad, bad ? "FAIL" : "ok");
+      printf("check %dx%dx%d %d->%d f%d r%d share %d: max %.3e rms %.3e bad %zu %s\n", n, h, w, ci, co, fl, rs, share, mx, sqrt(ss / out_e), bad, bad ? "FAIL" : "ok");
+      if (share) {      // bit-identical to the plain instantiation (same V, same MFMAs in the same order)?
+        ConvArgs b = a;
+        b.share = 0; b.vscr = nullptr;
+        float* d_pool2 = nullptr;
+        std::vector<float> pl1, pl2;
+        if (d_pool) { pl1.resize(out_e / 4); pl2.resize(out_e / 4); CK(hipMemcpy(pl1.data(), d_pool, out_e, hipMemcpyDeviceToHost)); CK(hipMalloc(&d_pool2, out_e)); b.pool_out = d_pool2; }
+        for (int rep_ = 0; rep_ < 3; ++rep_) {
+          CK(hipMemset(d_out, 0xff, out_e * 4));
+          CK(launch_any(rep_ == 0 ? b : a, nullptr));
+          CK(hipDeviceSynchronize());
+          std::vector<float> o2(out_e);
+          CK(hipMemcpy(o2.data(), d_out, out_e * 4, hipMemcpyDeviceToHost));
+          size_t diff = 0, firstd = 0;
+          for (size_t i = 0; i < out_e; ++i) if (memcmp(&o2[i], &o[i], 4)) { if (!diff) firstd = i; ++diff; }
+          printf("    %s vs first shared launch: %zu of %zu words differ%s\n", rep_ == 0 ? "plain instantiation" : "shared launch again", diff, out_e, diff ? "  FAIL" : "  (bit-identical)");
+          if (diff) { size_t i = firstd; const int c = i % co; size_t pp = i / co; const int x = pp % w; pp /= w; printf("      first at [n %zu y %zu x %d c %d] %g vs %g\n", pp / h, pp % h, x, c, o2[i], o[i]); }
+          if (rep_ == 0 && d_pool) {
+            CK(hipMemcpy(pl2.data(), d_pool2, out_e, hipMemcpyDeviceToHost));
+            printf("    pooled map: %s\n", memcmp(pl1.data(), pl2.data(), out_e) ? "DIFFERS  FAIL" : "bit-identical");
+          }
+        }
+        if (d_pool2) CK(hipFree(d_pool2));
+      }
       if (bad) {      // which channels / rows / columns are wrong
         std::vector<size_t> bc(co, 0), by(h, 0), bx(w, 0);
         int shown = 0;
@@ -187,6 +219,8 @@ int main(int argc, char** argv) {
     }
     CK(hipFree(d_in)); CK(hipFree(d_out)); CK(hipFree(d_b)); CK(hipFree(d_wp)); CK(hipFree(d_tr));
     if (d_res) CK(hipFree(d_res));
+    if (d_vscr) CK(hipFree(d_vscr));
+    if (d_pool) CK(hipFree(d_pool));
   }
   return 0;
 }

@@ -413,3 +413,97 @@ def test_tf_bundle_checkpoint_loads_on_the_gpu_path_table_layout_unpinned(tmp_pa
     with pytest.raises(KeyError):
         net2.load(str(tmp_path / "ck2"))
     net2.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# r05: `--phase test` makes its own pre-made files (the reference's two pre-processing scripts on the GPU)
+def _prep_args(r, out, extra=()):
+    return fmain.parse_args([
+        "--phase", "test", "--test_data_path", str(r / "LR_LFR"), "--test_label_path", str(r / "HR_HFR"),
+        "--test_flow_data_path", str(out / "flow" / "LR_set_test_ss1.flo"), "--test_warped_data_path", str(out / "warped" / "LR_set_test_ss1_warp.mat"),
+        "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(out / "img"),
+        "--text_dir", str(out / "text"), "--log_dir", str(out / "log"),
+        "--test_patch", "2,2", "--test_input_size", f"{S3},{S3}", "--synthetic_weights", "7", *extra])
+
+
+@pytest.mark.parametrize("ss", [1, 2])
+def test_prepare_scene_set_files_round_trip_and_index_like_the_scripts(scenes10, tmp_path, ss):
+    """FISR_pwcnet_predict_from_img_test.py:84-147 + FISR_warp_mat_with_flo.py:95-129 for a folder of ten 5-frame scenes:
+    [N_scenes, 8 / ss, H, W, 2] .flo and [N_scenes, 8 / ss, H, W, 3] HDF5 .mat.  The files read back (io.read_flo_file_5dim /
+    read_warp_file) equal the in-memory arrays bit for bit, and entry [num, 2 seq + d] is the flow / the warp of the scripts' pair
+    (frame ss seq, frame ss (seq + 1)) in direction d, recomputed here pair by pair through the estimator and the warp kernel."""
+    from fisr_amd import harness
+    from fisr_amd.fisrnet import FISRnet
+    r = scenes10["root"]
+    args = _prep_args(r, tmp_path, ["--prepare", "only", "--prepare_ss", str(ss)])
+    net = FISRnet(args)
+    flow, warp, fp, wp = harness.prepare_scene_set(net, args, ss=ss)
+    n_ent = 8 // ss
+    assert flow.shape == (N_SCENES, n_ent, S3, S3, 2) and warp.shape == (N_SCENES, n_ent, S3, S3, 3)
+    assert flow.dtype == np.float32 and warp.dtype == np.float32
+    assert ("ss%d" % ss) in os.path.basename(fp) and ("ss%d" % ss) in os.path.basename(wp)       # main.py:36-44's naming
+    f_back = fio.read_flo_file_5dim(fp)
+    w_back = fio.read_warp_file(wp, "pred")
+    assert f_back.dtype == np.float32 and np.array_equal(f_back.view(np.uint32), flow.view(np.uint32))
+    assert w_back.shape == warp.shape and np.array_equal(w_back.view(np.uint32), warp.view(np.uint32))
+    assert 0.0 <= warp.min() and warp.max() <= 255.0 and np.isfinite(flow).all() and float(np.abs(flow).max()) > 0
+    # the scripts' indexing, pair by pair (scenes 0, 3 and 9)
+    paths = harness.sorted_pngs(str(r / "LR_LFR"))
+    assert harness.scene_set_pairs(5, ss) == ([(0, 1), (1, 2), (2, 3), (3, 4)] if ss == 1 else [(0, 2), (2, 4)])
+    pwc = harness.open_pwc(net, args)
+    try:
+        for num in (0, 3, 9):
+            for seq, (a, b) in enumerate(harness.scene_set_pairs(5, ss)):
+                fa = torch.from_numpy(fio.read_png(paths[num * 5 + a])).cuda()
+                fb = torch.from_numpy(fio.read_png(paths[num * 5 + b])).cuda()
+                fab, fba = pwc.flow_pair(fa, fb)
+                # (the batched decoder of flow_stack and the pair call run the same kernels on other batch shapes: equal to rounding)
+                assert float((fab.cpu() - torch.from_numpy(flow[num, 2 * seq])).abs().max()) < 2e-3
+                assert float((fba.cpu() - torch.from_numpy(flow[num, 2 * seq + 1])).abs().max()) < 2e-3
+                w12 = net.warp(fb, torch.from_numpy(flow[num, 2 * seq]).cuda()).cpu().numpy()         # "1 -> 2": frame 2 by half the flow 1 -> 2
+                w21 = net.warp(fa, torch.from_numpy(flow[num, 2 * seq + 1]).cuda()).cpu().numpy()
+                assert np.array_equal(w12, warp[num, 2 * seq]) and np.array_equal(w21, warp[num, 2 * seq + 1])
+    finally:
+        pwc.close()
+    # ... and against the oracle's remap on one entry (cv2 semantics as oracle/fisr_oracle.py restates them)
+    ref = O.warp_frame(fio.read_png(paths[0 * 5 + ss]), flow[0, 0])
+    assert np.abs(ref.astype(np.float64) - warp[0, 0]).max() <= 3.1e-5         # <= 1 ulp of float32 at 255 (tests/test_gpu_parity.py)
+    net.close()
+
+
+def test_phase_test_prepares_its_own_files_and_scores_the_same(scenes10, tmp_path, capsys):
+    """`--phase test` with neither pre-made file present makes both (--prepare auto) and prints the same four averages as a second
+    run that READS the files it left behind (--prepare never); `--prepare only` through the CLI entry leaves the same files."""
+    from fisr_amd.fisrnet import FISRnet
+    r = scenes10["root"]
+    args = _prep_args(r, tmp_path)
+    assert args.prepare == "auto" and not os.path.exists(args.test_flow_data_path) and not os.path.exists(args.test_warped_data_path)
+    net = FISRnet(args)
+    res_a = net.test()
+    out_a = capsys.readouterr().out
+    net.close()
+    assert "Start to make flow and warped data (test) on the GPU." in out_a and out_a.count(" <Test> [") == 3 * N_SCENES
+    assert os.path.isfile(args.test_flow_data_path) and os.path.isfile(args.test_warped_data_path)
+    flo_bytes = open(args.test_flow_data_path, "rb").read()
+    args_b = _prep_args(r, tmp_path, ["--prepare", "never"])
+    net = FISRnet(args_b)
+    res_b = net.test()
+    out_b = capsys.readouterr().out
+    net.close()
+    assert "Start to read flow data (test)." in out_b and "on the GPU" not in out_b
+    for k in ("FISR_PSNR", "SR_PSNR", "FISR_SSIM", "SR_SSIM"):
+        assert res_a[k] == res_b[k], (k, res_a[k], res_b[k])
+    line = [l for l in out_a.splitlines() if "Test (average)" in l]
+    assert line and line == [l for l in out_b.splitlines() if "Test (average)" in l]
+    # the CLI entry: --prepare only rewrites the same flow file and stops before the network runs
+    rc = fmain.main(["--phase", "test", "--prepare", "only"] + [a for a in _cli_list(r, tmp_path)])
+    out_c = capsys.readouterr().out
+    assert rc == 0 and "Flow file saved" in out_c and " <Test> [" not in out_c
+    assert open(args.test_flow_data_path, "rb").read() == flo_bytes
+
+
+def _cli_list(r, out):
+    return ["--test_data_path", str(r / "LR_LFR"), "--test_label_path", str(r / "HR_HFR"),
+            "--test_flow_data_path", str(out / "flow" / "LR_set_test_ss1.flo"), "--test_warped_data_path", str(out / "warped" / "LR_set_test_ss1_warp.mat"),
+            "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(out / "img"), "--text_dir", str(out / "text"),
+            "--log_dir", str(out / "log"), "--test_patch", "2,2", "--test_input_size", f"{S3},{S3}", "--synthetic_weights", "7"]
