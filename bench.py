@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 from bench_report import (DTYPE, FLOP_PER_LR_PX, HBM_PEAK_GBPS, PEAK, UNIQUE_PER_STACK, cfg5_pipeline, cpu_baselines,
-                          executed_per_algorithmic, memory_plan, oracle_tile_check, roofline_pass, time_training_step, time_warp,
+                          executed_per_algorithmic, expected_step_ms, memory_plan, oracle_tile_check, roofline_pass, time_training_step, time_warp,
                           _pmc_key, _pmc_passes, _pmc_same_population)      # noqa: F401 -- (the last three: tests/test_host.py reaches them through this module)
 
 
@@ -242,23 +242,37 @@ def main():
     # ---- memory plan of this rank ("be right the first time a node shows up"): what the step will hold on the device,
     #      against what the device has.  A plan that does not fit is refused HERE, with numbers, on every rank -- not by an
     #      out-of-memory error inside the third collective of the first step.
-    plan = memory_plan(torch, net, dev, patch, args.batch, parallelism, topo, world if (parallelism == "frame" and not args.no_gather) else 1, rank,
-                       weight_bytes)
+    gather_on = parallelism == "frame" and not args.no_gather
+    plan = memory_plan(torch, net, dev, patch, args.batch, parallelism, topo, world if gather_on else 1, rank, weight_bytes, args.input_path)
+    # ... and what one step puts on the xGMI links, per collective, with the time the busiest link needs for it (fisr_amd/dist.py
+    # collective_plan: pure arithmetic) -- printed next to the compute time of a step so that the first run on a node has an
+    # expectation to be held against
+    from fisr_amd import tiling as _tiling
+    ph, pw = _tiling.crop_hw(1080, 1920, patch)
+    plan["collectives_per_step"] = fdist.collective_plan(parallelism, patch, world, rank, ph, pw, gather=gather_on)
     plans = [plan]
     if world > 1:
         plans = [None] * world
         dist.all_gather_object(plans, plan)
-    bad = [q for q in plans if not q["fits"]]
+    # --dry-run judges the plan against the device's size; a real run is refused only when the plan exceeds what is FREE on the
+    # device right now (and merely warned about a plan that is large for the device)
+    bad = [q for q in plans if not (q["fits"] if args.dry_run else q["fits_free_now"])]
+    if not args.dry_run and rank == 0:
+        for q in plans:
+            if not q["fits"] and q["fits_free_now"]:
+                print("# memory plan of rank %d is %.1f GB, more than its share of the device, but fits what is free now: running" % (q["rank"], q["total_bytes"] / 1e9), file=sys.stderr)
     if args.dry_run or bad:
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "parallelism": parallelism, "precision": args.precision, "batch": args.batch,
-                              "fits": not bad, "per_rank": plans}), flush=True)
+                              "fits": not bad, "compute_ms_per_step_expected": expected_step_ms(args.precision, parallelism, patch),
+                              "link_model": {"xgmi_link_gbps_both_directions": fdist.XGMI_LINK_GBPS_BIDIR, "links_per_gpu": fdist.XGMI_LINKS_PER_GPU,
+                                             "note": "link_ms_direct / link_ms_ring in collectives_per_step: one direction of one link = half of that"},
+                              "per_rank": plans}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         sys.exit(3 if bad else 0)
-    wl = Workload(torch, dev, stack_id, patch, args.batch, parallelism, topo, group,
-                  gather_group_world=world if (parallelism == "frame" and not args.no_gather) else 1)
+    wl = Workload(torch, dev, stack_id, patch, args.batch, parallelism, topo, group, gather_group_world=world if gather_on else 1)
     wl.premake_warps(net)
     wl.input_path = args.input_path
 
@@ -284,6 +298,7 @@ def main():
     if wl.gather is not None:
         wl.gather.gather_ms = 0.0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ================= the timed region: EXACTLY args.steps steps, barrier + synchronize on both sides (sync() above and below) =================
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
@@ -293,6 +308,7 @@ def main():
     t_local = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
+    # ================= end of the timed region; everything below (bench_report.py) is reporting on other passes =================
     per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -320,11 +336,13 @@ def main():
     parity_oracle = None
     other = {}
     cfg5 = None
+    extras_failed = []          # an extra that raised: named at the top level of the line, and the process exits with status 5 AFTER printing it
     if solo and not args.no_flow:
         try:
             cfg5 = cfg5_pipeline(torch, dev, W, wl, net, local_rank)
         except Exception as e:                                      # noqa: BLE001 -- must not kill the headline line
             cfg5 = {"error": repr(e)}
+            extras_failed.append("cfg5: " + repr(e))
     if solo:
         parity_oracle = None if args.no_parity else oracle_tile_check(net, torch)
         wl.step(net)
@@ -341,30 +359,35 @@ def main():
                     "uint8_mismatch_frac": float(((a * 255).to(torch.uint8) != (b * 255).to(torch.uint8)).double().mean())}
 
         for alt in [a for a in args.others.split(",") if a and a != "none" and a != args.precision]:
-            eng = FISRnet(device=f"cuda:{local_rank}", precision=alt)
-            eng.set_weights(W)
-            wl.step(eng)                                      # warm-up + this engine's output
-            torch.cuda.synchronize(dev)
-            out_alt = wl.full.clone()
-            nrep = max(2, min(args.steps, 5))
-            t0 = time.perf_counter()
-            for _ in range(nrep):
-                wl.step(eng)
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) / nrep
-            rl = None if args.no_roofline else roofline_pass(eng, wl, alt, 1)
-            rec = {"value": round(UNIQUE_PER_STACK / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
-                   "steps": nrep, "dtype": DTYPE[alt],
-                   "roofline": {k: rl[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "executed_per_algorithmic",
-                                                   "algorithmic_tflops", "pmc_mfma_busy_frac", "traffic", "avg_launch_us", "launches",
-                                                   "share_of_gpu_time", "all_conv_algorithmic_tflops", "all_conv_executed_frac",
-                                                   "kernels") if k in rl} if rl else None,
-                   "parity_vs_" + args.precision: compare(out_alt, out_main, f"{alt} vs the {args.precision} engine"),
-                   "parity_vs_oracle": None if args.no_parity else oracle_tile_check(eng, torch)}
-            other[alt] = rec
-            eng.close()
-            del eng, out_alt
-            torch.cuda.empty_cache()
+            try:
+                eng = FISRnet(device=f"cuda:{local_rank}", precision=alt)
+                eng.set_weights(W)
+                wl.step(eng)                                      # warm-up + this engine's output
+                torch.cuda.synchronize(dev)
+                out_alt = wl.full.clone()
+                nrep = max(2, min(args.steps, 5))
+                t0 = time.perf_counter()
+                for _ in range(nrep):
+                    wl.step(eng)
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t0) / nrep
+                rl = None if args.no_roofline else roofline_pass(eng, wl, alt, 1)
+                rec = {"value": round(UNIQUE_PER_STACK / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
+                       "steps": nrep, "dtype": DTYPE[alt],
+                       "roofline": {k: rl[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "executed_per_algorithmic",
+                                                       "algorithmic_tflops", "pmc_mfma_busy_frac", "traffic", "avg_launch_us", "launches",
+                                                       "share_of_gpu_time", "all_conv_algorithmic_tflops", "all_conv_executed_frac",
+                                                       "kernels") if k in rl} if rl else None,
+                       "parity_vs_" + args.precision: compare(out_alt, out_main, f"{alt} vs the {args.precision} engine"),
+                       "parity_vs_oracle": None if args.no_parity else oracle_tile_check(eng, torch)}
+                other[alt] = rec
+                eng.close()
+                del eng, out_alt
+                torch.cuda.empty_cache()
+            except Exception as e:                                  # noqa: BLE001 -- the headline must survive; the failure is named in extras_failed
+                other[alt] = {"error": repr(e)}
+                extras_failed.append("other_precisions.%s: %r" % (alt, e))
+                torch.cuda.empty_cache()
 
     training = None
     if solo and not args.no_train:
@@ -372,10 +395,13 @@ def main():
             training = time_training_step(W, torch, local_rank)
         except Exception as e:  # noqa: BLE001  (the headline must survive a failure of this extra)
             training = {"error": repr(e)}
+            extras_failed.append("training_step: " + repr(e))
 
     cpu_port = cpu_onednn = None
     if solo and not args.no_cpu_baseline:
         cpu_port, cpu_onednn = cpu_baselines(W, wl)
+        if isinstance(cpu_onednn, dict) and "error" in cpu_onednn:
+            extras_failed.append("cpu_baseline_onednn: " + cpu_onednn["error"])
 
     if rank == 0:
         t0_ = wl.tiles[0]
@@ -422,6 +448,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_port, "cpu_baseline_onednn": cpu_onednn,
             "parity_vs_oracle": parity_oracle, "cfg5": cfg5, "training_step": training,
             "other_precisions": other or None,
+            "extras_failed": extras_failed,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -429,7 +456,9 @@ def main():
         # JSON line; leave without running the C-level exit handlers so the JSON line stays the last line.
         dist.barrier()
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        os._exit(5 if extras_failed else 0)
+    if extras_failed:
+        sys.exit(5)
 
 
 if __name__ == "__main__":

@@ -81,7 +81,7 @@ def _pmc_passes(entry, launches_per_step):
     return round(r) if r >= 0.95 and abs(r - round(r)) <= 0.05 else 0
 
 
-def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, rank, weight_bytes):
+def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, rank, weight_bytes, input_path="fused"):
     """Bytes this rank's step holds on its device, by item, and whether they fit (cfg2 workload; `gather_world` > 1: rank 0 also
     holds the receive buffer of the frame gather).  The activation arena is what fisr_workspace_bytes says for the largest
     forward batch of the plan -- the library's own figure, not an estimate."""
@@ -97,6 +97,7 @@ def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, 
         th, tw = max(t.in_h for t in tiles), max(t.in_w for t in tiles)
         n_fwd = per
     arena = int(net._L.fisr_workspace_bytes(net._ctx, n_fwd, th, tw))
+    fused = input_path == "fused" and batch == "stack" and parallelism != "tile"
     out_f32 = 3 * (2 * h) * (2 * w) * 9 * 4
     out_u8 = 3 * (2 * h) * (2 * w) * 9
     items = {
@@ -104,8 +105,10 @@ def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, 
         "activation_arena": arena,
         "forward_batch": [n_fwd, th, tw],
         "inputs_frames_flows_warps": 5 * H0 * W0 * 3 + 8 * H0 * W0 * 2 * 4 + 8 * H0 * W0 * 3 * 4,
-        "packed_input_3_windows": 3 * h * w * 29 * 4,
-        "tile_batch_in_out": n_fwd * th * tw * 29 * 4 + n_fwd * 4 * th * tw * 9 * 4,
+        # (the fused input path -- fisr_forward_frames, the default with --batch stack -- never allocates the packed tensor or the
+        #  tile slices: the level inputs are cut straight out of the source planes)
+        "packed_input_3_windows": 0 if fused else 3 * h * w * 29 * 4,
+        "tile_batch_in_out": (0 if fused else n_fwd * th * tw * 29 * 4) + n_fwd * 4 * th * tw * 9 * 4,
         "stitched_output_f32": out_f32, "output_yuv_rgb_u8": 3 * out_u8,
         "gather_send_buffers": 2 * out_u8 if gather_world > 1 else 0,
         "gather_receive_buffer": gather_world * out_u8 if gather_world > 1 and rank == 0 else 0,
@@ -115,9 +118,36 @@ def memory_plan(torch, net, dev, patch, batch, parallelism, topo, gather_world, 
     free_b += int(weight_bytes)                               # (the weights are already resident)
     sharing = int(os.environ.get("FISR_BENCH_ONE_DEVICE", "0") == "1") and int(os.environ.get("WORLD_SIZE", "1")) or 1
     budget = total_b // max(sharing, 1)                        # (test mode: all ranks share device 0)
+    # `fits`: the plan against the device's size (what --dry-run answers); `fits_free_now`: against what is free on the device at
+    # this moment, weights counted back in -- the test a real run refuses on (a plan near an artificial per-rank share of a shared
+    # device, or beside another process's memory, is decided by what is actually free)
     return {"rank": rank, "device": str(dev), "bytes": items, "total_bytes": total, "device_total_bytes": int(total_b),
             "device_free_bytes_now": int(free_b), "ranks_sharing_device": sharing,
-            "fits": bool(total * 1.05 <= budget)}              # 5 % for the allocator's rounding
+            "fits": bool(total * 1.05 <= budget),              # 5 % for the allocator's rounding
+            "fits_free_now": bool(total * 1.05 <= free_b // max(sharing, 1))}
+
+
+def expected_step_ms(precision, parallelism, patch):
+    """What one step of this engine took on one MI355X in the latest committed bench line (profiles/r??_bench_default.json), for
+    `--dry-run` to print beside the link times: frame-parallel ranks run the whole step, a tile-parallel rank its tile of the 3
+    windows (1 / tiles of the step's convolutions).  None when no committed line has the engine."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_bench_default.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        ms = d.get("ms_per_step") if precision == "fp32" else ((d.get("other_precisions") or {}).get(precision) or {}).get("ms_per_step")
+        if ms:
+            best = {"ms": float(ms), "source": os.path.relpath(path, ROOT)}
+    if best is None:
+        return None
+    if parallelism == "tile":
+        best["ms"] = round(best["ms"] / (patch[0] * patch[1]), 2)
+        best["note"] = "a rank's tile of the 3 windows: the single-GPU step over the tiles of the plan"
+    return best
 
 
 def _pmc_table():
@@ -266,6 +296,9 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     busy = conv_field(dom["name"], "mfma_busy_frac")
     rl = {"bound": "mfma", "kernel": dom["name"], "achieved": round(epa * ach, 2), "peak": peak,
           "unit": "TFLOP/s", "frac": round(epa * ach / peak, 4),
+          # the other reading of the same launch: ALGORITHMIC (direct-convolution) FLOPs per second over the peak -- above 1 for the
+          # Winograd kernels, which execute a quarter (F(4x4)) / 4/9 (F(2x2)) of the direct algorithm's multiplies
+          "frac_algorithmic": round(ach / peak, 4),
           "achieved_is": "matrix-pipe FLOPs executed per second = algorithmic FLOPs x executed_per_algorithmic / duration",
           "executed_per_algorithmic": round(epa, 4),
           "algorithmic_tflops": round(ach, 2), "algorithmic_over_peak": round(ach / peak, 4),

@@ -11,12 +11,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libfisr_oracle.so")
+# FISR_ORACLE_SO: another build of the same source (oracle/Makefile `asan`: AddressSanitizer + UBSan, `make -C oracle asan-test`)
+_SO = os.environ.get("FISR_ORACLE_SO") and os.path.abspath(os.environ["FISR_ORACLE_SO"]) or os.path.join(_HERE, "_build", "libfisr_oracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "fisr_oracle.c")
+    if os.environ.get("FISR_ORACLE_SO"):
+        return _SO                          # (an explicitly chosen build is never rebuilt from here)
     if force or not os.path.isfile(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
                               stdout=subprocess.DEVNULL)

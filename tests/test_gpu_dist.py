@@ -25,6 +25,44 @@ def _free_port():
         return s.getsockname()[1]
 
 
+# (first in the file on purpose: a box with two GPUs reaches the only test that moves bytes BETWEEN devices over RCCL before the long ones)
+def _comm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fisr_amd import dist as fdist
+        torch.cuda.set_device(rank)
+        comm = fdist.FisrComm.from_torch_group(rank)
+        mine = torch.full((4, 1000), rank + 1, dtype=torch.uint8, device=f"cuda:{rank}")
+        got = comm.allgather(mine)
+        peer = comm.sendrecv(mine, (rank + 1) % world)
+        torch.cuda.synchronize()
+        ok = got.shape == (world, 4, 1000) and got[:, 0, 0].tolist() == [r + 1 for r in range(world)] and int(peer[0, 0]) == (rank + 1) % world + 1
+        comm.close()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fisr_comm_two_ranks_over_rccl():
+    """The C-ABI's own RCCL communicator (fisr_comm_*: unique id, init, all-gather, send/recv) between two GPUs.  Needs two
+    devices: skipped on the one-GPU box, runs wherever a node is available."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def _inputs(seed, H, W):
     rng = np.random.default_rng(seed)
     frames = [torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)) for _ in range(3)]
@@ -214,6 +252,24 @@ def test_bench_dry_run_reports_the_memory_plan_of_every_rank():
             b = r["bytes"]
             assert b["activation_arena"] > 0 and b["weights_packed_measured"] > 100e6 and r["total_bytes"] > b["activation_arena"]
             assert r["device_total_bytes"] > 200e9 and r["ranks_sharing_device"] == 8
+        # what a step puts on the links, per rank and collective, with the link-time estimate beside the expected compute time
+        assert plan["link_model"]["xgmi_link_gbps_both_directions"] == 153.0 and plan["link_model"]["links_per_gpu"] == 7
+        frame_bytes = 3 * 2048 * 3840 * 9
+        for r in plan["per_rank"]:
+            cs = r["collectives_per_step"]
+            if extra[1] == "frame":
+                assert len(cs) == 1 and cs[0]["group_size"] == 8
+                assert cs[0]["send_bytes"] == (0 if r["rank"] == 0 else frame_bytes) and cs[0]["recv_bytes"] == (7 * frame_bytes if r["rank"] == 0 else 0)
+                assert abs(cs[0]["link_ms_direct"] - frame_bytes / 76.5e9 * 1e3) < 0.01 and abs(cs[0]["link_ms_ring"] - 7 * cs[0]["link_ms_direct"]) < 0.05
+            else:
+                assert [c["group_size"] for c in cs] == [4, 4]
+                assert cs[0]["send_bytes"] == 3 * (2 * 32 * 960 + 2 * 512 * 32) * 29 * 4 and cs[0]["recv_bytes"] == 3 * cs[0]["send_bytes"]
+                assert cs[1]["send_bytes"] == 3 * 1024 * 1920 * 18 and cs[1]["recv_bytes"] == 3 * cs[1]["send_bytes"]
+        exp = plan["compute_ms_per_step_expected"]
+        assert exp is None or (exp["ms"] > 5 and exp["source"].startswith("profiles/"))
+        if exp is not None:      # the collectives are a few per cent of a step: the plan says so before a node has been seen
+            worst = max(c["link_ms_ring"] for r in plan["per_rank"] for c in r["collectives_per_step"])
+            print(f"dry run {extra[1]}: slowest collective {worst:.2f} ms on a ring against {exp['ms']:.1f} ms of compute per step")
         r0 = plan["per_rank"][0]["bytes"]
         if extra[1] == "frame":        # 12 tiles of 544 x 992 per forward; rank 0 holds the gather's receive buffer
             assert r0["forward_batch"] == [12, 544, 992] and r0["gather_receive_buffer"] == 8 * 3 * 2048 * 3840 * 9
@@ -222,43 +278,6 @@ def test_bench_dry_run_reports_the_memory_plan_of_every_rank():
             assert r0["forward_batch"] == [3, 544, 992] and r0["gather_send_buffers"] == 0
         print(f"dry run {extra[1]}: fits {plan['fits']}, per-rank total {plan['per_rank'][0]['total_bytes'] / 1e9:.1f} GB "
               f"(arena {r0['activation_arena'] / 1e9:.1f} GB, weights {r0['weights_packed_measured'] / 1e9:.2f} GB)")
-
-
-def _comm_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from fisr_amd import dist as fdist
-        torch.cuda.set_device(rank)
-        comm = fdist.FisrComm.from_torch_group(rank)
-        mine = torch.full((4, 1000), rank + 1, dtype=torch.uint8, device=f"cuda:{rank}")
-        got = comm.allgather(mine)
-        peer = comm.sendrecv(mine, (rank + 1) % world)
-        torch.cuda.synchronize()
-        ok = got.shape == (world, 4, 1000) and got[:, 0, 0].tolist() == [r + 1 for r in range(world)] and int(peer[0, 0]) == (rank + 1) % world + 1
-        comm.close()
-        q.put((rank, bool(ok)))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_fisr_comm_two_ranks_over_rccl():
-    """The C-ABI's own RCCL communicator (fisr_comm_*: unique id, init, all-gather, send/recv) between two GPUs.  Needs two
-    devices: skipped on the one-GPU box, runs wherever a node is available."""
-    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(ok for _, ok in res)
 
 
 def _rccl_single_worker(port, q):
@@ -279,6 +298,40 @@ def _rccl_single_worker(port, q):
         r = ag.wait()
         torch.cuda.synchronize()
         ok = ok and tuple(r.shape) == (1, 3, 64, 96, 9) and int(r.max()) == 4 and int(r.min()) == 4
+        # ... and it must not BLOCK: under gloo the "asynchronous" gather holds the host for the whole step (322.8 of 324.4 ms in
+        # a 2-rank log of round 4); under RCCL submit() only enqueues.  (a) host time of submit() < 1 ms (best of 5, warm);
+        # (b) the compute stream does not wait for a gather in flight -- the side stream is held up by a long sleep kernel, work
+        # enqueued on the compute stream behind submit() finishes while the gather's done-event is still pending; (c) re-using the
+        # send buffer DOES wait for it (buffer() makes the compute stream wait for that event).
+        import time as _time
+        big = fdist.AsyncGather((3, 512, 960, 9), torch.uint8, "cuda:0", dst=0)
+        host_ms = []
+        for step in range(5):
+            big.buffer(step).fill_(7)
+            t0 = _time.perf_counter()
+            big.submit(step)
+            host_ms.append((_time.perf_counter() - t0) * 1e3)
+        big.wait()
+        torch.cuda.synchronize()
+        assert min(host_ms) < 1.0, f"AsyncGather.submit blocks the host under RCCL: {host_ms} ms"
+        with torch.cuda.stream(big.side):
+            torch.cuda._sleep(int(1.0e9))                  # ~0.4 s of the side stream (cycles of the shader clock)
+        buf = big.buffer(6)                                # slot 0: its last gather finished above -> no wait on the compute stream
+        buf.fill_(9)
+        big.submit(6)
+        probe = torch.zeros(1 << 20, device="cuda:0").add_(1)
+        after = torch.cuda.Event()
+        after.record()
+        after.synchronize()                                # the compute stream's work behind submit() is DONE ...
+        assert not big.done[0].query(), "the compute stream waited for a gather in flight (or the side stream was not held up)"
+        again = big.buffer(8)                              # slot 0 again: now the compute stream must wait for that gather
+        again.fill_(1)
+        reuse = torch.cuda.Event()
+        reuse.record()
+        assert not reuse.query(), "re-using a send buffer did not wait for the gather that reads it"
+        big.wait()
+        reuse.synchronize()
+        assert big.done[0].query() and int(probe[0]) == 1 and int(big.recv.max()) == 9
         # halo all-gather + tile gather (a 1x1 "tile group"), prefetched on the side stream
         core = torch.rand((2, 64, 96, 29), device="cuda:0")
         pf = fdist.HaloPrefetcher((1, 1), "cuda:0")

@@ -300,3 +300,20 @@ def test_training_oracle_gradients_vs_finite_differences(syn_weights):
     s1 = lam["recn"] * terms["recn"] + lam["tm1"] * terms["tm"] + lam["tmm"] * terms["tmm"] + lam["td"] * terms["td"]
     s2 = lam["recn"] * terms["recn_ss2"] + lam["td"] * terms["td_ss2"] + lam["tm2"] * terms["tm_ss2"]
     assert abs(s1 + lam["ss2"] * s2 - loss) < 1e-9 * abs(loss)
+
+
+def test_c_oracle_under_address_sanitizer():
+    """SURVEY.md section 5 (sanitizers): the checker's own C code -- oracle/fisr_oracle.c, the thing every parity claim leans on --
+    rebuilt with -fsanitize=address,undefined runs its conv / pool / forward / golden tests without a report (`make -C oracle
+    asan-test`; a finding aborts the child process: -fno-sanitize-recover, ASan's default abort)."""
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = os.environ.get("CC", "gcc")
+    if shutil.which(cc) is None or not os.path.isabs(subprocess.run([cc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()):
+        pytest.skip("no gcc / libasan in this image")
+    if os.environ.get("FISR_ORACLE_SO"):
+        pytest.skip("already inside the sanitizer run")
+    p = subprocess.run(["make", "-s", "-C", os.path.join(here, "oracle"), "asan-test"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert " passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
