@@ -492,7 +492,8 @@ def test_phase_test_prepares_its_own_files_and_scores_the_same(scenes10, tmp_pat
     net.close()
     assert "Start to read flow data (test)." in out_b and "on the GPU" not in out_b
     for k in ("FISR_PSNR", "SR_PSNR", "FISR_SSIM", "SR_SSIM"):
-        assert res_a[k] == res_b[k], (k, res_a[k], res_b[k])
+        # (the SSIM kernel sums its tiles with atomics: the last bit of the double may differ between two runs of the SAME input)
+        assert abs(res_a[k] - res_b[k]) <= 1e-12, (k, res_a[k], res_b[k])
     line = [l for l in out_a.splitlines() if "Test (average)" in l]
     assert line and line == [l for l in out_b.splitlines() if "Test (average)" in l]
     # the CLI entry: --prepare only rewrites the same flow file and stops before the network runs
