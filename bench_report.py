@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 FLOP_PER_LR_PX = 5288328.0          # SURVEY.md 8d / BASELINE.md section 2 (2 x 2 644 164 MAC)
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md (spec; ~6300 achievable with a float4 copy)
 # dense MFMA peak of the instruction class each engine issues (MI355X_MICROARCH.md), TFLOP/s
-PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp32w4": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0, "mixed": 2500.0}
+PEAK = {"fp32": 157.3, "fp32d": 157.3, "fp32w": 157.3, "fp32w4": 157.3, "fp16": 2500.0, "bf16x3": 2500.0, "f16f8": 2500.0, "mixed": 2500.0,
+        "f16f8r": 2500.0, "mixedr": 2500.0}      # (the two A/B engines on round 1's register-staged kernels)
 # matrix-pipe FLOPs EXECUTED per algorithmic (direct 3x3 convolution) FLOP, per kernel class: Winograd F(2x2,3x3) issues 16
 # multiplies per 2x2 outputs instead of 36; split bf16 issues 3 MFMAs per product; fp16 + fp8 remainder one fp16 MFMA per tap
 # and one block-scaled fp8 MFMA (twice the fp16 rate per K element, four times the K) per tap pair: 1 + 5/9 * ... = 2.11 units
@@ -33,6 +34,8 @@ DTYPE = {"fp32": "f32", "fp32d": "f32", "fp32w": "f32", "fp32w4": "f32",
          "bf16x3": "bf16x3 (values as hi+lo bf16 pairs, 3 bf16 MFMA per product, f32 accumulate)",
          "f16f8": "f16f8 (values as fp16 + fp8 remainder, fp16 MFMA + block-scaled fp8 MFMA for the cross terms, f32 accumulate)",
          "mixed": "mixed (f16f8 at the full and half resolution of level 3 -- first two encoder levels, last two decoder levels, the SR head --, f16 elsewhere incl. the FI-SR head, r04; f32 accumulate)"}
+DTYPE["f16f8r"] = DTYPE["f16f8"] + " [register-staged kernel, A/B]"
+DTYPE["mixedr"] = DTYPE["mixed"] + " [register-staged kernels, A/B]"
 UNIQUE_PER_STACK = 7                # 3 windows x 3 frames, overlaps counted once (FISRnet.py:913-920)
 
 

@@ -65,17 +65,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// Channel slot of the fp16 + fp8 split format ("f16f8").  Per pixel, per 16 channels, 64 bytes:
+// Channel slot of the fp16 + fp8 split format ("f16f8").  Per pixel, per 16 channels, 64 bytes (r05: the fp8 fields are
+// interleaved per 8 channels -- "term-interleaved" -- so that a 16-byte unit holds BOTH fp8 parts of its 8 channels):
 //   [ 0..31] h   16 x fp16           h = fp16(x)
-//   [32..47] l8  16 x fp8 e4m3       l8 = fp8((x - h) * 2^14), clamped to +-448
-//   [48..63] h8  16 x fp8 e4m3       h8 = fp8(h), clamped to +-448 (operand of the cross terms only)
+//   [32..39] l8  ch 0-7  fp8 e4m3    l8 = fp8((x - h) * 2^14), clamped to +-448
+//   [40..47] h8  ch 0-7  fp8 e4m3    h8 = fp8(h), clamped to +-448 (operand of the cross terms only)
+//   [48..55] l8  ch 8-15             [56..63] h8  ch 8-15
 // x ~ h + l8 * 2^-14 (>= 14 significant bits).  A product a*w is computed as
 //   a_h*w_h                       one v_mfma_f32_32x32x16_f16 per tap, and
-//   a_l*w_h + a_h*w_l             one v_mfma_scale_f32_32x32x64_f8f6f4 per PAIR of taps: K block 0 =
-//                                 {l8 | wh8}, K block 1 = {h8 | wl8}, each block carrying 16 channels of tap t
-//                                 (lanes 0-31) and 16 of tap t+1 (lanes 32-63); the 2^-14 / per-conv weight
-//                                 exponents ride on the block scales.  The cross terms are 2^-12 of the product, so 4-bit
-//                                 operands there cost ~2^-16 relative: 2.1 instead of 3 MFMA-units per product.
+//   a_l*w_h + a_h*w_l             one v_mfma_scale_f32_32x32x64_f8f6f4 per PAIR of taps: a K block of 32 = one tap's 16 channels x
+//                                 both cross terms, {l8 | h8} of 8 channels against {wh8 | wl8} of the same 8 channels per lane
+//                                 half.  ONE scale pair serves both terms: the weights are packed as wh8 = fp8(w_h * 2^wexp),
+//                                 wl8 = fp8((w - w_h) * 2^(wexp + 14)), so a_l*w_h = l8*wh8 * 2^-(14 + wexp) and
+//                                 a_h*w_l = h8*wl8 * 2^-(14 + wexp) carry the same block scales 2^-14 (pixels) x 2^-wexp (weights).
+//                                 The cross terms are 2^-12 of the product, so 4-bit operands there cost ~2^-16 relative: 2.1
+//                                 instead of 3 MFMA-units per product.
+// Why interleaved: relu-on-load needs the sign of h for l8 AND h8; with both fp8 parts of a channel in one 16-byte unit the
+// lane that holds the unit masks it by h8's own sign bits (h8 = fp8(h) keeps the sign), and a fragment of the LDS-DMA kernel
+// (conv3x3_dma_fs.h) is one ds_read_b128 that is reused by every (row, dy) pair like the fp16 fragments.
 struct fsplit { uint32_t raw; };
 constexpr int FS_LSHIFT = 14;
 
@@ -200,19 +207,28 @@ template <> struct Rec16<bsplit> {
   }
 };
 template <> struct Rec16<fsplit> {
-  static constexpr int NV = 4;   // q[0..1] = h, q[2] = l8, q[3] = h8
+  static constexpr int NV = 4;   // q[0..1] = h, q[2] = {l8 | h8} of channels 0-7, q[3] = {l8 | h8} of channels 8-15
   static __device__ __forceinline__ void decode(const uint4* q, float* v) {
     fsplit_decode8(q[0], make_uint2(q[2].x, q[2].y), v);
-    fsplit_decode8(q[1], make_uint2(q[2].z, q[2].w), v + 8);
+    fsplit_decode8(q[1], make_uint2(q[3].x, q[3].y), v + 8);
   }
   static __device__ __forceinline__ void encode(const float* v, uint4* q) {
     uint2 l0, l1, g0, g1;
     fsplit_encode8(v, q[0], l0, g0);
     fsplit_encode8(v + 8, q[1], l1, g1);
-    q[2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    q[3] = make_uint4(g0.x, g0.y, g1.x, g1.y);
+    q[2] = make_uint4(l0.x, l0.y, g0.x, g0.y);
+    q[3] = make_uint4(l1.x, l1.y, g1.x, g1.y);
   }
 };
+
+// relu of the fp8 half of 8 channels, {l8.x l8.y | h8.x h8.y}: a byte of l8 / h8 is cleared where h8's sign bit is set
+// (h8 = fp8(h) carries the sign of h; -0 counts as negative, as in the fp16 test of the h field)
+__device__ __forceinline__ void fsplit_relu_x(uint4& x, uint32_t sign_sel = 0x80808080u) {
+  const uint32_t t0 = x.z & sign_sel, t1 = x.w & sign_sel;
+  const uint32_t m0 = t0 | (t0 - (t0 >> 7)), m1 = t1 | (t1 - (t1 >> 7));     // 0xff per negative byte
+  x.x &= ~m0; x.z &= ~m0;
+  x.y &= ~m1; x.w &= ~m1;
+}
 
 // 4x4 transpose of 16-byte units inside a quad of lanes (lane l, unit k) -> (lane k, unit l): afterwards
 // store instruction k makes the four lanes of a quad write 64 CONTIGUOUS bytes (one record of pixel
@@ -356,45 +372,29 @@ template <> struct Prec<fsplit> {
   static constexpr int UC = 8;
   static constexpr bool PAIR_LOAD = false;
   typedef f16x8 Frag;
-  // relu of one 64-byte record (16 channels): the sign of h decides for h, l8 and h8
-  static __device__ __forceinline__ void relu_record(uint4& h0, uint4& h1, uint4& l8, uint4& h8) {
+  // relu of one 64-byte record (16 channels): the sign of h decides for h, its fp8 copy's sign for l8 and h8
+  static __device__ __forceinline__ void relu_record(uint4& h0, uint4& h1, uint4& x0, uint4& x1) {
     uint32_t* a = reinterpret_cast<uint32_t*>(&h0);
     uint32_t* b = reinterpret_cast<uint32_t*>(&h1);
-    uint32_t* l = reinterpret_cast<uint32_t*>(&l8);
-    uint32_t* g = reinterpret_cast<uint32_t*>(&h8);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {  // dword d of l8/h8 = channels 4d..4d+3 = fp16 dwords 2d, 2d+1 of h
-      const uint32_t w0 = d < 2 ? a[2 * d] : b[2 * d - 4], w1 = d < 2 ? a[2 * d + 1] : b[2 * d - 3];
-      const uint32_t keep16_0 = ((w0 & 0x8000u) ? 0u : 0xffffu) | ((w0 & 0x80000000u) ? 0u : 0xffff0000u);
-      const uint32_t keep16_1 = ((w1 & 0x8000u) ? 0u : 0xffffu) | ((w1 & 0x80000000u) ? 0u : 0xffff0000u);
-      const uint32_t keep8 = ((w0 & 0x8000u) ? 0u : 0xffu) | ((w0 & 0x80000000u) ? 0u : 0xff00u) |
-                             ((w1 & 0x8000u) ? 0u : 0xff0000u) | ((w1 & 0x80000000u) ? 0u : 0xff000000u);
-      if (d < 2) { a[2 * d] &= keep16_0; a[2 * d + 1] &= keep16_1; } else { b[2 * d - 4] &= keep16_0; b[2 * d - 3] &= keep16_1; }
-      l[d] &= keep8;
-      g[d] &= keep8;
+    for (int d = 0; d < 4; ++d) {
+      a[d] &= ((a[d] & 0x8000u) ? 0u : 0xffffu) | ((a[d] & 0x80000000u) ? 0u : 0xffff0000u);
+      b[d] &= ((b[d] & 0x8000u) ? 0u : 0xffffu) | ((b[d] & 0x80000000u) ? 0u : 0xffff0000u);
     }
+    fsplit_relu_x(x0);
+    fsplit_relu_x(x1);
   }
   // relu of one 16-byte unit in the quad layout used by the heads loader (lane 0: h[0..7], lane 1: h[8..15],
-  // lane 2: l8[0..15], lane 3: h8[0..15] of a quad): the sign of h decides; the fp8 lanes fetch the eight h
-  // dwords of lanes 0 and 1 by DPP.
+  // lane 2: {l8 | h8} of channels 0-7, lane 3: of channels 8-15): every unit decides for itself.
   static __device__ __forceinline__ uint4 relu16(uint4 v) {
     uint32_t* d = reinterpret_cast<uint32_t*>(&v);
     const bool fp8_lane = (__lane_id() & 2) != 0;
-    uint32_t h0[4], h1[4];
+    uint4 x = v;
+    fsplit_relu_x(x);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      h0[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)d[i], 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
-      h1[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)d[i], 0x55, 0xF, 0xF, true);   // quad_perm [1,1,1,1]
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t keep16 = ((d[i] & 0x8000u) ? 0u : 0xffffu) | ((d[i] & 0x80000000u) ? 0u : 0xffff0000u);
-      const uint32_t w0 = i < 2 ? h0[2 * i] : h1[2 * i - 4], w1 = i < 2 ? h0[2 * i + 1] : h1[2 * i - 3];
-      const uint32_t keep8 = ((w0 & 0x8000u) ? 0u : 0xffu) | ((w0 & 0x80000000u) ? 0u : 0xff00u) |
-                             ((w1 & 0x8000u) ? 0u : 0xff0000u) | ((w1 & 0x80000000u) ? 0u : 0xff000000u);
-      d[i] &= fp8_lane ? keep8 : keep16;
-    }
-    return v;
+    for (int i = 0; i < 4; ++i)
+      d[i] &= ((d[i] & 0x8000u) ? 0u : 0xffffu) | ((d[i] & 0x80000000u) ? 0u : 0xffff0000u);
+    return fp8_lane ? x : v;
   }
 };
 
@@ -415,7 +415,7 @@ struct ConvArgs {
   int d2s_shift;     // log2(Cout/4) when d2s (Cout/4 must be a power of two)
   // channel scatter of the direct store: oc = n + coff + (n >= split ? gap : 0), row stride cstride
   int out_cstride, out_coff, out_split, out_gap;
-  int wexp;          // f16f8: wh8 = fp8(w_h * 2^wexp), wl8 = fp8(w_l * 2^(wexp+11)) (per conv, host-chosen)
+  int wexp;          // f16f8: wh8 = fp8(w_h * 2^wexp), wl8 = fp8(w_l * 2^(wexp+14)) (per conv, host-chosen)
   // (the PWC-Net decoder reads and writes channel ranges of one wide buffer)
   int in0_cs, in1_cs;   // pixel strides of in0 / in1 in elements (>= C0 / C1)
   int rec_cs, rec_co;   // Winograd kernel only: pixel stride and first channel of the (non-d2s) output and of the residual
@@ -752,13 +752,12 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
               acc4[m][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc4[m][ct], 0, 0, 0);
             }
         }
-        // Lane group kg carries tap 4g + kg: its 32 operand bytes are bytes 32..63 of that tap's record
-        // (pixel: l8 | h8, weight: wh8 | wl8), i.e. bytes 0-15 = term a_l*w_h, bytes 16-31 = term a_h*w_l.
-        // Probed block structure: the 32-element scale blocks are {bytes 0-15 of groups 0,1}, {bytes 16-31 of
-        // groups 0,1}, {bytes 0-15 of groups 2,3}, {bytes 16-31 of groups 2,3} and take their scales from lane
-        // groups 0, 2, 1, 3 -- so lane groups 0,1 hold the term-0 scales and 2,3 the term-1 scales.
-        const int s_w8 = (kg >> 1) == 0 ? 127 - p.wexp : 127 - p.wexp - 11;   // weights (row operand)
-        const int s_a8 = (kg >> 1) == 0 ? 127 - FS_LSHIFT : 127;              // pixels (column operand)
+        // Lane group kg carries tap 4g + kg: its 32 operand bytes are bytes 32..63 of that tap's record (pixel: {l8 | h8} of
+        // channels 0-7, then of channels 8-15; weight: {wh8 | wl8} likewise), i.e. both cross terms of 8 channels per 16 bytes.
+        // Probed block structure: the 32-element scale blocks are {bytes 0-15 of groups 0,1}, {bytes 16-31 of groups 0,1},
+        // {bytes 0-15 of groups 2,3}, {bytes 16-31 of groups 2,3} -- every block mixes both terms, which share one scale pair.
+        const int s_w8 = 127 - p.wexp;       // weights (row operand)
+        const int s_a8 = 127 - FS_LSHIFT;    // pixels (column operand)
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
           const int t = 4 * g + kg, tc = t < 9 ? t : 8;
@@ -785,11 +784,11 @@ __global__ __launch_bounds__(64 * (TILE_H / MR), MR == 1 ? 4 : 2) void conv3x3_m
       // + 1 block-scaled fp8 MFMA carrying both cross terms of both taps.
       // Operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 (probed, scripts/probes/): lane (row, kh)
       // holds bytes 0-15 = K block 0 elements kh*16.., bytes 16-31 = K block 1 elements kh*16..; the
-      // scale of block b is taken from the lanes with kh == b.  So lane half kh carries tap 2*tp+kh:
-      // bytes 0-15 = l8 | wh8 (block 0: a_l*w_h, scales 2^-14 | 2^-wexp), bytes 16-31 = h8 | wl8
-      // (block 1: a_h*w_l, scales 1 | 2^-(wexp+11)) = bytes 32..63 of that tap's 64-byte record.
-      const int sa = kh == 0 ? 127 - FS_LSHIFT : 127;
-      const int sb = kh == 0 ? 127 - p.wexp : 127 - p.wexp - 11;
+      // scale of block b is taken from the lanes with kh == b.  Lane half kh carries tap 2*tp+kh: its 32 bytes are
+      // bytes 32..63 of that tap's 64-byte record = {l8 | h8} x {wh8 | wl8} of channels 0-7 (block 0) and 8-15 (block 1);
+      // both cross terms carry the scales 2^-14 (pixels) x 2^-wexp (weights).
+      const int sa = 127 - FS_LSHIFT;
+      const int sb = 127 - p.wexp;
       const char* ax_base = s_in + ((wave * MR) * HALO_W + li) * REC_BYTES + 32;
       const char* bx_base = s_w + li * REC_BYTES + 32;
 #pragma unroll

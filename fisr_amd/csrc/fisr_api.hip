@@ -31,6 +31,7 @@
 #include "conv3x3_wino8p.h"
 #include "conv3x3_wf4.h"
 #include "conv3x3_dma.h"
+#include "conv3x3_dma_fs.h"
 #ifdef FISR_DIAG
 #include "diag/conv3x3_wino4.h"
 #include "diag/conv3x3_wino8.h"
@@ -57,7 +58,8 @@ struct ConvW {
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino_common.h), else NULL
   void* d_wu4 = nullptr;  // FISR_PREC_F32W4: U = G g G^T of F(4x4,3x3) in the LDS image of conv3x3_wf4.h, else NULL
   float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][4 | 6] for the vector-ALU head kernel (head_conv.h), else NULL
-  void* d_wd = nullptr;   // FISR_PREC_F16, Cout > 32: the weight slabs of the LDS-DMA kernel (conv3x3_dma.h), else NULL
+  void* d_wd = nullptr;   // FISR_PREC_F16, Cout > 32: the weight slabs of the LDS-DMA kernel (conv3x3_dma.h); FISR_PREC_F16F8, Cout % 64 == 0: of
+                          // the persistent one (conv3x3_dma_fs.h); else NULL
   int cout_pad_d = 0;     // ... and its Cout padded to the 64-channel block
   int prec = -1;          // the precision the device copies are packed for (differs per layer in FISR_PREC_MIXED)
 };
@@ -189,12 +191,13 @@ template <typename F>
 auto with_prec(int precision, F&& f) {
   if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4) return f(float());
   if (precision == FISR_PREC_F16 || precision == FISR_PREC_F16R) return f(_Float16());
-  if (precision == FISR_PREC_F16F8) return f(fsplit());
+  if (precision == FISR_PREC_F16F8 || precision == FISR_PREC_F16F8R) return f(fsplit());
   return f(bsplit());
 }
 inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
-         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W || precision == FISR_PREC_F16R || precision == FISR_PREC_F32W4;
+         precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W || precision == FISR_PREC_F16R || precision == FISR_PREC_F32W4 ||
+         precision == FISR_PREC_F16F8R;
 }
 // FISR_PREC_MIXED: which layers keep a split-precision arithmetic (f16f8) -- everything that works at the full and at
 // the half resolution of level 3 (its first two encoder levels, its last two decoder levels, both heads: 55 % of the
@@ -212,9 +215,12 @@ inline bool mixed_layer_is_hi(const std::string& name) {
 inline bool prec_mixed(int precision) { return precision == FISR_PREC_MIXED || precision == FISR_PREC_MIXEDR; }
 inline int layer_prec(int precision, const std::string& name) {
   if (!prec_mixed(precision)) return precision;
-  return mixed_layer_is_hi(name) ? FISR_PREC_F16F8 : (precision == FISR_PREC_MIXED ? FISR_PREC_F16 : FISR_PREC_F16R);
+  if (mixed_layer_is_hi(name)) return precision == FISR_PREC_MIXED ? FISR_PREC_F16F8 : FISR_PREC_F16F8R;
+  return precision == FISR_PREC_MIXED ? FISR_PREC_F16 : FISR_PREC_F16R;
 }
-inline bool prec_grouped16(int precision) { return precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8; }
+inline bool prec_grouped16(int precision) { return precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8 || precision == FISR_PREC_F16F8R; }
+// the precisions whose convolutions with whole 64-channel blocks run on an LDS-DMA kernel (conv3x3_dma.h / conv3x3_dma_fs.h)
+inline bool prec_dma(int precision) { return precision == FISR_PREC_F16 || precision == FISR_PREC_F16F8; }
 
 // host fp8 e4m3fn (OCP) encode, round-to-nearest-even, saturating at +-448
 inline uint8_t host_fp8_e4m3(float f) {
@@ -276,12 +282,13 @@ void pack_weights(const float* w, const float* b, int ci, int co, int cin_pad, i
         } else if constexpr (std::is_same<T, _Float16>::value) {
           reinterpret_cast<_Float16*>(rec)[cc] = (_Float16)v;
         } else if constexpr (std::is_same<T, fsplit>::value) {
-          // [ 0..31] w_h fp16 | [32..47] fp8(w_h * 2^wexp) | [48..63] fp8((w - w_h) * 2^(wexp+11))
+          // [ 0..31] w_h fp16 | per 8 channels {8 x fp8(w_h * 2^wexp) | 8 x fp8((w - w_h) * 2^(wexp+14))}: the layout of the
+          // activations' fp8 fields (conv3x3.h), both cross terms under one block scale
           const _Float16 h = (_Float16)v;
           const float hf = (float)h;
           reinterpret_cast<_Float16*>(rec)[cc] = h;
-          reinterpret_cast<uint8_t*>(rec)[32 + cc] = host_fp8_e4m3(std::ldexp(hf, wexp));
-          reinterpret_cast<uint8_t*>(rec)[48 + cc] = host_fp8_e4m3(std::ldexp(v - hf, wexp + 11));
+          reinterpret_cast<uint8_t*>(rec)[32 + (cc >> 3) * 16 + (cc & 7)] = host_fp8_e4m3(std::ldexp(hf, wexp));
+          reinterpret_cast<uint8_t*>(rec)[40 + (cc >> 3) * 16 + (cc & 7)] = host_fp8_e4m3(std::ldexp(v - hf, wexp + 14));
         } else {
           const uint16_t hi = host_bf16(v);
           const uint16_t lo = host_bf16(v - host_bf16_to_f32(hi));
@@ -350,6 +357,38 @@ inline bool dma_fits(int h, int w, int c0, int c1, int cs0, int cs1) {
   return c0 % D_CH == 0 && c1 % D_CH == 0 && c0 > 0 && (c1 == 0 || cs0 == cs1) && (double)h * w * cs0 * 2.0 < 2147483648.0;
 }
 
+// f16f8 weights for the persistent LDS-DMA kernel (conv3x3_dma_fs.h): [Cin/16][Cout/64][36 864 B], a slab being the kernel's LDS
+// image: [tap 9][row 64][32 B of w_h] exactly as pack_weights_dma lays fp16 out, then the fp8 parts of the tap pairs (0,3) (1,4)
+// (2,5) (6,7) as [pair 4][plane 2 kh + tap of the pair][row 64][16 B] and of tap 8 as [plane kh][row 64][16 B], a 16-byte piece =
+// {8 x fp8(w_h * 2^wexp) | 8 x fp8((w - w_h) * 2^(wexp+14))} of channels 8 kh .. 8 kh + 7 (pack_weights<fsplit>'s bytes 32..63).
+void pack_weights_dma_fs(const float* w, int ci, int co, int cin_pad, int wexp, std::vector<char>& wp) {
+  const int nb = co / FS_BN, nch = cin_pad / FS_CH;
+  wp.assign((size_t)nch * nb * FS_W_BYTES, 0);
+  static const int pair_of[9] = {0, 1, 2, 0, 1, 2, 3, 3, 4}, slot_of[9] = {0, 0, 0, 1, 1, 1, 0, 1, 0};
+  for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < ci; ++c)
+      for (int n = 0; n < co; ++n) {
+        const int kc = c / FS_CH, cc = c % FS_CH, h = cc >> 3, e = cc & 7;
+        const int blk = n / FS_BN, nl = n % FS_BN, wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+        const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+        char* slab = wp.data() + ((size_t)kc * nb + blk) * FS_W_BYTES;
+        const float v = w[((size_t)tap * ci + c) * co + n];
+        const _Float16 hh = (_Float16)v;
+        const float hf = (float)hh;
+        reinterpret_cast<_Float16*>(slab + ((size_t)tap * FS_BN + row) * 32 + ((h ^ ((row >> 3) & 1)) * 16))[e] = hh;
+        const int q = pair_of[tap], t = slot_of[tap];
+        uint8_t* x = reinterpret_cast<uint8_t*>(slab + FS_WM_BYTES + (q < 4 ? q * 4096 + (2 * h + t) * 1024 : 4 * 4096 + h * 1024) + row * 16);
+        x[e] = host_fp8_e4m3(std::ldexp(hf, wexp));
+        x[8 + e] = host_fp8_e4m3(std::ldexp(v - hf, wexp + 14));
+      }
+}
+// what that kernel takes: dense f16f8 tensors, whole 64-channel output blocks, whole 16-channel chunks, both concat sources of the
+// same width, an image inside 31-bit byte offsets
+inline bool dmafs_fits(int h, int w, int c0, int c1, int co) {
+  return co % FS_BN == 0 && c0 % FS_CH == 0 && c0 > 0 && (c1 == 0 || c1 == c0) && (double)h * w * c0 * 4.0 < 2147483648.0 &&
+         (double)h * w * co * 4.0 < 2147483648.0;
+}
+
 // N-block of a conv: 64 channels (NT = 2), 32 (NT = 1), or the 16-row heads variant (NT = 0: Cout < 16; ConvW::rows16: fp32 also Cout = 16;
 // always fp32 output; FISR_DIAG builds: FISR_CONV_HEAD16=0 turns it off for A/B runs).
 template <typename T> inline int nt_for(int co) {
@@ -374,8 +413,10 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, b
   if (std::is_same<T, fsplit>::value) {
     float mx = 0.f;
     for (float v : cw.w) mx = std::max(mx, std::fabs(v));
-    // largest power of two with max|w| * 2^wexp <= 448 (fp8 e4m3 max), kept inside the scale byte's range
-    cw.wexp = mx > 0.f ? std::min(30, std::max(-30, 8 - std::ilogb(mx) - 1)) : 0;
+    // wh8 = fp8(w_h * 2^wexp), wl8 = fp8((w - w_h) * 2^(wexp+14)): one block scale for both cross terms (conv3x3.h).  The
+    // remainder is <= 2^-11 |w|, so the largest power of two with max|w| * 2^(wexp+3) <= 448 (fp8 e4m3 max) keeps both inside
+    // the format (wh8 <= 56: its 4 significant bits reach down to max|w| / 3584), kept inside the scale byte's range
+    cw.wexp = mx > 0.f ? std::min(30, std::max(-30, 5 - std::ilogb(mx) - 1)) : 0;
   }
   pack_weights<T>(cw.w.data(), cw.b.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad, wp, bp, cw.wexp);
   if (cw.d_w) { (void)hipFree(cw.d_w); cw.d_w = nullptr; }
@@ -400,6 +441,12 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, b
   if (dma && std::is_same<T, _Float16>::value && cw.co > 32) {
     cw.cout_pad_d = round_up(cw.co, D_BN);
     pack_weights_dma(cw.w.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad_d, wp);
+    HIP_OK(ctx, hipMalloc(&cw.d_wd, wp.size()));
+    HIP_OK(ctx, hipMemcpy(cw.d_wd, wp.data(), wp.size(), hipMemcpyHostToDevice));
+  }
+  if (dma && std::is_same<T, fsplit>::value && cw.co % FS_BN == 0) {
+    cw.cout_pad_d = cw.co;
+    pack_weights_dma_fs(cw.w.data(), cw.ci, cw.co, cw.cin_pad, cw.wexp, wp);
     HIP_OK(ctx, hipMalloc(&cw.d_wd, wp.size()));
     HIP_OK(ctx, hipMemcpy(cw.d_wd, wp.data(), wp.size(), hipMemcpyHostToDevice));
   }
@@ -582,6 +629,60 @@ hipError_t launch_conv_dma(const ConvArgs& a, hipStream_t st, int nt = 2) {
   return hipGetLastError();
 }
 
+// The persistent f16f8 LDS-DMA kernel (conv3x3_dma_fs.h; a.wpk = the conv's d_wd, a.CoutPad = Cout).  Pooling with relu-on-load is
+// not instantiated (no layer asks for it): the callers keep that combination on the direct kernel.
+inline bool dmafs_takes(const ConvArgs& a) { return !(a.pool_out && a.relu_in) && !(a.pool_out && !a.res); }
+// Tile width: 32 for the layers with one 64-channel output block (their half-line re-visits must survive in L2: conv3x3_dma_fs.h), else 64.
+// (FISR_DIAG builds: FISR_FS_TW=32|64 forces one for A/B runs.)
+inline int dmafs_tile_w(const ConvArgs& a) {
+#ifdef FISR_DIAG
+  static const int forced = [] { const char* e = getenv("FISR_FS_TW"); return e ? atoi(e) : 0; }();
+  if (forced == 32 || forced == 64) return forced;
+#endif
+  return a.Cout / FS_BN == 1 ? 32 : 64;
+}
+template <int TW>
+hipError_t launch_conv_dmafs_tw(const ConvArgs& a, hipStream_t st, int n_cu, bool set_attr) {
+  constexpr size_t lds = dmafs_lds_bytes(TW);
+  if (set_attr) {
+    for (const void* k : {reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, false, false>), reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, true, false, false>),
+                          reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, true, false>), reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, true, true, false>),
+                          reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, true, true>)}) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+  }
+  const int tiles = ((a.W + TW - 1) / TW) * ((a.H + FS_TH - 1) / FS_TH) * a.N;
+  const int items = tiles * (a.Cout / FS_BN);
+  // two workgroups per CU (each takes half of a CU's LDS at most), a multiple of 8 so that the items of a workgroup stay on one XCD
+  const int grid = std::min(items, std::max(8, (2 * n_cu) & ~7));
+  const bool res = a.res != nullptr;
+  if (a.pool_out) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, true, true>), dim3(grid), dim3(256), lds, st, a, items);
+  else if (a.relu_in && res) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, true, true, false>), dim3(grid), dim3(256), lds, st, a, items);
+  else if (a.relu_in) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, true, false, false>), dim3(grid), dim3(256), lds, st, a, items);
+  else if (res) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, true, false>), dim3(grid), dim3(256), lds, st, a, items);
+  else hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, false, false>), dim3(grid), dim3(256), lds, st, a, items);
+  return hipGetLastError();
+}
+hipError_t launch_conv_dmafs(const ConvArgs& a, hipStream_t st) {
+  static bool attr_done[64][2] = {};
+  static int n_cu[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (!n_cu[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  if (!dmafs_fits(a.H, a.W, a.C0, a.C1, a.Cout) || a.CoutPad != a.Cout || !dmafs_takes(a) || (a.pool_out && ((a.H | a.W) & 1))) return hipErrorInvalidValue;
+  const int tw = dmafs_tile_w(a);
+  bool& done = attr_done[dev][tw == 64];
+  const hipError_t e = tw == 64 ? launch_conv_dmafs_tw<64>(a, st, n_cu[dev], !done) : launch_conv_dmafs_tw<32>(a, st, n_cu[dev], !done);
+  if (e == hipSuccess) done = true;
+  return e;
+}
+
 template <typename T>
 hipError_t launch_conv(const ConvArgs& a, int nt, bool out_f32, hipStream_t st) {
   const bool m1 = conv_mr<T>() == 1;
@@ -758,9 +859,11 @@ struct Runner {
     }
     const bool use_head = std::is_same<T, float>::value && ctx->wino && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
     const bool use_dma = std::is_same<T, _Float16>::value && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
-    if (use_dma) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
+    const bool use_dmafs = std::is_same<T, fsplit>::value && cw.d_wd && !out_f32 && dmafs_fits(h, w, c0, c1, cw.co) && dmafs_takes(a);
+    if (use_dma || use_dmafs) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
     char cls[96];
     if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
+    else if (use_dmafs) snprintf(cls, sizeof cls, "conv3x3_dma_fs<f16f8,%s,%s>", a.relu_in ? "relu_in" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : ups ? "up2" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
@@ -774,6 +877,7 @@ struct Runner {
     ProfScope ps(ctx, st, cname, 2.0 * 9 * cw.ci * cw.co * px,
                  px * (double)((ups ? c0 * 0.25 : c0) + c1 + cw.co + (res ? cw.co : 0)) * sizeof(T));
     check(use_dma ? launch_conv_dma(a, st)
+                  : use_dmafs ? launch_conv_dmafs(a, st)
                   : use_wf4 ? launch_conv_wf4(a, st)
                   : use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
   }
@@ -1138,7 +1242,7 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
     const int lp = layer_prec(precision, kv.first);
-    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, prec_f32w(lp), lp == FISR_PREC_F16, lp == FISR_PREC_F32W4); });
+    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, prec_f32w(lp), prec_dma(lp), lp == FISR_PREC_F32W4); });
     if (rc) return rc;
     kv.second.prec = lp;
   }
@@ -1372,7 +1476,7 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   if (!in0 || !w_host || !b_host || !out || n < 1 || h < 1 || w < 1 || cout < 1)
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3: bad argument");
   // (r04: the split formats' direct kernel has the pooled second store too -- any flags but d2s / fused bilinear, residual optional)
-  const bool pool_split = precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8;
+  const bool pool_split = precision == FISR_PREC_BF16X3 || precision == FISR_PREC_F16F8 || precision == FISR_PREC_F16F8R;
   if (pool_out && pool_split && (out_f32 || (h & 1) || (w & 1) || (flags & (FISR_CONV_D2S | FISR_CONV_UP2_IN)) || cout % CONV_REC))
     return fail(nullptr, FISR_EINVAL, "fisr_op_conv3x3_pool: on the split formats the pooled second store needs even h / w, whole 16-channel records, no d2s / fused bilinear");
   if (pool_out && !pool_split && (precision != FISR_PREC_F32W4 || out_f32 || !res || (h & 1) || (w & 1) || (flags & (FISR_CONV_RELU_IN | FISR_CONV_D2S | FISR_CONV_UP2_IN)) ||
@@ -1402,15 +1506,18 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
   cw.b.assign(b_host, b_host + cout);
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), precision == FISR_PREC_F16, precision == FISR_PREC_F32W4); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), prec_dma(precision), precision == FISR_PREC_F32W4); });
   if (rc) return rc;
   // (FISR_PREC_F32W4 at op level: the F(4x4) kernel for every shape it takes -- the engine adds its map-size rule, wf4_wins)
   const bool use_wf4 = precision == FISR_PREC_F32W4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cout) && !(res && (flags & FISR_CONV_D2S));
   const bool use_wino = !use_wf4 && prec_f32w(precision) && cw.d_wu && !out_f32 && wino_chunks_ok(c0, c1) && wino_fits(n, h, w, c0, c1, cout);
   const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
+  // (FISR_PREC_F16F8: the persistent LDS-DMA kernel wherever it has an instantiation)
+  bool use_dmafs = precision == FISR_PREC_F16F8 && cw.d_wd && !out_f32 && dmafs_fits(h, w, c0, c1, cout) &&
+                   !(pool_out && ((flags & FISR_CONV_RELU_IN) || !res));
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wpk = use_dma ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
-  a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma ? cw.cout_pad_d : cw.cout_pad;
+  a.in0 = in0; a.in1 = in1; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
+  a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma || use_dmafs ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
@@ -1423,6 +1530,7 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   // (the fp32 engine's 3 / 6-channel heads: the vector-ALU kernel, as in the forward)
   const bool use_head = prec_f32w(precision) && out_f32 && cw.d_wh && c1 == 0 && c0 % HEAD_CH == 0 && !res && head_valu_enabled();
   hipError_t e = use_dma ? launch_conv_dma(a, st)
+                 : use_dmafs ? launch_conv_dmafs(a, st)
                  : use_wf4 ? launch_conv_wf4(a, st)
                  : use_wino ? launch_conv_wino(a, st)
                  : use_head ? launch_head_valu(a, cw.d_wh, st)
@@ -1514,11 +1622,12 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   cw.b.assign(cout, 0.01f);
   uint32_t st = 12345u;
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), precision == FISR_PREC_F16, precision == FISR_PREC_F32W4); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), prec_dma(precision), precision == FISR_PREC_F32W4); });
   if (rc) return rc;
   const bool use_wf4 = precision == FISR_PREC_F32W4 && cw.d_wu4 && wf4_fits(h, w, cin, 0, cout) && !(with_res && (flags & FISR_CONV_D2S));
   const bool use_wino = !use_wf4 && prec_f32w(precision) && cw.d_wu && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
   const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && dma_fits(h, w, cin, 0, cin, 0);
+  const bool use_dmafs = precision == FISR_PREC_F16F8 && cw.d_wd && dmafs_fits(h, w, cin, 0, cout);
   void *d_in = nullptr, *d_out = nullptr, *d_res = nullptr;
   HIP_OK(nullptr, hipMalloc(&d_in, in_b));
   HIP_OK(nullptr, hipMalloc(&d_out, out_b));
@@ -1535,8 +1644,8 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
         HIP_OK(nullptr, hipMemcpy((char*)d_res + o, hbuf.data(), std::min(hbuf.size() * 2, out_b - o), hipMemcpyHostToDevice));
   }
   ConvArgs a;
-  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
-  a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma ? cw.cout_pad_d : cw.cout_pad;
+  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
+  a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma || use_dmafs ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
   a.relu_out = (flags & FISR_CONV_RELU_OUT) != 0;
@@ -1544,7 +1653,8 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   a.d2s_shift = a.d2s ? ilog2(cout / 4) : 0;
   a.out_cstride = cout; a.out_coff = 0; a.out_split = 1 << 30; a.out_gap = 0; a.trace = nullptr; a.wexp = cw.wexp;
   unsigned long long* d_trace = nullptr;
-  const size_t nblocks = use_dma ? (size_t)(((w + D_TW - 1) / D_TW) * ((h + D_TH - 1) / D_TH) * n) * (cw.cout_pad_d / D_BN)
+  const size_t nblocks = use_dmafs ? (size_t)1024      // (persistent: one trace record per workgroup)
+                         : use_dma ? (size_t)(((w + D_TW - 1) / D_TW) * ((h + D_TH - 1) / D_TH) * n) * (cw.cout_pad_d / D_BN)
                          : use_wf4 ? (size_t)(((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n) * (cw.cout_pad / F4_BN)
                                  : (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
                                        (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
@@ -1559,6 +1669,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   hipError_t e = hipSuccess;
   auto launch = [&]() -> hipError_t {
     if (use_dma) return launch_conv_dma(a, nullptr);
+    if (use_dmafs) return launch_conv_dmafs(a, nullptr);
     if (use_wf4) return launch_conv_wf4(a, nullptr);
     if (use_wino) return launch_conv_wino(a, nullptr);
     return with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
@@ -1592,7 +1703,7 @@ int fisr_bench_conv(int precision, int n, int h, int w, int cin, int cout, int f
 #ifdef FISR_DIAG
 // FISR_DIAG builds only: the micro-benchmark with zero-filled operands / masked lo planes (DVFS probes: zero operands draw
 // less power) and a per-workgroup {start, main-loop end, end, HW_ID, ...} timeline written to trace_file (scripts/trace_conv.py)
-int fisr_diag_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters, double* out_us,
+FISR_API int fisr_diag_bench_conv(int precision, int n, int h, int w, int cin, int cout, int flags, int with_res, int iters, double* out_us,
                          int zero_fill, unsigned lomask, const char* trace_file) {
   return bench_conv_impl(precision, n, h, w, cin, cout, flags, with_res, iters, out_us, zero_fill != 0, lomask, trace_file);
 }

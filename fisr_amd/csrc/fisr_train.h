@@ -203,7 +203,7 @@ int fisr_train_wgrad(const float* x0, int c0, const float* x1, int c1, int relu_
 #ifdef FISR_DIAG
 /* diagnostics builds: the same launch with a per-workgroup cycle trace (8 words per workgroup, device memory, at least
  * 1024 workgroups' worth) */
-int fisr_diag_wgrad_trace(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
+FISR_API int fisr_diag_wgrad_trace(const float* x0, int c0, const float* x1, int c1, int relu_in, const float* g, int cg, float* dw, float* db,
                           int ci, int co, int n, int h, int w, void* stream, unsigned long long* d_trace) {
   return wgrad_impl(x0, c0, x1, c1, relu_in, g, cg, dw, db, ci, co, n, h, w, stream, d_trace);
 }

@@ -61,12 +61,12 @@ template <> struct Unit<bsplit> {
   }
 };
 
-template <> struct Unit<fsplit> {   // 8 channels = 16 B of h + 8 B of l8 (+ 8 B of h8 on store), see conv3x3.h
+template <> struct Unit<fsplit> {   // 8 channels = 16 B of h + one 16-byte unit {8 B of l8 | 8 B of h8}, see conv3x3.h
   static constexpr int UC = 8;
   static __device__ __forceinline__ void load(const fsplit* pix, int cu, float* v) {
     const char* b = reinterpret_cast<const char*>(pix) + (cu >> 1) * 64;
     const int half = cu & 1;
-    fsplit_decode8(*reinterpret_cast<const uint4*>(b + half * 16), *reinterpret_cast<const uint2*>(b + 32 + half * 8), v);
+    fsplit_decode8(*reinterpret_cast<const uint4*>(b + half * 16), *reinterpret_cast<const uint2*>(b + 32 + half * 16), v);
   }
   static __device__ __forceinline__ void store(fsplit* pix, int cu, const float* v) {
     uint4 h; uint2 l8, h8;
@@ -74,8 +74,7 @@ template <> struct Unit<fsplit> {   // 8 channels = 16 B of h + 8 B of l8 (+ 8 B
     char* b = reinterpret_cast<char*>(pix) + (cu >> 1) * 64;
     const int half = cu & 1;
     *reinterpret_cast<uint4*>(b + half * 16) = h;
-    *reinterpret_cast<uint2*>(b + 32 + half * 8) = l8;
-    *reinterpret_cast<uint2*>(b + 48 + half * 8) = h8;
+    *reinterpret_cast<uint4*>(b + 32 + half * 16) = make_uint4(l8.x, l8.y, h8.x, h8.y);
   }
 };
 

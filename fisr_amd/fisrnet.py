@@ -36,13 +36,14 @@ _PREC = {"fp32": _lib.PREC_F32W4, "f32": _lib.PREC_F32W4, "float32": _lib.PREC_F
          "fp32d": _lib.PREC_F32, "fp32w4": _lib.PREC_F32W4,      # F(4x4,3x3) Winograd for the large maps (conv3x3_wf4.h)
          "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16, "float16": _lib.PREC_F16,
          "bf16x3": _lib.PREC_BF16X3, "f16f8": _lib.PREC_F16F8, "mixed": _lib.PREC_MIXED,
-         "fp16r": _lib.PREC_F16R, "mixedr": _lib.PREC_MIXEDR}          # round 1's register-staged fp16 kernel (A/B runs)
+         "fp16r": _lib.PREC_F16R, "mixedr": _lib.PREC_MIXEDR,          # round 1's register-staged fp16 kernel (A/B runs)
+         "f16f8r": _lib.PREC_F16F8R}                                   # ... and its f16f8 form (r05: "f16f8" runs conv3x3_dma_fs.h)
 
 
 # ONE default arithmetic for every entry point (FISRnet(), main.py, bench.py): the reference computes in
 # fp32 (cfg2 of BASELINE.json), so the default is the fp32 engine; the split-precision modes are opt-in.
 DEFAULT_PRECISION = "fp32"
-PRECISIONS = ("fp32", "fp32w4", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16", "fp16r", "mixedr")     # CLI names
+PRECISIONS = ("fp32", "fp32w4", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16", "fp16r", "mixedr", "f16f8r")     # CLI names
 
 
 def _torch():

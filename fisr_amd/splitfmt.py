@@ -42,7 +42,8 @@ def split_round(x: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------------------------
-# fp16 + fp8 split ("f16f8", FISR_PREC_F16F8): per 16 channels 16 x fp16 h | 16 x fp8 l8 | 16 x fp8 h8
+# fp16 + fp8 split ("f16f8", FISR_PREC_F16F8): per 16 channels 16 x fp16 h | l8, h8 of channels 0-7 | l8, h8 of channels 8-15
+# (8 x fp8 each; conv3x3.h: the fp8 fields are interleaved per 8 channels)
 # ----------------------------------------------------------------------------------------------
 FS_LSHIFT = 14
 
@@ -82,13 +83,13 @@ def to_fsplit(x: np.ndarray) -> np.ndarray:
     hf = h.astype(np.float32)
     l8 = fp8_e4m3_encode(np.clip((g - hf) * np.float32(2 ** FS_LSHIFT), -448, 448))
     h8 = fp8_e4m3_encode(np.clip(hf, -448, 448))
-    return np.ascontiguousarray(np.concatenate([h.view(np.uint8).reshape(g.shape[:-1] + (32,)), l8, h8], axis=-1))
+    return np.ascontiguousarray(np.concatenate([h.view(np.uint8).reshape(g.shape[:-1] + (32,)), l8[..., :8], h8[..., :8], l8[..., 8:], h8[..., 8:]], axis=-1))
 
 
 def from_fsplit(s: np.ndarray) -> np.ndarray:
     """uint8 [..., C/16, 64] -> float32 [..., C]  (x = h + l8 * 2^-14)."""
     s = np.ascontiguousarray(s, np.uint8)
     h = s[..., :32].copy().view(np.float16).astype(np.float32)
-    l = fp8_e4m3_decode(s[..., 32:48]) * np.float32(2.0 ** -FS_LSHIFT)
+    l = fp8_e4m3_decode(np.concatenate([s[..., 32:40], s[..., 48:56]], axis=-1)) * np.float32(2.0 ** -FS_LSHIFT)
     v = h + l
     return v.reshape(v.shape[:-2] + (v.shape[-2] * 16,))

@@ -68,22 +68,26 @@ enum {
                           the fp64 oracle <= 0.005 dB on the three weight sets of tests/, 0.007 dB on the worst of 30
                           full-size windows (all-fp16: 0.026 dB, outside north_star's +-0.02 dB). */
   FISR_PREC_F16F8 = 3, /* fp16 + fp8 split: x ~ h + l8*2^-14 (h = fp16(x)); per pixel and 16 channels
-                          16 x fp16 h (32 B), 16 x fp8-e4m3 l8 (16 B), 16 x fp8-e4m3 copy of h (16 B).
+                          16 x fp16 h (32 B), then per 8 channels 8 x fp8-e4m3 l8 and 8 x fp8-e4m3 copy of h (2 x 16 B; r05:
+                          the fp8 fields are interleaved per 8 channels).
                           Product = a_h*w_h (v_mfma_f32_32x32x16_f16) + both cross terms in ONE
                           block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per pair of taps: ~2^-15
                           relative per product at 2.1 instead of 3 MFMA-units (fp32 accumulate).  Values beyond
-                          the fp16 range saturate to +-65504 when stored (no inf). */
+                          the fp16 range saturate to +-65504 when stored (no inf).  r05: the convolutions with Cout % 64 == 0
+                          run on the persistent LDS-DMA kernel (conv3x3_dma_fs.h: same products, another summation order). */
   FISR_PREC_F16R = 6,  /* FISR_PREC_F16 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h);
                           FISR_PREC_F16 itself runs the convolutions with Cout > 32 on the LDS-DMA kernel (conv3x3_dma.h: same
                           products, another summation order inside a chunk -> results agree to fp32 rounding).  For A/B runs. */
   FISR_PREC_MIXEDR = 7, /* engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
-  FISR_PREC_F32W4 = 8  /* fp32 activations/weights and arithmetic like FISR_PREC_F32W, with Winograd F(4x4,3x3) (conv3x3_wf4.h: 36
+  FISR_PREC_F32W4 = 8, /* fp32 activations/weights and arithmetic like FISR_PREC_F32W, with Winograd F(4x4,3x3) (conv3x3_wf4.h: 36
                           multiplies per 4x4 outputs on v_mfma_f32_16x16x4_f32, a quarter of the direct algorithm's) for the
                           convolutions with Cout % 64 == 0 on maps of at least 48 x 64 pixels and on 512-channel maps (op level: on
                           every map); smaller maps and the rest as in FISR_PREC_F32W; the 2x2 max pooling behind an encoder level
                           is a second store of that level's last convolution.  The F(4,3) transforms are worse conditioned: ~2e-5
                           instead of ~2e-6 per convolution against float64 -- through the network it does not add up (1.5e-6 on the
                           full tile, the F(2x2) engine's figure).  What fisrnet.py's "fp32" selects since round 3. */
+  FISR_PREC_F16F8R = 9 /* FISR_PREC_F16F8 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h).
+                          For A/B runs, as FISR_PREC_F16R is for fp16. */
 };
 
 /* flags of fisr_op_conv3x3 */

@@ -21,7 +21,7 @@ SHAPES = [  # n, h, w, cin, cout, flags, res
 ]
 if os.environ.get("CONV_SHAPES"):   # "n,h,w,cin,cout,flags,res;..."
     SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["CONV_SHAPES"].split(";")]
-PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4, "fp16r": 6, "fp32w4": 8}
+PID = {"fp32": 0, "fp16": 1, "bf16x3": 2, "f16f8": 3, "fp32w": 4, "fp16r": 6, "fp32w4": 8, "f16f8r": 9}
 L = lib.lib()
 for prec in (sys.argv[1:] or ["bf16x3"]):
     for (n, h, w, ci, co, fl, rs) in SHAPES:
