@@ -49,20 +49,21 @@ def _src_of(library):
     return m.group(1) if m else None
 
 
-def _pmc_table_checked(running_library):
-    """profiles/pmc_traffic.json, or {} when it was measured on another library (its `_meta.library` names the build): a counter
-    of another kernel build under this build's name would read as measured."""
+def _pmc_table_checked(running_library, engine=None):
+    """profiles/pmc_traffic[_<engine>].json, or {} when it was measured on another library (its `_meta.library` names the build): a
+    counter of another kernel build under this build's name would read as measured."""
     global PMC_SRC
-    pmc = _pmc_table()
+    pmc = _pmc_table(engine)
+    fname = os.path.relpath(_pmc_file(engine), ROOT)
     meta = pmc.pop("_meta", None) or {}
     have, want = _src_of(meta.get("library")), _src_of(running_library)
     if not pmc:
-        PMC_SRC = {"file": "profiles/pmc_traffic.json", "status": "absent"}
+        PMC_SRC = {"file": fname, "status": "absent"}
         return {}, meta
     if have is None or have != want:
-        PMC_SRC = {"file": "profiles/pmc_traffic.json", "status": "dropped: measured on library src %s, running src %s" % (have, want)}
+        PMC_SRC = {"file": fname, "status": "dropped: measured on library src %s, running src %s" % (have, want)}
         return {}, meta
-    PMC_SRC = {"file": "profiles/pmc_traffic.json", "status": "same library", "library_src": have,
+    PMC_SRC = {"file": fname, "status": "same library", "library_src": have,
                "how": "rocprofv3 --pmc, separate passes (FETCH_SIZE x 2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE), scripts/gpu_profile.sh"}
     return pmc, meta
 
@@ -153,18 +154,29 @@ def expected_step_ms(precision, parallelism, patch):
     return best
 
 
-def _pmc_table():
+def _pmc_file(engine=None):
+    """profiles/pmc_traffic_<engine>.json when that engine was profiled ALONE (r05: `mixed` shares kernel names with f16f8 / fp16, so a
+    table of all engines in one run can never match its launch population), else the table of the all-engines run"""
+    own = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % engine) if engine else None
+    return own if own and os.path.isfile(own) else os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def _pmc_table(engine=None):
     """HBM bytes per launch of every kernel, from the rocprofv3 PMC passes of this same command
-    (scripts/gpu_profile.sh -> profiles/pmc_traffic.json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    (scripts/gpu_profile.sh -> profiles/pmc_traffic[_<engine>].json; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     separate passes as MI355X_MICROARCH.md prescribes)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(_pmc_file(engine)) as f:
             return json.load(f)
     except (OSError, ValueError):
         return {}
 
 
 def _pmc_key(name):
+    if name.startswith("conv3x3_dma_fs"):       # "conv3x3_dma_fs<f16f8,tw32,relu_in,nores>" -> conv3x3_dma_fs_kernel<32, true, false, false>
+        f = name.split("<")[1].rstrip(">").split(",")
+        return "conv3x3_dma_fs_kernel<%s, %s, %s, %s>" % (f[1][2:], "true" if f[2] == "relu_in" else "false",
+                                                         "false" if f[3] == "nores" else "true", "true" if f[3] == "res+pool" else "false")
     if name.startswith("conv3x3_dma"):
         return "conv3x3_dma_f16_kernel<false>"
     if name.startswith("conv3x3_wf4"):
@@ -226,7 +238,7 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
     if not convs:
         return None
     from fisr_amd import lib as _fl
-    pmc, pmc_meta = _pmc_table_checked(_fl.lib().fisr_version().decode())
+    pmc, pmc_meta = _pmc_table_checked(_fl.lib().fisr_version().decode(), precision)
     lps = {p["name"]: p["launches"] / max(reps, 1) for p in prof}          # launches per step of this run, per kernel
     dropped = []
 
@@ -276,6 +288,8 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
         if e and "hbm_bytes_per_launch" in e:
             rec["pmc_gb_per_launch"] = round(e["hbm_bytes_per_launch"] / 1e9, 4)
             rec["pmc_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / max(alg_bytes / launches, 1.0), 3)
+        if e and "valu_issue_frac" in e:      # (the heads: vector-ALU kernels -- their floor is this, not the bytes; profiles/r05_heads_pmc.txt)
+            rec["pmc_valu_issue_frac"] = round(e["valu_issue_frac"], 3)
         hbm[name] = rec
 
     for p in prof:

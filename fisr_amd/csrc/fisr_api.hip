@@ -37,6 +37,10 @@
 #include "diag/conv3x3_wino8.h"
 #endif
 #include "head_conv.h"
+#include "head_conv_strip.h"
+#ifndef FISR_HEAD_STRIP_DEFAULT
+#define FISR_HEAD_STRIP_DEFAULT 0      // decided by measurement
+#endif
 #include "glue_kernels.h"
 
 using namespace fisr;
@@ -513,6 +517,13 @@ inline bool head_valu_enabled() {
   return true;
 #endif
 }
+inline bool head_strip_enabled() {
+#ifdef FISR_DIAG
+  static const int forced = [] { const char* e = getenv("FISR_HEAD_STRIP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  if (forced >= 0) return forced != 0;
+#endif
+  return FISR_HEAD_STRIP_DEFAULT != 0;
+}
 hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st) {
   static bool attr_done[64] = {};
   int dev = 0;
@@ -528,6 +539,8 @@ hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st
   h.in = (const float*)a.in0; h.w = d_wh; h.bias = a.bias; h.out = (float*)a.out;
   h.N = a.N; h.H = a.H; h.W = a.W; h.Cin = a.C0; h.Cout = a.Cout; h.relu_in = a.relu_in; h.relu_out = a.relu_out;
   h.out_cstride = a.out_cstride; h.out_coff = a.out_coff; h.out_split = a.out_split; h.out_gap = a.out_gap;
+  // the strip-walking LDS-DMA form (head_conv_strip.h, r05) where it takes the shape; FISR_DIAG builds: FISR_HEAD_STRIP=0 | 1 forces one
+  if (head_strip_enabled() && head_strip_fits(a.H, a.W, a.C0)) return launch_head_strip(h, st);
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + HEAD_TH - 1) / HEAD_TH) * a.N;
   if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(HEAD_NTHR), head_lds_bytes<2>(), st, h);
   else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(HEAD_NTHR), head_lds_bytes<3>(), st, h);
@@ -863,7 +876,7 @@ struct Runner {
     if (use_dma || use_dmafs) { a.wpk = cw.d_wd; a.CoutPad = cw.cout_pad_d; }
     char cls[96];
     if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
-    else if (use_dmafs) snprintf(cls, sizeof cls, "conv3x3_dma_fs<f16f8,%s,%s>", a.relu_in ? "relu_in" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
+    else if (use_dmafs) snprintf(cls, sizeof cls, "conv3x3_dma_fs<f16f8,tw%d,%s,%s>", dmafs_tile_w(a), a.relu_in ? "relu_in" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : ups ? "up2" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");

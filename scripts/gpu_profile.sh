@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps ${STEPS:-2} --warmup 1 --precision $PREC --others $OTHERS --no-cpu-baseline --no-roofline --no-parity --no-flow --no-train"
 echo "== kernel trace + stats"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1; echo "rc=$?"
-echo "== pmc pass 1 (SQ / MFMA busy)"
-timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc1" -o pmc1 -- $CMD > "$OUT/pmc1.log" 2>&1; echo "rc=$?"
+echo "== pmc pass 1 (SQ / MFMA busy / vector-ALU instructions)"
+timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU --kernel-trace -d "$OUT/pmc1" -o pmc1 -- $CMD > "$OUT/pmc1.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 2 (LDS / waits)"
 timeout 900 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace -d "$OUT/pmc2" -o pmc2 -- $CMD > "$OUT/pmc2.log" 2>&1; echo "rc=$?"
 echo "== pmc pass 3 (HBM read)"

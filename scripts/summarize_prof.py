@@ -90,11 +90,11 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
     cur = sqlite3.connect(f).cursor()
     try:
         rows = list(cur.execute("select name, counter_name, count(*), sum(counter_value), sum(duration) from pmc_events "
-                                "where counter_name in ('SQ_VALU_MFMA_BUSY_CYCLES','GRBM_GUI_ACTIVE') group by name, counter_name"))
+                                "where counter_name in ('SQ_VALU_MFMA_BUSY_CYCLES','GRBM_GUI_ACTIVE','SQ_INSTS_VALU') group by name, counter_name"))
     except sqlite3.Error:
         try:
             rows = [r + (None,) for r in cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
-                                                     "where counter_name in ('SQ_VALU_MFMA_BUSY_CYCLES','GRBM_GUI_ACTIVE') group by name, counter_name")]
+                                                     "where counter_name in ('SQ_VALU_MFMA_BUSY_CYCLES','GRBM_GUI_ACTIVE','SQ_INSTS_VALU') group by name, counter_name")]
         except sqlite3.Error:
             continue
     agg = defaultdict(dict)
@@ -107,6 +107,8 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
             e["gui_active_cycles_per_launch"] = d["GRBM_GUI_ACTIVE"][1] / max(d["GRBM_GUI_ACTIVE"][0], 1)
             if k in durations:
                 e["shader_clock_mhz"] = e["gui_active_cycles_per_launch"] / (durations[k][1] / 1e3)
+            if "SQ_INSTS_VALU" in d:      # a wave64 vector instruction holds its SIMD's vector ALU for 4 cycles (packed fp32 included)
+                e["valu_issue_frac"] = 4.0 * d["SQ_INSTS_VALU"][1] / (1024.0 * d["GRBM_GUI_ACTIVE"][1] / 8.0)
 # ---- which run this is: the library string (it carries the sha256 of csrc/ + include/fisr.h) and the number of steps, read from the
 # bench line of the trace pass -- bench.py drops counter-derived fields whose run is not the running library's, or whose launch
 # population (dispatches per step) is not the one it sees

@@ -1223,7 +1223,9 @@ def test_winograd_f4_vs_direct_random_large_shapes():
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,flags", [(1, 8, 32, 64, 6, 0), (2, 13, 45, 64, 3, 1), (1, 37, 70, 32, 6, 3), (3, 5, 9, 64, 5, 0),
-                                                   (1, 64, 96, 64, 6, 1), (1, 16, 33, 128, 2, 2)])
+                                                   (1, 64, 96, 64, 6, 1), (1, 16, 33, 128, 2, 2),
+                                                   # (several strips / segments / ring rounds of head_conv_strip.h)
+                                                   (2, 150, 95, 64, 6, 1), (1, 300, 64, 64, 3, 0), (1, 41, 200, 64, 4, 3)])
 def test_fp32_heads_on_the_vector_alu_vs_oracle(n, h, w, cin, cout, flags):
     """head_conv.h (the fp32 engine's 3 / 6-channel heads, FISRnet.py:100,105) through the conv op: ragged tiles, relu in /
     out, channel counts the forward does not use."""
