@@ -211,7 +211,11 @@ inline bool prec_ok(int precision) {
 // full-size window --, this plan by 0.004 dB.)
 inline bool mixed_layer_is_hi(const std::string& name) {
   static const char* const hi[] = {"FISRnet/level_3/enc/level_0/", "FISRnet/level_3/enc/level_1/", "FISRnet/level_3/dec/level_1/",
-                                   "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/SR/"};
+                                   "FISRnet/level_3/dec/level_0/", "FISRnet/level_3/SR/",
+#ifdef FISR_MIXED_FISR_SPLIT
+                                   "FISRnet/level_3/FI-SR/",
+#endif
+  };
   for (const char* h : hi)
     if (name.compare(0, strlen(h), h) == 0) return true;
   return false;
@@ -1127,6 +1131,14 @@ struct MixedRunner {
     if (hi.rc) return hi.rc;
     lo.ar = hi.ar;
     // (the fp16 branch works inside the SR branch's scratch: S is dead once SR/conv/2 has been enqueued on the same stream)
+#ifdef FISR_MIXED_FISR_SPLIT
+    // A/B build (lib.build(defines=["FISR_MIXED_FISR_SPLIT"])): the FI-SR branch stays in the split format, as before r04 -- kept until
+    // --check_published has been run on the real checkpoint (the fp16 branch's accuracy was measured with synthetic weights)
+    hi.head(P, 0, top, n, h, w, l3, Hx, A, S);
+    lo.ar = hi.ar;
+    return hi.rc;
+#endif
+    static_assert(sizeof(THi) * 256 >= sizeof(_Float16) * 448, "the fp16 FI-SR branch lives inside the SR branch's scratch S: [4 px, 64] THi must hold [px, 448] fp16");
     _Float16* s16 = (_Float16*)S;                  // px * 4 * 64 fsplit = 8 x px x 64 fp16
     _Float16* top16 = s16;                         // [px, 64]
     _Float16* Hx16 = s16 + px * 64;

@@ -240,17 +240,41 @@ def prepare_scene_set(net, args, ss: int = 1, data_path=None, flow_path=None, wa
     return flow, warp, flow_path, warp_path
 
 
+def _pad_mode(net) -> bool:
+    return bool(getattr(getattr(net, "args", None), "pad_mode", False))
+
+
+def _frame_hw(net, H, W, num_patch):
+    """the size the network runs on: the reference's crop (FISRnet.py:820-824) or, with --pad_mode, the padded frame"""
+    return tiling.pad_hw(H, W, num_patch) if _pad_mode(net) else tiling.crop_hw(H, W, num_patch)
+
+
+def _pad_window(src, H, W, hp, wp):
+    """--pad_mode: frames / flows / warps [H, W, c] -> [hp, wp, c], the last row / column repeated (edge replication)"""
+    import torch
+    if (hp, wp) == (H, W):
+        return src
+    dev = src[0][0].device
+    iy = torch.arange(hp, device=dev).clamp_(max=H - 1)
+    ix = torch.arange(wp, device=dev).clamp_(max=W - 1)
+    pad = lambda t: t[:H, :W].index_select(0, iy).index_select(1, ix).contiguous()
+    return tuple([pad(t) for t in group] for group in src)
+
+
 def _window_inputs(net, frame_paths, flow_seq, warp_seq, scene_i, sample_i, n_test_in_seq, H, W, num_patch):
     """Device tensors for one 3-frame window (FISRnet.py:803-843): (frames, flows, warps) as pack_input / forward_tiled_frames take
     them, and the crop size."""
     import torch
-    h, w = tiling.crop_hw(H, W, num_patch)
+    h, w = _frame_hw(net, H, W, num_patch)
     frames = [torch.from_numpy(fio.read_png(frame_paths[scene_i * n_test_in_seq + sample_i + k])).to(net.device)
               for k in range(3)]
     # flow[scene, :, :, 4*s : 4*s+8] = flow sequence entries 2s..2s+3; warp likewise (6s..6s+12)
     flows = [torch.from_numpy(np.ascontiguousarray(flow_seq[scene_i, 2 * sample_i + k])).to(net.device) for k in range(4)]
     warps = [torch.from_numpy(np.ascontiguousarray(warp_seq[scene_i, 2 * sample_i + k])).to(net.device) for k in range(4)]
-    return (frames, flows, warps), h, w
+    src = (frames, flows, warps)
+    if _pad_mode(net):
+        src = _pad_window(src, H, W, h, w)
+    return src, h, w
 
 
 def run_test(net):
@@ -291,6 +315,9 @@ def run_test(net):
             # input assembly (FISRnet.py:828-843), the tile loop (:847-880) and the forward in one call per group of equal tiles:
             # bit-identical to pack_input -> forward_tiled (tests/test_gpu_frames.py)
             full = net.forward_tiled_frames([src], h, w, num_patch, timed=True)
+            if _pad_mode(net):          # the padded rows / columns were input only: the frame is H x W again
+                h, w = min(h, H), min(w, W)
+                full = full[:h * sf, :w * sf].contiguous()
             yuv_u8, rgb_u8 = net.unpack_output(full)
             have_gt = len(label_paths) >= (scene_i + 1) * n_test_label_seq
             psnr, ssim, psnr_y = [float("nan")] * 3, [float("nan")] * 3, [float("nan")] * 3
@@ -402,12 +429,15 @@ def run_fisr_for_video(net, flow_file_name, warp_file_name, parallel=None):
     else:
         my_windows = list(range(n_win))
         writer = True
-    h, w = tiling.crop_hw(H, W, num_patch)
+    if _pad_mode(net) and parallel == "tile":
+        raise ValueError("--pad_mode is not available with tile-parallel ranks (the halo exchange works on the cropped frame)")
+    h, w = _frame_hw(net, H, W, num_patch)
 
     def window_tensors(fr):
-        return ([torch.from_numpy(fio.read_png(paths[fr + k])).to(net.device) for k in range(3)],
-                [torch.from_numpy(np.ascontiguousarray(flow[fr, k])).to(net.device) for k in range(4)],
-                [torch.from_numpy(np.ascontiguousarray(warp[fr, k])).to(net.device) for k in range(4)])
+        src = ([torch.from_numpy(fio.read_png(paths[fr + k])).to(net.device) for k in range(3)],
+               [torch.from_numpy(np.ascontiguousarray(flow[fr, k])).to(net.device) for k in range(4)],
+               [torch.from_numpy(np.ascontiguousarray(warp[fr, k])).to(net.device) for k in range(4)])
+        return _pad_window(src, H, W, h, w) if _pad_mode(net) else src
 
     # tile-parallel: the core packing + halo all-gather of the NEXT window run on a side stream under this window's forward
     prefetch = fdist.HaloPrefetcher(num_patch, net.device, group=grp) if parallel == "tile" else None
@@ -441,6 +471,8 @@ def run_fisr_for_video(net, flow_file_name, warp_file_name, parallel=None):
             next_t = window_tensors(my_windows[wi + 2]) if wi + 2 < len(my_windows) else None
         else:
             full = net.forward_tiled_frames([(frames, flows, warps)], h, w, num_patch, timed=True)
+            if _pad_mode(net):
+                full = full[:min(h, H) * sf, :min(w, W) * sf].contiguous()
             yuv_u8, rgb_u8 = net.unpack_output(full)
         if writer:
             yuv_host = yuv_u8.cpu().numpy()

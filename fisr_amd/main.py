@@ -108,6 +108,10 @@ def parse_args(argv=None):
                         "GPU (the reference's FISR_pwcnet_predict_from_img_test.py + FISR_warp_mat_with_flo.py): 'auto' = when neither "
                         "file exists, 'always', 'never', 'only' = make the files (also the ss2 pair with --prepare_ss 2) and stop")
     p.add_argument("--prepare_ss", type=int, default=1, choices=[1, 2], help="temporal stride of --prepare only (ss1 / ss2 files)")
+    p.add_argument("--pad_mode", action="store_true",
+                   help="not in the reference (FISRnet.py:820-825 crops the frame to a multiple of 32 x patches: 1080 -> 1024 rows, a "
+                        "2048 x 3840 output): replicate-pad the inputs instead (1080 -> 1088), predict, and crop the output to 2 H x 2 W "
+                        "(2160 x 3840).  Default off: the reference's crop, bit for bit")
     p.add_argument("--no_batch_tiles", dest="batch_tiles", action="store_false",
                    help="run the tiles of a window one forward at a time (reference schedule, smallest workspace)")
     p.add_argument("--device", type=str, default=None, help="default cuda:<LOCAL_RANK>")

@@ -76,7 +76,7 @@ def _crc32c_lanes(buf, c: int) -> int:
     state = np.zeros(K, dtype=np.uint32)
     state[0] = c
     cols = a[:K * L].reshape(K, L)
-    step = 2048                                             # transpose a slab of byte positions at a time (bounded extra memory)
+    step = max(1, (32 << 20) // (4 * K))                    # transpose a slab of byte positions at a time: <= 32 MB of uint32 (+ 8 MB of bytes)
     for j0 in range(0, L, step):
         slab = np.ascontiguousarray(cols[:, j0:j0 + step].T).astype(np.uint32)
         for row in slab:

@@ -44,6 +44,13 @@ def crop_hw(H: int, W: int, num_patch: Tuple[int, int]) -> Tuple[int, int]:
     return H - H % (32 * num_patch[0]), W - W % (32 * num_patch[1])
 
 
+def pad_hw(H: int, W: int, num_patch: Tuple[int, int]) -> Tuple[int, int]:
+    """`--pad_mode` (not in the reference): the size the frame is replicate-padded to, so that the rows / columns
+    FISRnet.py:820-824 crops away (56 of 1080 rows with 2 x 2 patches) are predicted too."""
+    mh, mw = 32 * num_patch[0], 32 * num_patch[1]
+    return (H + mh - 1) // mh * mh, (W + mw - 1) // mw * mw
+
+
 def get_hw_boundary(pb: int, h: int, w: int, pH: int, sH: int, pW: int, sW: int):
     """utils.py:118-135."""
     h_lo = max(pH * sH - pb, 0)

@@ -1,6 +1,7 @@
 """GPU end-to-end tests of the reference's drivers (cfg1 of BASELINE.json: `main.py --phase test`
 on the 96x96 LR 5-frame crop of scene1) through the CLI mirror, against oracle-derived numbers."""
 import os
+import shutil
 
 import numpy as np
 import pytest
@@ -96,6 +97,48 @@ def test_phase_test_cfg1(scene, prec, capsys):
     exp = O.yuv_u8_to_rgb_u8(O.quantize_u8(scene["preds"][2][..., 6:9]))
     assert (np.abs(last.astype(int) - exp.astype(int)) > 1).mean() < 1e-3   # +-1 LSB at truncation boundaries only
     net.close()
+
+
+def test_pad_mode_predicts_the_rows_the_reference_crops_away(scene, tmp_path):
+    """--pad_mode (not in the reference): an 80 x 96 scene, which FISRnet.py:820-824 crops to 64 x 96 (a 128 x 192 output),
+    comes out as 160 x 192 -- bit for bit what the default mode makes of the same inputs padded by hand to 96 x 96 (edge replication),
+    cropped; and the default mode is what it was."""
+    from fisr_amd.fisrnet import FISRnet
+    g = scene["g"]
+
+    def make(root, frames, flows, warps):
+        (root / "LR_LFR").mkdir(parents=True)
+        for i in range(5):
+            fio.write_png(str(root / "LR_LFR" / f"LR_vid_1_fr_07171_seq_{2 * i + 1}.png"), frames[i])
+        fio.write_flow(flows, str(root / "flow.flo"))
+        fio.write_warp_file(str(root / "warp.npy"), warps)
+
+    def run(root, size, extra=()):
+        r = scene["root"]
+        args = fmain.parse_args(["--phase", "test", "--test_data_path", str(root / "LR_LFR"), "--test_label_path", str(root / "none"),
+                                 "--test_flow_data_path", str(root / "flow.flo"), "--test_warped_data_path", str(root / "warp.npy"),
+                                 "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(root / "out"),
+                                 "--text_dir", str(root / "text_dir"), "--log_dir", str(root / "logdir"),
+                                 "--test_patch", "(1,1)", "--test_input_size", size, "--prepare", "never", *extra])
+        net = FISRnet(args)
+        net.test()
+        net.close()
+        d = root / "out" / "FISRnet_exp1"
+        return [fio.read_png(str(d / n)) for n in sorted(os.listdir(d))]
+
+    a, b = tmp_path / "short", tmp_path / "padded"
+    frames80 = [f[:80] for f in g["frames"]]
+    make(a, frames80, g["flows"][:, :, :80], g["warps"][:, :, :80])
+    rep = lambda x, ax: np.concatenate([x, np.repeat(np.take(x, [-1], axis=ax), 16, axis=ax)], axis=ax)
+    make(b, [rep(f, 0) for f in frames80], rep(g["flows"][:, :, :80], 2), rep(g["warps"][:, :, :80], 2))
+    dflt = run(a, "80,96")
+    assert all(im.shape == (128, 192, 3) for im in dflt)                   # the reference's crop: 80 -> 64 rows
+    shutil.rmtree(a / "out")
+    padded = run(a, "80,96", ["--pad_mode"])
+    by_hand = run(b, "96,96")
+    assert len(padded) == len(by_hand) == len(dflt) == 9
+    for p_, h_ in zip(padded, by_hand):
+        assert p_.shape == (160, 192, 3) and np.array_equal(p_, h_[:160])
 
 
 def test_phase_fisr_for_video(scene):

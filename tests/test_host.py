@@ -49,6 +49,10 @@ def test_npz_roundtrip_and_checkpoint_lookup(tmp_path, syn_weights):
 def test_tiles_default_1080p():
     assert tiling.crop_hw(1080, 1920, (2, 2)) == (1024, 1920)
     assert tiling.crop_hw(1080, 1920, (1, 1)) == (1056, 1920)
+    # --pad_mode: the frame is padded up instead, 1080 -> 1088 rows, and 2 x 2 tiles of 576 x 992 cover it
+    assert tiling.pad_hw(1080, 1920, (2, 2)) == (1088, 1920) and tiling.pad_hw(1080, 1920, (1, 1)) == (1088, 1920)
+    assert tiling.pad_hw(1024, 1920, (2, 2)) == (1024, 1920)
+    assert [(t.in_h, t.in_w) for t in tiling.plan_tiles(1088, 1920, (2, 2))] == [(576, 992)] * 4
     tiles = tiling.plan_tiles(1024, 1920, (2, 2))
     assert [(t.h_lo, t.h_hi, t.w_lo, t.w_hi) for t in tiles] == [
         (0, 544, 0, 992), (0, 544, 928, 1920), (480, 1024, 0, 992), (480, 1024, 928, 1920)]
