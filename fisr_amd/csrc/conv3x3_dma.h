@@ -322,14 +322,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
   auto act = [&](float v_) { return fmaxf(v_, leaky ? lk * v_ : relu_floor); };
   const int cq_shift = p.d2s_shift;
   const int x = (x0 + 32 * cg + li) * dil + rx;
+  // Stores: a lane's 16-channel record is 32 bytes = two 16-byte units.  Written by the lane alone (two instructions, each a
+  // 16-byte piece per pixel) the launch put 1.58 x its output bytes on the HBM write path (r05, WRITE_SIZE: 1.31 GB for 0.83 GB at
+  // 64 -> 64 @ 12 x 544 x 992; partial 32-byte sectors from non-temporal 16-byte pieces).  Now neighbouring lanes trade one unit
+  // (DPP quad_perm [1,0,3,2]): instruction 0 writes the EVEN lane's record -- the even lane its first unit, the odd lane the
+  // second --, instruction 1 the odd lane's, so every instruction writes whole 32-byte records (64 contiguous bytes with the
+  // kh = 1 half of the wave).  No lane leaves before the exchange: validity travels with the offsets.
+  const bool odd = (li & 1) != 0;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int y = (y0 + 4 * rg + m) * dil + ry;
-    if (y >= p.H || x >= p.W) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int c0 = n0 + 32 * j + 16 * kh;
-      if (c0 >= p.Cout) continue;
+      const bool ok = y < p.H && x < p.W && c0 < p.Cout;
       float vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) vv[r] = act(acc[m][j][r]);
@@ -342,12 +349,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_f16_kernel(const ConvArgs 
       } else {
         e = ((size_t)(nb * p.H + y) * p.W + x) * rec_cs + rec_co + c0;
       }
-      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-      u32x4_t* ob = reinterpret_cast<u32x4_t*>((T*)p.out + e);
-#pragma unroll
-      for (int k = 0; k < R16::NV; ++k) {
-        u32x4_t nv; nv.x = q[k].x; nv.y = q[k].y; nv.z = q[k].z; nv.w = q[k].w;
-        __builtin_nontemporal_store(nv, ob + k);       // streaming: the activation tensors are never re-read from cache by this kernel
+      static_assert(R16::NV == 2, "fp16 records are two 16-byte units");
+      // the unit this lane gives away: the even lane its second, the odd lane its first
+      const uint4 give = odd ? q[0] : q[1];
+      uint4 got;
+      got.x = dpp_quad_xor1(give.x); got.y = dpp_quad_xor1(give.y); got.z = dpp_quad_xor1(give.z); got.w = dpp_quad_xor1(give.w);
+      const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32), okw = ok ? 1u : 0u;
+      const uint32_t plo = dpp_quad_xor1(elo), phi = dpp_quad_xor1(ehi), pok = dpp_quad_xor1(okw);
+      const size_t e_pair = ((size_t)phi << 32) | plo;
+      // instruction 0: the even lane's record (pixel A), instruction 1: the odd lane's (pixel B); this lane's unit = its parity
+      const size_t eA = odd ? e_pair : e, eB = odd ? e : e_pair;
+      const bool okA = odd ? pok != 0 : ok, okB = odd ? ok : pok != 0;
+      const uint4 uA = odd ? got : q[0], uB = odd ? q[1] : got;
+      const int uo = odd ? 8 : 0;                         // elements: the second 16-byte unit of a record
+#ifndef FISR_DMA_STORE_NT
+#define FISR_DMA_STORE_NT 0      // A/B hook: 1 = non-temporal stores (r03's choice)
+#endif
+      if (okA) {
+        u32x4_t nv; nv.x = uA.x; nv.y = uA.y; nv.z = uA.z; nv.w = uA.w;
+        if (FISR_DMA_STORE_NT) __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>((T*)p.out + eA + uo));
+        else *reinterpret_cast<u32x4_t*>((T*)p.out + eA + uo) = nv;
+      }
+      if (okB) {
+        u32x4_t nv; nv.x = uB.x; nv.y = uB.y; nv.z = uB.z; nv.w = uB.w;
+        if (FISR_DMA_STORE_NT) __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t*>((T*)p.out + eB + uo));
+        else *reinterpret_cast<u32x4_t*>((T*)p.out + eB + uo) = nv;
       }
     }
   }
