@@ -48,7 +48,7 @@ constexpr int FS_WM_BYTES = 9 * FS_BN * 32;                            // 18432:
 constexpr int FS_WX_BYTES = 4 * 4096 + 2048;                           // 18432: four tap pairs x 4 planes + tap 8 x 2 planes
 constexpr int FS_W_BYTES = FS_WM_BYTES + FS_WX_BYTES;                  // 36864
 constexpr int FS_W_COPIES = FS_W_BYTES / 1024;                         // 36: nine per wave
-constexpr size_t dmafs_lds_bytes(int tw, int ph = 1) { return (size_t)fs_halo_bytes(tw) + (ph == 2 ? FS_WM_BYTES : FS_W_BYTES); }      // 79872 / 59392: two workgroups per CU; 40960 (two phases): three
+constexpr size_t dmafs_lds_bytes(int tw) { return (size_t)fs_halo_bytes(tw) + FS_W_BYTES; }      // 79872 / 59392: two workgroups per CU
 
 #define FISR_FS_BEGIN(KEEP, LDS)   "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
 #define FISR_FS_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen lds\n\t"
@@ -95,12 +95,8 @@ __device__ __forceinline__ void fsplit_encode16_sat(const float* v, uint4* q) {
 //     bytes fetched from HBM (r05, FETCH_SIZE); 2.8 MB with the narrow one.  Layers with several output blocks share their lines
 //     between the blocks of a tile (neighbours in the XCD's range) and keep the wide tile.
 // RELU_IN: conv(relu(x)); HAS_RES: + residual (plain layout, may alias out); POOL: the 2x2 maxima of the output as a second store
-// PH: 1 = a chunk's weights as one slab (above); 2 (narrow tile only) = in two phases through ONE 18 KB buffer -- the w_h image
-//     under the 36 fp16 MFMAs of a wave, then the fp8 groups under its 20 block-scaled ones -- which takes a workgroup to 40 KB of
-//     LDS and (its two phases never hold h rows and fp8 rows at once) under 168 registers: THREE workgroups per CU.
-template <int TW, bool RELU_IN, bool HAS_RES, bool POOL, int PH = 1>
-__global__ __launch_bounds__(256, PH == 2 ? 3 : 2) void conv3x3_dma_fs_kernel(const ConvArgs p, const int n_items) {
-  static_assert(PH == 1 || (PH == 2 && TW == 32), "the two-phase form exists for the narrow tile");
+template <int TW, bool RELU_IN, bool HAS_RES, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p, const int n_items) {
   typedef fsplit T;
   typedef Rec16<T> R16;
   constexpr int FS_TW = TW, FS_HW = TW + 2;
@@ -175,22 +171,6 @@ __global__ __launch_bounds__(256, PH == 2 ? 3 : 2) void conv3x3_dma_fs_kernel(co
       hoff[q] = ok ? (unsigned)(gy * p.W + gx) * pix_bytes + unit * 16u : OOB;
     }
   };
-  // (two phases) 18 linear copies of 1 KB from byte `from` of the weight table into the weight buffer: waves 0, 1 five, waves 2, 3 four
-  auto copy_half = [&](unsigned from) {
-    unsigned keep;
-    unsigned sw = from + (unsigned)wave * 1024u;
-    const unsigned lw = lds_w;
-    if (wave < 2)
-      asm volatile(FISR_FS_BEGIN(keep, lds) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
-                   FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_END(keep)
-                   : [keep] "=&s"(keep), [s] "+s"(sw) : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff) : "memory", "scc");
-    else
-      asm volatile(FISR_FS_BEGIN(keep, lds) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
-                   FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_END(keep)
-                   : [keep] "=&s"(keep), [s] "+s"(sw) : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff) : "memory", "scc");
-  };
-  // (two phases) the fp8 groups of chunk kc
-  auto copy_x = [&](int kc, const Item& it) { copy_half((unsigned)(((size_t)kc * nblocks + it.nblk) * FS_W_BYTES) + (unsigned)FS_WM_BYTES); };
   // chunk kc of item `it` -> LDS (KEEP_GEOM: hoff_item describes `it`)
   auto copy_chunk = [&](int kc, const Item& it) {
     const int nb = it.nb, nblk = it.nblk;
@@ -244,20 +224,16 @@ __global__ __launch_bounds__(256, PH == 2 ? 3 : 2) void conv3x3_dma_fs_kernel(co
     }
 #undef FISR_FS_H1
 #undef FISR_FS_HN
-    // weight slab: 36 linear copies of 1 KB, wave w takes copies w, w + 4, ... (nine each); two phases: the first 18 (w_h)
-    if constexpr (PH == 1) {
-      unsigned sw = (unsigned)(((size_t)kc * nblocks + nblk) * FS_W_BYTES) + (unsigned)wave * 1024u;
-      const unsigned lw = lds_w;
-      asm volatile(FISR_FS_BEGIN(keep, lds) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
-                   FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
-                   FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
-                   FISR_FS_COPY(o, rs, s) FISR_FS_END(keep)
-                   : [keep] "=&s"(keep), [s] "+s"(sw)
-                   : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff)
-                   : "memory", "scc");
-    } else {
-      copy_half((unsigned)(((size_t)kc * nblocks + nblk) * FS_W_BYTES));
-    }
+    // weight slab: 36 linear copies of 1 KB, wave w takes copies w, w + 4, ... (nine each)
+    unsigned sw = (unsigned)(((size_t)kc * nblocks + nblk) * FS_W_BYTES) + (unsigned)wave * 1024u;
+    const unsigned lw = lds_w;
+    asm volatile(FISR_FS_BEGIN(keep, lds) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
+                 FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
+                 FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s) FISR_FS_COPY(o, rs, s) FISR_FS_NEXTW(s)
+                 FISR_FS_COPY(o, rs, s) FISR_FS_END(keep)
+                 : [keep] "=&s"(keep), [s] "+s"(sw)
+                 : [rs] "s"(rsw), [lds] "s"(lw), [o] "v"(woff)
+                 : "memory", "scc");
   };
   auto copies_landed_barrier = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -278,9 +254,8 @@ __global__ __launch_bounds__(256, PH == 2 ? 3 : 2) void conv3x3_dma_fs_kernel(co
     a_x[dx] = rec + (((2 + kh) ^ rot) * 16);
   }
   const char* const b_main = sW + (32 * j0 + li) * 32 + ((kh ^ ((li >> 3) & 1)) * 16);
-  constexpr int WX0 = PH == 2 ? 0 : FS_WM_BYTES;       // where the fp8 groups live in the weight buffer
-  const char* const b_x = sW + WX0 + kh * 2048 + (32 * j0 + li) * 16;        // pair q: + 4096 q, tap t of the pair: + 1024 t, j: + 512 j
-  const char* const b_x8 = sW + WX0 + 4 * 4096 + kh * 1024 + (32 * j0 + li) * 16;
+  const char* const b_x = sW + FS_WM_BYTES + kh * 2048 + (32 * j0 + li) * 16;        // pair q: + 4096 q, tap t of the pair: + 1024 t, j: + 512 j
+  const char* const b_x8 = sW + FS_WM_BYTES + 4 * 4096 + kh * 1024 + (32 * j0 + li) * 16;
   const int sa = 127 - FS_LSHIFT, sb = 127 - p.wexp;
 
   typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
@@ -439,123 +414,6 @@ __global__ __launch_bounds__(256, PH == 2 ? 3 : 2) void conv3x3_dma_fs_kernel(co
 #undef FISR_FS_SCHED
   };
 
-  // ---- the two-phase form (PH == 2): phase A = the 36 fp16 MFMAs of a wave (h rows double-buffered: the next column's are read
-  //      under this column's first block), phase B = its 20 block-scaled ones (fp8 rows of two columns live at once, so the
-  //      (dy 2: dx 0 | dx 1) group needs no copy)
-  auto compute_a = [&]() {
-    auto ld_h = [&](uint4 (&H)[6], int dx) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) H[r] = *reinterpret_cast<const uint4*>(a_main[dx] + r * (FS_HW * FS_REC));
-    };
-    auto ld_bm = [&](uint4 (&B)[NJ], int tap) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) B[j] = *reinterpret_cast<const uint4*>(b_main + (tap * FS_BN + 32 * j) * 32);
-    };
-    auto relu_h = [&](uint4 (&H)[6]) {
-      if constexpr (RELU_IN) {
-        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 6; ++r) H[r] = __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(f16x8, H[r]), z));
-      }
-    };
-    uint4 H[2][6], Bm[2][NJ];
-    ld_h(H[0], 0);
-    ld_bm(Bm[0], 0);
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int cu = dx & 1;
-      relu_h(H[cu]);
-      __builtin_amdgcn_sched_barrier(0);
-      ld_bm(Bm[1], 3 + dx);
-      if (dx < 2) ld_h(H[cu ^ 1], dx + 1);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(Bm[0][j]), as_h(H[cu][m]), acc[m][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ld_bm(Bm[0], 6 + dx);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(Bm[1][j]), as_h(H[cu][m + 1]), acc[m][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (dx < 2) ld_bm(Bm[1], dx + 1);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h(Bm[0][j]), as_h(H[cu][m + 2]), acc[m][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (dx < 2) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) Bm[0][j] = Bm[1][j];
-      }
-    }
-  };
-  auto compute_b = [&]() {
-    auto ld_x = [&](uint4 (&X)[6], int dx) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) X[r] = *reinterpret_cast<const uint4*>(a_x[dx] + r * (FS_HW * FS_REC));
-    };
-    auto ld_wx = [&](i32x8 (&Wp)[NJ], int q) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        Wp[j] = cat(*reinterpret_cast<const uint4*>(b_x + q * 4096 + j * 512), *reinterpret_cast<const uint4*>(b_x + q * 4096 + 1024 + j * 512));
-    };
-    auto relu_x = [&](uint4 (&X)[6]) {
-      if constexpr (RELU_IN) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) fsplit_relu_x(X[r]);
-      }
-    };
-    uint4 X0[6], X1[6];
-    i32x8 Wa[NJ], Wb[NJ];
-    ld_x(X0, 0);
-    ld_wx(Wa, 0);
-    relu_x(X0);
-    __builtin_amdgcn_sched_barrier(0);
-    // column 0: (dy 0, dy 1); reads column 1's rows and weights
-    ld_x(X1, 1);
-    ld_wx(Wb, 1);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wa[j], cat(X0[m], X0[m + 1]), acc[m][j], 0, 0, 0, sb, 0, sa);
-    __builtin_amdgcn_sched_barrier(0);
-    relu_x(X1);
-    // column 1: (dy 0, dy 1); reads the (dy 2: dx 0 | dx 1) group
-    ld_wx(Wa, 3);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wb[j], cat(X1[m], X1[m + 1]), acc[m][j], 0, 0, 0, sb, 0, sa);
-    __builtin_amdgcn_sched_barrier(0);
-    // (dy 2: dx 0 | dx 1); reads column 2's weights
-    ld_wx(Wb, 2);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wa[j], cat(X0[m + 2], X1[m + 2]), acc[m][j], 0, 0, 0, sb, 0, sa);
-    __builtin_amdgcn_sched_barrier(0);
-    // column 2
-    ld_x(X0, 2);
-    {
-      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) Wa[j] = cat(z, *reinterpret_cast<const uint4*>(b_x8 + j * 512));
-    }
-    relu_x(X0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wb[j], cat(X0[m], X0[m + 1]), acc[m][j], 0, 0, 0, sb, 0, sa);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[m][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Wa[j], cat(X0[m + 1], X0[m + 2]), acc[m][j], 0, 0, 0, sb, 0, sa);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
   // ---- epilogue of one item: (+ residual) -> relu -> f16f8 records -> quad-transposed 64-byte stores (conv3x3.h's record store)
   const float relu_floor = p.relu_out ? 0.f : -__builtin_huge_valf();
   const unsigned img_out = (unsigned)((size_t)p.H * p.W * p.Cout * 4);          // bytes of one output image (plain and d2s layout alike)
@@ -673,17 +531,7 @@ __global__ __launch_bounds__(256, PH == 2 ? 3 : 2) void conv3x3_dma_fs_kernel(co
       if (p.trace) t1 = __builtin_readcyclecounter();
       copies_landed_barrier();            // this chunk has landed
       if (p.trace) { t2 = __builtin_readcyclecounter(); c_wait += t2 - t1; }
-      if constexpr (PH == 1) {
-        compute();
-      } else {
-        compute_a();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();     // everybody is done with the w_h image
-        asm volatile("" ::: "memory");
-        copy_x(kc, cur);
-        copies_landed_barrier();          // the fp8 groups have landed (the other workgroups of the CU multiply meanwhile)
-        compute_b();
-      }
+      compute();
       if (p.trace) { t3 = __builtin_readcyclecounter(); c_comp += t3 - t2; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();       // everybody is done reading it

@@ -658,43 +658,31 @@ inline int dmafs_tile_w(const ConvArgs& a) {
 #endif
   return a.Cout / FS_BN == 1 ? 32 : 64;
 }
-// Weight phases of the narrow tile (conv3x3_dma_fs.h, PH): 1 unless a build says otherwise (FISR_DIAG builds: FISR_FS_PH=1|2 for A/B runs)
-#ifndef FISR_FS_PH_DEFAULT
-#define FISR_FS_PH_DEFAULT 1
-#endif
-inline int dmafs_phases(int tw) {
-  if (tw != 32) return 1;
-#ifdef FISR_DIAG
-  static const int forced = [] { const char* e = getenv("FISR_FS_PH"); return e ? atoi(e) : 0; }();
-  if (forced == 1 || forced == 2) return forced;
-#endif
-  return FISR_FS_PH_DEFAULT;
-}
-template <int TW, int PH>
+template <int TW>
 hipError_t launch_conv_dmafs_tw(const ConvArgs& a, hipStream_t st, int n_cu, bool set_attr) {
-  constexpr size_t lds = dmafs_lds_bytes(TW, PH);
+  constexpr size_t lds = dmafs_lds_bytes(TW);
   if (set_attr) {
-    for (const void* k : {reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, false, false, PH>), reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, true, false, false, PH>),
-                          reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, true, false, PH>), reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, true, true, false, PH>),
-                          reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, true, true, PH>)}) {
+    for (const void* k : {reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, false, false>), reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, true, false, false>),
+                          reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, true, false>), reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, true, true, false>),
+                          reinterpret_cast<const void*>(conv3x3_dma_fs_kernel<TW, false, true, true>)}) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
   }
   const int tiles = ((a.W + TW - 1) / TW) * ((a.H + FS_TH - 1) / FS_TH) * a.N;
   const int items = tiles * (a.Cout / FS_BN);
-  // two (three) workgroups per CU (each takes a half (a quarter) of a CU's LDS at most), a multiple of 8 so that the items of a workgroup stay on one XCD
-  const int grid = std::min(items, std::max(8, ((PH == 2 ? 3 : 2) * n_cu) & ~7));
+  // two workgroups per CU (each takes half of a CU's LDS at most), a multiple of 8 so that the items of a workgroup stay on one XCD
+  const int grid = std::min(items, std::max(8, (2 * n_cu) & ~7));
   const bool res = a.res != nullptr;
-  if (a.pool_out) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, true, true, PH>), dim3(grid), dim3(256), lds, st, a, items);
-  else if (a.relu_in && res) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, true, true, false, PH>), dim3(grid), dim3(256), lds, st, a, items);
-  else if (a.relu_in) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, true, false, false, PH>), dim3(grid), dim3(256), lds, st, a, items);
-  else if (res) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, true, false, PH>), dim3(grid), dim3(256), lds, st, a, items);
-  else hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, false, false, PH>), dim3(grid), dim3(256), lds, st, a, items);
+  if (a.pool_out) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, true, true>), dim3(grid), dim3(256), lds, st, a, items);
+  else if (a.relu_in && res) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, true, true, false>), dim3(grid), dim3(256), lds, st, a, items);
+  else if (a.relu_in) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, true, false, false>), dim3(grid), dim3(256), lds, st, a, items);
+  else if (res) hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, true, false>), dim3(grid), dim3(256), lds, st, a, items);
+  else hipLaunchKernelGGL((conv3x3_dma_fs_kernel<TW, false, false, false>), dim3(grid), dim3(256), lds, st, a, items);
   return hipGetLastError();
 }
 hipError_t launch_conv_dmafs(const ConvArgs& a, hipStream_t st) {
-  static bool attr_done[64][3] = {};
+  static bool attr_done[64][2] = {};
   static int n_cu[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -705,10 +693,9 @@ hipError_t launch_conv_dmafs(const ConvArgs& a, hipStream_t st) {
     n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   if (!dmafs_fits(a.H, a.W, a.C0, a.C1, a.Cout) || a.CoutPad != a.Cout || !dmafs_takes(a) || (a.pool_out && ((a.H | a.W) & 1))) return hipErrorInvalidValue;
-  const int tw = dmafs_tile_w(a), ph = dmafs_phases(tw);
-  bool& done = attr_done[dev][tw == 64 ? 0 : ph];
-  const hipError_t e = tw == 64 ? launch_conv_dmafs_tw<64, 1>(a, st, n_cu[dev], !done)
-                       : ph == 2 ? launch_conv_dmafs_tw<32, 2>(a, st, n_cu[dev], !done) : launch_conv_dmafs_tw<32, 1>(a, st, n_cu[dev], !done);
+  const int tw = dmafs_tile_w(a);
+  bool& done = attr_done[dev][tw == 64];
+  const hipError_t e = tw == 64 ? launch_conv_dmafs_tw<64>(a, st, n_cu[dev], !done) : launch_conv_dmafs_tw<32>(a, st, n_cu[dev], !done);
   if (e == hipSuccess) done = true;
   return e;
 }
