@@ -51,7 +51,7 @@ import numpy as np
 
 from bench_report import (DTYPE, FLOP_PER_LR_PX, HBM_PEAK_GBPS, PEAK, UNIQUE_PER_STACK, cfg5_pipeline, cpu_baselines,
                           executed_per_algorithmic, expected_step_ms, memory_plan, oracle_tile_check, roofline_pass, time_training_step, time_warp,
-                          _pmc_key, _pmc_passes, _pmc_same_population)      # noqa: F401 -- (the last three: tests/test_host.py reaches them through this module)
+                          _pmc_file, _pmc_key, _pmc_passes, _pmc_same_population)      # noqa: F401 -- (the last four: tests/test_host.py reaches them through this module)
 
 
 def synthetic_stack(seed, H=1080, W=1920):

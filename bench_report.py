@@ -177,15 +177,16 @@ def _pmc_key(name):
         f = name.split("<")[1].rstrip(">").split(",")
         return "conv3x3_dma_fs_kernel<%s, %s, %s, %s>" % (f[1][2:], "true" if f[2] == "relu_in" else "false",
                                                          "false" if f[3] == "nores" else "true", "true" if f[3] == "res+pool" else "false")
+    # (keys are PREFIXES of the demangled names: no closing '>' -- the kernels grew template parameters behind these, r05: SHARE, NT)
     if name.startswith("conv3x3_dma"):
-        return "conv3x3_dma_f16_kernel<false>"
+        return "conv3x3_dma_f16_kernel<false,"
     if name.startswith("conv3x3_wf4"):
         if "res+pool" in name:
-            return "conv3x3_wf4_kernel<false, true, true, false, false>"
+            return "conv3x3_wf4_kernel<false, true, true, false, false"
         if "up2" in name:
-            return "conv3x3_wf4_kernel<false, false, false, true, false>"
+            return "conv3x3_wf4_kernel<false, false, false, true, false"
         # (5th parameter: the GENERAL instantiation of the flow network)
-        return "conv3x3_wf4_kernel<%s, %s, false, false, false>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
+        return "conv3x3_wf4_kernel<%s, %s, false, false, false" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
     tname = {"f32": "float", "f32w": "float", "f16": "_Float16", "bf16x3": "bsplit", "f16f8": "fsplit"}[name.split("<")[1].split(",")[0]]
     if name.startswith("conv3x3_wino"):
         return "conv3x3_wino8p_kernel<%s, false, %s>" % ("true" if "relu_in" in name else "false", "false" if "nores" in name else "true")
@@ -258,6 +259,18 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
         e = pmc_raw(key)
         if e is None:
             return None
+        hits = [v for k, v in pmc.items() if k.startswith(key)]
+        if len(hits) > 1 and not _pmc_same_population(e, pmc_passes, lps.get(name, 0)):
+            # one profile class, several instantiations (the fp32 heads: head_conv_f32_kernel<2> and <3>): the class's population is
+            # their sum, its per-launch figures their dispatch-weighted means
+            tot = sum(v.get("dispatches", 0) for v in hits)
+            if tot:
+                m = {"dispatches": tot}
+                for f in set().union(*[set(v) for v in hits]) - {"dispatches"}:
+                    vals = [(v[f], v.get("dispatches", 0)) for v in hits if isinstance(v.get(f), (int, float))]
+                    if len(vals) == len(hits):
+                        m[f] = sum(a * b for a, b in vals) / tot
+                e = m
         if not _pmc_same_population(e, pmc_passes, lps.get(name, 0)):
             dropped.append("%s: %s dispatches in the PMC run, %.1f launches per step here, %s passes of this engine" % (name, e.get("dispatches", 0), lps.get(name, 0), pmc_passes or "no whole number of"))
             return None

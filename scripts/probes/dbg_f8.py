@@ -12,8 +12,8 @@ b=rng.standard_normal(cout).astype(np.float32)
 got=T.hip_conv(x,wt,b,prec="f16f8",out_f32=True).astype(np.float64)
 xh=x.astype(np.float16).astype(np.float64); xl=fp8_e4m3_decode(fp8_e4m3_encode(np.clip((x-xh.astype(np.float32))*2**14,-448,448))).astype(np.float64)*2.0**-14
 xh8=fp8_e4m3_decode(fp8_e4m3_encode(np.clip(xh,-448,448))).astype(np.float64)
-mx=np.abs(wt).max(); wexp=7-int(np.floor(np.log2(mx)))
-wh=wt.astype(np.float16).astype(np.float64); wl=fp8_e4m3_decode(fp8_e4m3_encode((wt-wh.astype(np.float32)).astype(np.float64)*2.0**(wexp+11))).astype(np.float64)*2.0**-(wexp+11)
+mx=np.abs(wt).max(); wexp=4-int(np.floor(np.log2(mx)))     # r05: wh8 = fp8(w_h 2^wexp), wl8 = fp8(w_l 2^(wexp+14)) (conv3x3.h)
+wh=wt.astype(np.float16).astype(np.float64); wl=fp8_e4m3_decode(fp8_e4m3_encode((wt-wh.astype(np.float32)).astype(np.float64)*2.0**(wexp+14))).astype(np.float64)*2.0**-(wexp+14)
 wh8=fp8_e4m3_decode(fp8_e4m3_encode(wh*2.0**wexp)).astype(np.float64)*2.0**-wexp
 z=np.zeros(cout)
 main=O.conv2d(xh,wh,b); c1_=O.conv2d(xl,wh8,z); c2_=O.conv2d(xh8,wl,z)

@@ -334,5 +334,12 @@ def test_bench_counter_fields_need_the_same_launch_population():
     assert b._pmc_same_population({"dispatches": 132}, 4, 33.0)               # residual instantiation: 33 per step x 4
     assert not b._pmc_same_population({"dispatches": 58}, 4, 1.0)             # maxpool2 of all engines against the one launch left here
     assert not b._pmc_same_population({"dispatches": 132}, 0, 33.0)
-    assert b._pmc_key("conv3x3_wf4<f32w4,relu_in,nores>") == "conv3x3_wf4_kernel<true, false, false, false, false>"
-    assert b._pmc_key("conv3x3_wf4<f32w4,plain,res+pool>") == "conv3x3_wf4_kernel<false, true, true, false, false>"
+    # (keys are prefixes of the demangled names, without the closing bracket: r05's SHARE parameter sits behind these)
+    assert b._pmc_key("conv3x3_wf4<f32w4,relu_in,nores>") == "conv3x3_wf4_kernel<true, false, false, false, false"
+    assert b._pmc_key("conv3x3_wf4<f32w4,plain,res+pool>") == "conv3x3_wf4_kernel<false, true, true, false, false"
+    assert "conv3x3_wf4_kernel<true, false, false, false, false, false>".startswith(b._pmc_key("conv3x3_wf4<f32w4,relu_in,nores>"))
+    assert b._pmc_key("conv3x3_dma_fs<f16f8,tw32,relu_in,nores>") == "conv3x3_dma_fs_kernel<32, true, false, false>"
+    assert b._pmc_key("conv3x3_dma_fs<f16f8,tw64,plain,res+pool>") == "conv3x3_dma_fs_kernel<64, false, true, true>"
+    assert "conv3x3_dma_f16_kernel<false, 2>".startswith(b._pmc_key("conv3x3_dma<f16>"))
+    # an engine profiled alone has its own table (r05: `mixed` shares its kernel names with f16f8 / fp16)
+    assert b._pmc_file("no_such_engine").endswith(os.path.join("profiles", "pmc_traffic.json"))
