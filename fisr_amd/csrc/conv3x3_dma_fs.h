@@ -531,7 +531,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
       if (p.trace) t1 = __builtin_readcyclecounter();
       copies_landed_barrier();            // this chunk has landed
       if (p.trace) { t2 = __builtin_readcyclecounter(); c_wait += t2 - t1; }
+      // the wave that multiplies goes first on its SIMD: its partner (the CU's other workgroup) is then in its epilogue or its copy
+      // phase -- vector and memory instructions that wait anyway.  `mixed` 111.2 -> 113.3 frames/s (two alternating rounds on one
+      // box, priority 1 / 2 / 3 alike; the same on the fp16 kernel's K loop: nothing)
+#ifndef FISR_FS_PRIO
+#define FISR_FS_PRIO 1
+#endif
+      __builtin_amdgcn_s_setprio(FISR_FS_PRIO);
       compute();
+      __builtin_amdgcn_s_setprio(0);
       if (p.trace) { t3 = __builtin_readcyclecounter(); c_comp += t3 - t2; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();       // everybody is done reading it
