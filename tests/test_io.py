@@ -223,6 +223,31 @@ def test_split_format_roundtrip():
     assert np.array_equal(splitfmt.to_split(np.zeros((1, 16), np.float32)), np.zeros((1, 1, 2, 16), np.uint16))
 
 
+def test_f16f8_record_layout_and_roundtrip():
+    """The f16f8 record as the kernels read it (conv3x3.h, r05): per 16 channels 32 B of fp16 h, then per 8 channels {8 x l8 | 8 x h8} --
+    both fp8 parts of a channel in one 16-byte unit; x ~ h + l8 * 2^-14 (>= 14 significant bits), h8 = fp8(h) keeps h's sign."""
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal((3, 5, 32)) * np.array([1e-3, 1.0, 30.0])[:, None, None]).astype(np.float32)
+    s = splitfmt.to_fsplit(x)
+    assert s.shape == (3, 5, 2, 64) and s.dtype == np.uint8
+    r = splitfmt.from_fsplit(s)
+    assert np.abs(r - x).max() <= np.abs(x).max() * 2.0 ** -14
+    assert np.array_equal(splitfmt.from_fsplit(splitfmt.to_fsplit(r)), r)                      # idempotent
+    h = s[..., :32].copy().view(np.float16).astype(np.float32)                                # [3, 5, 2, 16]
+    g = x.reshape(3, 5, 2, 16)
+    assert np.array_equal(h, g.astype(np.float16).astype(np.float32))
+    for half in range(2):                                                                      # channels 8 half .. 8 half + 7
+        l8 = splitfmt.fp8_e4m3_decode(s[..., 32 + 16 * half:40 + 16 * half])
+        h8 = splitfmt.fp8_e4m3_decode(s[..., 40 + 16 * half:48 + 16 * half])
+        hh = h[..., 8 * half:8 * half + 8]
+        assert np.array_equal(h8, splitfmt.fp8_e4m3_decode(splitfmt.fp8_e4m3_encode(np.clip(hh, -448, 448))))
+        assert np.array_equal(np.signbit(h8), np.signbit(hh))                                  # relu-on-load masks l8 / h8 by h8's sign
+        assert np.abs(hh + l8 * 2.0 ** -14 - g[..., 8 * half:8 * half + 8]).max() <= np.abs(g).max() * 2.0 ** -14
+    assert not splitfmt.to_fsplit(np.zeros((1, 16), np.float32)).any()
+    big = splitfmt.from_fsplit(splitfmt.to_fsplit(np.full((1, 16), 1e6, np.float32)))         # saturates instead of overflowing
+    assert np.isfinite(big).all() and big.max() <= 65504 + 448 * 2.0 ** -14
+
+
 def test_snappy_decompressor_vs_real_snappy(gold_dir):
     """tests/golden/snappy_blocks.npz was compressed by libsnappy 1.1.8 (oracle/make_golden_snappy.py)."""
     g = np.load(os.path.join(gold_dir, "snappy_blocks.npz"))
