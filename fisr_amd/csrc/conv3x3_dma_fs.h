@@ -434,7 +434,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
       for (int k = 0; k < 4; ++k) {
         const unsigned eo = (((unsigned)(y * p.W) + (unsigned)(xq + k)) * (unsigned)p.Cout + c0) * 4u + 16u * (unsigned)(li & 3);
         const unsigned off = (y < p.H && xq + k < p.W) ? eo : img_out;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
+#ifndef FISR_FS_RES_AUX
+#define FISR_FS_RES_AUX 2        // the residual is read once: a non-temporal load keeps it from ageing the halo lines out of L2 (r05: FETCH_SIZE
+#endif                           // of 64 -> 64 + residual at 12 x 544 x 992 4.69 -> 4.26 GB, mixed step 62.49 -> 62.11 ms; A/B hook: 0)
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, FISR_FS_RES_AUX);
         q[k] = make_uint4(v.x, v.y, v.z, v.w);
       }
     };
