@@ -53,6 +53,7 @@ struct PwcConv {                 // one packed convolution
   char* d_wu = nullptr;          // fp32 engine: Winograd slabs for conv3x3_wino8p_kernel (stride 1, Cout >= 32)
   char* d_wu4 = nullptr;         // fp32 engine with F(4x4) (FISR_PREC_F32W4): slabs for conv3x3_wf4_kernel<GENERAL> beside them
   void* d_wd = nullptr;          // fp16 engine: weight slabs of the LDS-DMA kernel conv3x3_dma.h (stride 1, Cout >= 16)
+  void* d_wg16 = nullptr;        // fp16 engine: fp16 weights of pwc_convg_f16_kernel (the stride-2 pyramid convolutions, level 6's 196-channel layers)
   int cout_pad_d = 0, nt_d = 2;  // ... its Cout padding and N block (32 * nt_d channels: 32 when Cout % 64 == 32)
   ConvW dw;                      // FISRnet's direct kernel in the engine's arithmetic (stride 1, dilation 1: the 2-channel flow heads; fp32: also level 1)
   bool have_dw = false;
@@ -142,6 +143,24 @@ int pwc_pack_conv(fisr_pwc* ctx, const std::string& name, const std::vector<int>
       for (int j = 0; j < 3; ++j)
         for (int n = 0; n < 16; ++n) pc.w1a->w[(size_t)tap * 64 + chmap[j] * 16 + n] = kw.v[((size_t)tap * 3 + j) * 16 + n];
     for (int n = 0; n < 16; ++n) pc.w1a->bias[n] = kb.v[n];
+  }
+  if (ctx->precision == FISR_PREC_F16 && cin_buf % 4 == 0 && cin_buf >= 16 && co >= 16 && (!wino || co % 16 != 0 || cin_buf % D_CH != 0)) {
+    // (the layers of the fp16 engine that get no LDS-DMA slabs below: the stride-2 pyramid convolutions and level 6's 196-channel maps)
+    // fp16 engine, generic kernel in fp16 arithmetic: [cin_buf/16][CoutPad/64][9][64 rows][16 halves], pwc_convg_f16_kernel's LDS image
+    const int nch16 = (cin_buf + 15) / 16;
+    std::vector<_Float16> w16((size_t)nch16 * nb * 9 * G_BN * 16, (_Float16)0.f);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int j = 0; j < ci; ++j) {
+        const int c = chmap[j], kc = c / 16, cc = c % 16, h = cc >> 3, e = cc & 7;
+        for (int n = 0; n < co; ++n) {
+          const int blk = n / G_BN, nl = n % G_BN, wi = nl & 31, wk = wi >> 4, wr = wi & 15;
+          const int row = (nl & 32) + (wr & 3) + 8 * (wr >> 2) + 4 * wk;
+          w16[((((size_t)kc * nb + blk) * 9 + tap) * G_BN + row) * 16 + ((h ^ ((row >> 3) & 1)) * 8) + e] =
+              (_Float16)kw.v[((size_t)tap * ci + j) * co + n];
+        }
+      }
+    HIP_OK(nullptr, hipMalloc(&pc.d_wg16, w16.size() * 2));
+    HIP_OK(nullptr, hipMemcpy(pc.d_wg16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
   }
   if (!wino) return 0;
   // the same kernel scattered to the buffer channels it reads, for FISRnet's fast kernels
@@ -250,7 +269,8 @@ inline PwcItems swapped(const PwcItems& x) { PwcItems it = x; for (int i = 0; i 
 
 template <typename TE>
 hipError_t launch_costvol(const TE* c1, int c1_cs, int c1_co, const PwcItems& c1_img, const TE* c2, const PwcItems& c2_img, int C, TE* out,
-                          int out_cs, int out_co, int n, int h, int w, hipStream_t st) {
+                          int out_cs, int out_co, int n, int h, int w, hipStream_t st, int zero_pad = 0) {
+  if (zero_pad && (zero_pad + 1) % 4) return hipErrorInvalidValue;        // 81 + zero_pad channels in 4-channel stores
   static bool cv_attr[64] = {};
   int dev = 0; (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !cv_attr[dev]) {
@@ -261,7 +281,7 @@ hipError_t launch_costvol(const TE* c1, int c1_cs, int c1_co, const PwcItems& c1
   }
   const int cv_tiles = ((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n;
   hipLaunchKernelGGL(pwc_costvol_kernel<TE>, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, c1_cs, c1_co, c1_img, c2, c2_img, C, out,
-                     out_cs, out_co, n, h, w);
+                     out_cs, out_co, n, h, w, zero_pad);
   return hipGetLastError();
 }
 
@@ -337,7 +357,10 @@ struct PwcRunner {
     if (ar.dry) return;
     if (route == 7) {
       if (in_co || out_co) { rc = pfail(ctx, FISR_EINVAL, name + ": conv1a reads and writes whole buffers"); return; }
-      hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * 4)), dim3(256), 0, st, in, *pc.w1a, (TE*)out, n, h, w, slope);
+      if constexpr (HALF)
+        hipLaunchKernelGGL(pwc_conv1a_f16_kernel, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * 4)), dim3(256), 0, st, in, *pc.w1a, (TE*)out, n, h, w, slope);
+      else
+        hipLaunchKernelGGL(pwc_conv1a_kernel<TE>, dim3(grid_for((size_t)n * (h / 2) * (w / 2) * 4)), dim3(256), 0, st, in, *pc.w1a, (TE*)out, n, h, w, slope);
       check(name.c_str());
       return;
     }
@@ -402,12 +425,31 @@ struct PwcRunner {
     const int tot_h = std::max((g.OH - 1) * stride + 2 * dil + 1 - h, 0), tot_w = std::max((g.OW - 1) * stride + 2 * dil + 1 - w, 0);
     g.pad_t = tot_h / 2; g.pad_l = tot_w / 2;                      // TF 'SAME': the smaller half goes first
     const int tiles = ((g.OW + TILE_W - 1) / TILE_W) * ((g.OH + TILE_H - 1) / TILE_H) * n;
+    if (HALF && pc.d_wg16 && !out_f32 && !add && in_cs % 4 == 0 && in_co % 4 == 0) {
+      // fp16 engine: the generic kernel on the fp16 matrix pipe (the stride-2 pyramid convolutions)
+      static bool attr16_done[64] = {};
+      if (dev < 0 || dev >= 64 || !attr16_done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_convg_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)convg16_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwc_convg_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)convg16_lds_bytes());
+        if (dev >= 0 && dev < 64) attr16_done[dev] = true;
+      }
+      g.w = (const float*)pc.d_wg16;
+      const int tiles16 = ((g.OW + 31) / 32) * ((g.OH + G16_TH - 1) / G16_TH) * n;
+      if (pc.cin_buf % 16 == 0 && in_cs % 8 == 0 && in_co % 8 == 0)
+        hipLaunchKernelGGL(pwc_convg_f16_kernel<true>, dim3(tiles16 * (pc.cout_pad / G_BN)), dim3(256), convg16_lds_bytes(), st, g);
+      else
+        hipLaunchKernelGGL(pwc_convg_f16_kernel<false>, dim3(tiles16 * (pc.cout_pad / G_BN)), dim3(256), convg16_lds_bytes(), st, g);
+      check(name.c_str());
+      return;
+    }
     if (out_f32) hipLaunchKernelGGL((pwc_convg_kernel<TE, float>), dim3(tiles * (pc.cout_pad / G_BN)), dim3(256), convg_lds_bytes(), st, g);
     else hipLaunchKernelGGL((pwc_convg_kernel<TE, TE>), dim3(tiles * (pc.cout_pad / G_BN)), dim3(256), convg_lds_bytes(), st, g);
     check(name.c_str());
   }
   template <typename TI>
-  void deconv(const std::string& name, const TI* in, int in_cs, int in_co, TE* out, int out_cs, int out_co, int n, int h, int w) {
+  void deconv(const std::string& name, const TI* in, int in_cs, int in_co, TE* out, int out_cs, int out_co, int n, int h, int w, bool pad4 = false) {
+    const int p4 = pad4 && out_cs % 4 == 0 && out_co % 4 == 0 ? 1 : 0;     // (pad4: the decoder's call -- channels out_co + 2, + 3 are padding, written as zeros)
+    if (pad4 && !p4) { if (rc == 0) rc = pfail(ctx, FISR_EINVAL, name + ": padded pair needs a 4-channel aligned slot"); return; }
     const PwcDeconv& pd = ctx->deconvs[name];
     if (HALF && std::is_same<TI, TE>::value && pd.d_wd && dma_fits(h, w, pd.cin4, 0, in_cs, 0)) {
       // wide input: taps x outputs as 32 channels of a centre-tap convolution on the matrix pipe, then the 2x2 gather
@@ -421,7 +463,7 @@ struct PwcRunner {
       a.in0_cs = in_cs; a.in1_cs = 0; a.rec_cs = 32; a.rec_co = 0; a.slope = 0.f; a.dil = 1; a.trace = nullptr;
       hipError_t e = launch_conv_dma(a, st, 1);
       if (e != hipSuccess && rc == 0) { rc = pfail(ctx, FISR_EHIP, name + " (lds-dma): " + hipGetErrorString(e)); return; }
-      hipLaunchKernelGGL(pwc_deconv_combine_kernel<TE>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, out, out_cs, out_co, n, h, w);
+      hipLaunchKernelGGL(pwc_deconv_combine_kernel<TE>, dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, out, out_cs, out_co, n, h, w, p4);
       check(name.c_str());
       return;
     }
@@ -435,13 +477,13 @@ struct PwcRunner {
       pa.in = (const float*)in; pa.in_cs = in_cs; pa.in_co = in_co; pa.Cin = pd.cin4; pa.w = pd.d_wp; pa.out = P; pa.npix = (size_t)n * h * w;
       hipLaunchKernelGGL(pwc_pointwise_f32_kernel<32>, dim3((unsigned)((pa.npix + PW_PX - 1) / PW_PX)), dim3(256), 0, st, pa);
       hipLaunchKernelGGL((pwc_deconv_combine_kernel<float, true>), dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, P, pd.d_b, (float*)out, out_cs,
-                         out_co, n, h, w);
+                         out_co, n, h, w, p4);
       check(name.c_str());
       return;
     }
     if (rc || ar.dry) return;
     hipLaunchKernelGGL((pwc_deconv_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w * 8)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
-                       pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w);
+                       pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w, p4);
     check(name.c_str());
   }
 
@@ -482,18 +524,14 @@ struct PwcRunner {
       const int h = hh[l], w = ww[l];
       const size_t px = (size_t)h * w, npx = px * N;
       TE* D = ealloc(npx * L.total);
-      // channel padding must read as finite zeros (its weights are zero); every other channel is written before it is read
-      auto zero_ch = [&](int c0, int nc) {
-        if (nc > 0 && !rc && !ar.dry)
-          hipLaunchKernelGGL(pwc_zero_channels_kernel<TE>, dim3(grid_for(npx * nc)), dim3(256), 0, st, D, L.total, c0, nc, npx);
-      };
-      zero_ch(L.off_corr + 81, L.off_c1 - (L.off_corr + 81));
-      if (L.c1) { zero_ch(L.off_upflow + 2, 2); zero_ch(L.off_upfeat + 2, 2); }
+      // channel padding must read as finite zeros (its weights are zero): written by the kernels that fill the group in front of it
+      const int corr_pad = L.off_c1 - (L.off_corr + 81);          // 7 (15 at the top level): written by the cost volume kernel
+      // (the padding behind up_flow / up_feat is written by their transpose convolutions: deconv(..., pad4))
       const std::string ls = std::to_string(l);
       if (l != PWC_LVLS) {
         // up-sampled flow / features of the level above land directly in this level's buffer (:1577-1578, :1424)
-        deconv<float>("pwcnet/upsample/up_flow" + std::to_string(l + 1), flow_prev, 4, 0, D, L.total, L.off_upflow, N, hh[l + 1], ww[l + 1]);
-        deconv<TE>("pwcnet/upsample/up_feat" + std::to_string(l + 1), Dprev, prev_total, 0, D, L.total, L.off_upfeat, N, hh[l + 1], ww[l + 1]);
+        deconv<float>("pwcnet/upsample/up_flow" + std::to_string(l + 1), flow_prev, 4, 0, D, L.total, L.off_upflow, N, hh[l + 1], ww[l + 1], true);
+        deconv<TE>("pwcnet/upsample/up_feat" + std::to_string(l + 1), Dprev, prev_total, 0, D, L.total, L.off_upfeat, N, hh[l + 1], ww[l + 1], true);
         TE* Wp = ealloc(npx * PWC_CH[l]);
         if (!rc && !ar.dry) {
           hipLaunchKernelGGL(pwc_warp_kernel<TE>, dim3(grid_for(npx * PWC_CH[l] / 4)), dim3(256), 0, st, F[l], items_b, PWC_CH[l], D, L.total,
@@ -502,11 +540,11 @@ struct PwcRunner {
           hipLaunchKernelGGL(pwc_copy_channels_kernel<TE>, dim3(grid_for(npx * PWC_CH[l] / 4)), dim3(256), 0, st, F[l], items, PWC_CH[l], D,
                              L.total, L.off_c1, px, N);
           check("copy c1");
-          hipError_t e = launch_costvol<TE>(D, L.total, L.off_c1, ident, Wp, ident, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st);   // :1277
+          hipError_t e = launch_costvol<TE>(D, L.total, L.off_c1, ident, Wp, ident, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st, corr_pad);   // :1277
           if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string("cost volume: ") + hipGetErrorString(e));
         }
       } else if (!rc && !ar.dry) {
-        hipError_t e = launch_costvol<TE>(F[l], PWC_CH[l], 0, items, F[l], items_b, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st);
+        hipError_t e = launch_costvol<TE>(F[l], PWC_CH[l], 0, items, F[l], items_b, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st, corr_pad);
         if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string("cost volume: ") + hipGetErrorString(e));
       }
       for (int i = 0; i < 5; ++i)                                  // predict_flow :1426-1445 (dense connections)
@@ -617,7 +655,7 @@ int fisr_pwc_create(fisr_pwc** out, int device_id) {
 static void pwc_release_packed(fisr_pwc* c) {
   for (auto& kv : c->convs) {
     PwcConv& pc = kv.second;
-    if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd);
+    if (pc.d_w) (void)hipFree(pc.d_w); if (pc.d_b) (void)hipFree(pc.d_b); if (pc.d_wu) (void)hipFree(pc.d_wu); if (pc.d_wd) (void)hipFree(pc.d_wd); if (pc.d_wg16) (void)hipFree(pc.d_wg16);
     if (pc.d_wu4) (void)hipFree(pc.d_wu4);
     if (pc.d_wp) (void)hipFree(pc.d_wp);
     delete pc.w1a; pc.w1a = nullptr;

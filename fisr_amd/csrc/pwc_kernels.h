@@ -162,6 +162,131 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
   }
 }
 
+// The same implicit GEMM in the fp16 engine's arithmetic (r05): fp16 features and fp16 weights on v_mfma_f32_32x32x16_f16, fp32
+// accumulation.  pwc_convg_kernel<_Float16, _Float16> converted every loaded value to fp32 and multiplied on the fp32 pipe -- 144 MFMAs
+// of 64 cycles per wave and 8-channel chunk, one workgroup per CU, loads and MFMAs one after the other: the stride-2 pyramid
+// convolutions of a 5-frame stack took 2.45 ms for 0.8 GB of traffic.  Here a chunk is 16 channels in the same 32-byte records (9
+// tap-shifted pixel blocks + the weight slab) and costs 18 MFMAs of 32 cycles per wave; a workgroup is 4 x 32 output pixels x 64
+// channels with 54 KB of LDS, so two of them share a CU and one's loads fly under the other's MFMAs.
+// A16: Cin % 16 == 0 and 16-byte aligned pixel records (in_cs % 8 == 0, in_co % 8 == 0) -> one 16-byte load per unit; otherwise
+// (the 196-channel maps of pyramid level 6: in_cs % 4 == 0, in_co % 4 == 0, Cin % 4 == 0) two 8-byte loads, the second of the last chunk guarded.
+// w: [ceil(Cin/16)][CoutPad/64][9][64 rows][16 halves], halves of a record swizzled by row bit 3, zeros behind Cin (pwc_pack_conv).
+constexpr int G16_TH = 4, G16_PX = G16_TH * 32;       // output pixels of a workgroup
+constexpr size_t convg16_lds_bytes() { return (size_t)9 * G16_PX * G_REC + (size_t)9 * G_BN * G_REC; }     // 55296
+template <bool A16>
+__global__ __launch_bounds__(256, 2) void pwc_convg_f16_kernel(const ConvGArgs p) {
+  typedef _Float16 TE;
+  constexpr int CH = 16, NU = 9 * G16_PX * 2 / 256;     // 9 loader units per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sIn = smem;                               // [tap 9][px 128][32 B]
+  char* const sW = smem + 9 * G16_PX * G_REC;           // [tap 9][row 64][32 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  const int pxh = wave & 1, coh = wave >> 1;            // wave = 64 pixels (2 rows) x 32 channels
+
+  const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + G16_TH - 1) / G16_TH;
+  const int nblocks = p.CoutPad / G_BN;
+  int t = blockIdx.x / nblocks;
+  const int nblk = blockIdx.x - t * nblocks;
+  const int tx_ = t % tiles_x; t /= tiles_x;
+  const int ty_ = t % tiles_y;
+  const int nb = t / tiles_y;
+  const int x0 = tx_ * 32, y0 = ty_ * G16_TH;
+  const int nch = (p.Cin + CH - 1) / CH;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // loader: unit u = tid + 256 i, i < 9: half = u & 1, pixel = (u >> 1) & 127, tap = u >> 8 = i.  The source offsets do not depend on
+  // the chunk: computed once (pixel index in the image, or -1 outside it)
+  const int l_half = tid & 1, l_px = tid >> 1;
+  const int f_off = li * G_REC + ((kh ^ ((li >> 3) & 1)) * 16);
+  int src[NU];
+  {
+    const int oy = y0 + (l_px >> 5), ox = x0 + (l_px & 31);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const int iy = oy * p.stride - p.pad_t + (i / 3) * p.dil, ix = ox * p.stride - p.pad_l + (i % 3) * p.dil;
+      src[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (iy * p.W + ix) : -1;
+    }
+  }
+  const TE* const img = (const TE*)p.in + (size_t)nb * p.H * p.W * p.in_cs + p.in_co + 8 * l_half;
+  char* const s_dst = sIn + l_px * G_REC + ((l_half ^ ((l_px >> 3) & 1)) * 16);
+  const bool w5 = tid + 1024 < 9 * G_BN * 2;            // 1152 weight units: four per thread + one for the first 128 threads
+
+  for (int kc = 0; kc < nch; ++kc) {
+    uint4 v[NU], wv[5];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      v[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (src[i] >= 0) {
+        const TE* q = img + (size_t)src[i] * p.in_cs + kc * CH;
+        if constexpr (A16) v[i] = *reinterpret_cast<const uint4*>(q);
+        else {
+          const int c = kc * CH + 8 * l_half;                // first channel of this unit
+          uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+          if (c < p.Cin) lo = *reinterpret_cast<const uint2*>(q);
+          if (c + 4 < p.Cin) hi = *reinterpret_cast<const uint2*>(q + 4);
+          v[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+    }
+    const uint4* g = reinterpret_cast<const uint4*>((const char*)p.w + ((size_t)kc * nblocks + nblk) * (9 * G_BN * G_REC)) + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wv[i] = g[256 * i];
+    wv[4] = w5 ? g[1024] : make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();                                    // the previous chunk's fragments are consumed (the loads above are in flight)
+#pragma unroll
+    for (int i = 0; i < NU; ++i) *reinterpret_cast<uint4*>(s_dst + i * (G16_PX * G_REC)) = v[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sW + (tid + 256 * i) * 16) = wv[i];
+    if (w5) *reinterpret_cast<uint4*>(sW + (tid + 1024) * 16) = wv[4];
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(sW + (tap * G_BN + 32 * coh) * G_REC + f_off);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f16x8 b = *reinterpret_cast<const f16x8*>(sIn + (tap * G16_PX + 32 * (2 * pxh + j)) * G_REC + f_off);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: lane (li, kh) of block j owns pixel (y0 + 2*pxh + j, x0 + li), channels cb + r, r = 0..15
+  const int cb = nblk * G_BN + 32 * coh + 16 * kh;
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bv[r] = p.bias[cb + r];
+  const int ox = x0 + li;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int oy = y0 + 2 * pxh + j;
+    if (oy >= p.OH || ox >= p.OW || cb >= p.Cout) continue;
+    const size_t pix = (size_t)(nb * p.OH + oy) * p.OW + ox;
+    TE* ob = (TE*)p.out + pix * p.out_cs + p.out_co + cb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s_ = acc[j][4 * q + e] + bv[4 * q + e];
+        v4[e] = s_ >= 0.f ? s_ : s_ * p.slope;
+      }
+      if (cb + 4 * q + 3 < p.Cout) {
+        PwcElem<TE>::st4(ob + 4 * q, f32x4{v4[0], v4[1], v4[2], v4[3]});
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + 4 * q + e < p.Cout) ob[4 * q + e] = (TE)v4[e];
+      }
+    }
+  }
+}
+
 // tf.layers.conv2d_transpose(x, 2, 4, 2, 'same'): out[2*i + k - 1] += in[i] * kernel[k]  (two output channels).
 // EIGHT lanes per output pixel, each taking every eighth group of 4 input channels (the eight lanes of a pixel read 32
 // consecutive channels per step: whole 64- / 128-byte pieces of a pixel record instead of one lane striding through a 1.2-KB
@@ -170,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void pwc_convg_kernel(const ConvGArgs p) {
 template <typename TI, typename TO>
 __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_co, int Cin4, const float* __restrict__ w,
                                   const float* __restrict__ bias, TO* __restrict__ out, int out_cs, int out_co,
-                                  int N, int H, int W) {
+                                  int N, int H, int W, int pad4) {
   const int OH = 2 * H, OW = 2 * W;
   const size_t total = (size_t)N * OH * OW;
   const int sub = threadIdx.x & 7;
@@ -205,7 +330,9 @@ __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_c
     for (int m = 1; m < 8; m <<= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); }
     if (live && sub == 0) {
       TO* o = out + i * out_cs + out_co;
-      o[0] = (TO)(a0 + bias[0]); o[1] = (TO)(a1 + bias[1]);
+      // pad4: the two padding channels behind the pair (the decoder buffers' groups are multiples of 4 channels) as part of one store
+      if (pad4) PwcElem<TO>::st4(o, f32x4{a0 + bias[0], a1 + bias[1], 0.f, 0.f});
+      else { o[0] = (TO)(a0 + bias[0]); o[1] = (TO)(a1 + bias[1]); }
     }
   }
 }
@@ -217,7 +344,7 @@ __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_c
 // pixel re-read the 78 KB of weights from L2 for every pixel: 4.1 ms on the 608-channel level-2 buffer of a 5-frame stack.)
 template <typename TE, bool PLANAR = false>      // PLANAR: P [tap][N, H, W][2] (the fp32 pointwise kernel) instead of [N, H, W][32]
 __global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float* __restrict__ bias, TE* __restrict__ out, int out_cs, int out_co,
-                                          int N, int H, int W) {
+                                          int N, int H, int W, int pad4) {
   const int OH = 2 * H, OW = 2 * W;
   const size_t total = (size_t)N * OH * OW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -237,7 +364,8 @@ __global__ void pwc_deconv_combine_kernel(const TE* __restrict__ P, const float*
       }
     }
     TE* o = out + i * out_cs + out_co;
-    o[0] = (TE)a0; o[1] = (TE)a1;
+    if (pad4) PwcElem<TE>::st4(o, f32x4{a0, a1, 0.f, 0.f});
+    else { o[0] = (TE)a0; o[1] = (TE)a1; }
   }
 }
 
@@ -368,14 +496,9 @@ __global__ void pwc_conv3_combine_kernel(const float* __restrict__ T, const floa
   }
 }
 
-// zero the channel range [c0, c0 + nc) of every pixel (the padding channels of a decoder buffer: everything else is written
-// before it is read, so a memset of the whole 608-channel buffer -- 5 GB at level 2 of a 5-frame stack -- is not needed)
-template <typename TE>
-__global__ void pwc_zero_channels_kernel(TE* __restrict__ buf, int cs, int c0, int nc, size_t npix) {
-  const size_t total = npix * nc;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    buf[(i / nc) * cs + c0 + (int)(i % nc)] = (TE)0.f;
-}
+// (The padding channels of a decoder buffer -- 7 / 15 behind the cost volume, 2 behind up_flow and up_feat -- are written as zeros by
+// the kernels that fill the group in front of them (r05; a launch of their own before that: 0.5 ms per stack, the level-2 ones 0.1-0.2 ms
+// each for 4-14 bytes per 1152-byte pixel).  Everything else is written before it is read: no memset of the buffers.)
 
 // conv1a of the feature pyramid (model_pwcnet.py:1092: 3 -> 16 channels, stride 2, 'same' = pad (0, 1) on the even sizes the
 // network runs on, leaky relu): [N, H, W, 4] -> [N, H/2, W/2, 16] on v_mfma_f32_16x16x4_f32 -- rows = the 16 output channels, columns =
@@ -421,6 +544,50 @@ __global__ __launch_bounds__(256) void pwc_conv1a_kernel(const TE* __restrict__ 
   }
 }
 
+// The fp16 engine's conv1a (r05): K = 16 of v_mfma_f32_16x16x16_f16 is FOUR taps x the 4 channels of an input pixel, so lane (pixel
+// col, quad kq) fetches the whole 8-byte pixel of tap 4 m + kq for MFMA m: three 8-byte loads and three MFMAs per 16 output pixels
+// instead of nine 2-byte loads and nine fp32 MFMAs (497 us per 5-frame stack at 1.35 TB/s).  Weights rounded to fp16 like every other
+// layer of this engine; bias, accumulation and the leaky relu in fp32.
+__global__ __launch_bounds__(256) void pwc_conv1a_f16_kernel(const _Float16* __restrict__ in, const Conv1aWeights cw, _Float16* __restrict__ out,
+                                                             int N, int H, int W, float slope) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, col = lane & 15, kq = lane >> 4;
+  h4 wa[3];
+  int dy[3], dx[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int t = 4 * m + kq;                                                  // this lane's tap of MFMA m (taps 9 .. 11 do not exist)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wa[m][c] = t < 9 ? (_Float16)cw.w[t * 64 + c * 16 + col] : (_Float16)0.f;
+    dy[m] = t < 9 ? t / 3 : 0; dx[m] = t < 9 ? t % 3 : 0;
+  }
+  f32x4 b4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) b4[e] = cw.bias[4 * kq + e];                     // result register e of lane (pixel col, quad kq) = output 4 kq + e
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)N * OH * OW, groups = (total + 15) / 16;
+  const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t g = wave0; g < groups; g += nwaves) {
+    const size_t i = g * 16 + col;
+    const bool live = i < total;
+    const size_t ii = live ? i : total - 1;
+    const int ox = (int)(ii % OW), oy = (int)((ii / OW) % OH), n = (int)(ii / ((size_t)OW * OH));
+    h4 x[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int iy = 2 * oy + dy[m], ix = 2 * ox + dx[m];
+      x[m] = h4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      if (iy < H && ix < W && 4 * m + kq < 9) x[m] = *reinterpret_cast<const h4*>(in + ((size_t)(n * H + iy) * W + ix) * 4);
+    }
+    f32x4 acc = b4;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[m], x[m], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] >= 0.f ? acc[e] : acc[e] * slope;
+    if (live) PwcElem<_Float16>::st4(out + i * 16 + 4 * kq, acc);
+  }
+}
+
 // cost volume: out[px][(dy+4)*9 + (dx+4)] = leaky_relu(mean_c c1[px][c] * w2[px + (dy, dx)][c], 0.1), zero outside.
 // One workgroup per 8x32 pixel tile, one thread per pixel with all 81 sums in registers; the (8+8) x (32+8) halo of w2
 // goes through LDS 16 channels at a time (80-byte records: a ds_read_b128 phase of 16 neighbouring pixels hits every
@@ -435,7 +602,7 @@ constexpr size_t costvol_lds_bytes() { return (size_t)CV_HH * CV_HW * CV_REC; }
 template <typename TE>
 __global__ __launch_bounds__(256) void pwc_costvol_kernel(const TE* __restrict__ c1, int c1_cs, int c1_co, const PwcItems c1_img,
                                                           const TE* __restrict__ w2, const PwcItems w2_img, int C,
-                                                          TE* __restrict__ out, int out_cs, int out_co, int N, int H, int W) {
+                                                          TE* __restrict__ out, int out_cs, int out_co, int N, int H, int W, int zero_pad) {
   extern __shared__ __attribute__((aligned(16))) char cv_smem[];
   const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
@@ -496,7 +663,12 @@ __global__ __launch_bounds__(256) void pwc_costvol_kernel(const TE* __restrict__
     for (int e = 0; e < 4; ++e) { const float m = s[k + e] * inv; v[e] = m >= 0.f ? m : 0.1f * m; }
     PwcElem<TE>::st4(o + k, v);
   }
-  { const float m = s[80] * inv; o[80] = (TE)(m >= 0.f ? m : 0.1f * m); }
+  const float m80 = s[80] * inv, v80 = m80 >= 0.f ? m80 : 0.1f * m80;
+  if (zero_pad == 0) { o[80] = (TE)v80; return; }
+  // zero_pad (a multiple of 4, the decoder's 7 or 15): the padding channels behind the 81 displacements read as zeros in the next
+  // convolution; written here they are part of the pixel's one contiguous run (as a launch of their own they were 184 us at level 2)
+  PwcElem<TE>::st4(o + 80, f32x4{v80, 0.f, 0.f, 0.f});
+  for (int k = 84; k < 81 + zero_pad; k += 4) PwcElem<TE>::st4(o + k, f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
 // dense_image_warp: out[px][c] = bilinear(img, x + scale*u, y + scale*v); floor index clamped to [0, size-2], weight

@@ -448,6 +448,36 @@ def test_lds_dma_general_dilated_fp16_vs_oracle(dil, shape, cout):
     assert (got[..., :out_co] == 7.25).all() and (got[..., out_co + cout:] == 7.25).all()
 
 
+@pytest.mark.parametrize("case", [
+    # h, w, cin, cout, stride, in_cs, in_co, out_cs, out_co
+    (271, 479, 16, 32, 2, 16, 0, 32, 0),        # conv2a's shape on an odd size: Cout 32 of a 64-channel block, TF 'SAME' pads (1, 1)
+    (136, 241, 96, 128, 2, 96, 0, 128, 0),      # six chunks
+    (19, 31, 196, 196, 1, 196, 0, 196, 0),      # level 6: 196 channels = 12 chunks + 4, pixel records 8-byte aligned only
+    (23, 40, 52, 48, 1, 60, 4, 52, 4),          # a channel range of a wider buffer at an 8-byte offset, ragged last chunk, untouched neighbours
+    (40, 70, 64, 16, 2, 72, 8, 16, 0),          # 16-byte aligned range of a wider buffer (the aligned instantiation), 16 outputs
+])
+def test_fp16_generic_kernel_on_the_matrix_pipe_vs_oracle(case):
+    """pwc_convg_f16_kernel<A16> (r05): the fp16 engine's stride-2 pyramid convolutions and level 6's 196-channel layers -- fp16 operands
+    (inputs and weights exactly representable here), fp32 accumulation: what is left against the float64 oracle is the accumulation
+    order and the fp16 rounding of the stored result."""
+    h, wd, cin, cout, stride, in_cs, in_co, out_cs, out_co = case
+    rng = np.random.default_rng(h * 131 + cin)
+    xfull = _h16(rng.standard_normal((2, h, wd, in_cs)) * 0.5)
+    w = _h16(rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin)))
+    b = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    oh, ow = -(-h // stride), -(-wd // stride)
+    xb = _dev(xfull, "fp16")
+    ob = torch.full((2, oh, ow, out_cs), 7.25, dtype=torch.float16, device="cuda")
+    took = _run_conv(xb, in_co, cin, w, b, None, ob, out_co, 2, h, wd, stride, 1, 0.1, 1, prec="fp16")
+    assert took == 1
+    exp = _oracle_conv(xfull[..., in_co:in_co + cin], w, b, stride, 1, 0.1)
+    got = _host(ob)
+    err = np.abs(got[..., out_co:out_co + cout] - exp).max()
+    print(f"fp16 generic kernel {case}: max|err| {err:.2e}")
+    assert err < 1.5e-3 * max(1.0, np.abs(exp).max())
+    assert (got[..., :out_co] == 7.25).all() and (got[..., out_co + cout:] == 7.25).all()
+
+
 def test_fp16_engine_routes_and_small_kernels_vs_oracle():
     """The other layer types of the fp16 flow engine on level-sized maps: stride-2 pyramid conv (generic kernel, fp16 in / out),
     the 2-channel flow head and dc_conv7 (FISRnet's 16-row fp16 kernel, float32 out, + the float32 flow),
