@@ -280,7 +280,8 @@ hipError_t launch_costvol(const TE* c1, int c1_cs, int c1_co, const PwcItems& c1
     cv_attr[dev] = true;
   }
   const int cv_tiles = ((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n;
-  hipLaunchKernelGGL(pwc_costvol_kernel<TE>, dim3(cv_tiles), dim3(256), costvol_lds_bytes(), st, c1, c1_cs, c1_co, c1_img, c2, c2_img, C, out,
+  const size_t cv_lds = std::is_same<TE, _Float16>::value ? (size_t)CV_HH * CV_HW * CV_REC16 : costvol_lds_bytes();
+  hipLaunchKernelGGL(pwc_costvol_kernel<TE>, dim3(cv_tiles), dim3(256), cv_lds, st, c1, c1_cs, c1_co, c1_img, c2, c2_img, C, out,
                      out_cs, out_co, n, h, w, zero_pad);
   return hipGetLastError();
 }
@@ -482,6 +483,12 @@ struct PwcRunner {
       return;
     }
     if (rc || ar.dry) return;
+    if (pd.cin4 == 4) {
+      hipLaunchKernelGGL((pwc_deconv4_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w)), dim3(256), 0, st, in, in_cs, in_co, pd.d_w, pd.d_b, out,
+                         out_cs, out_co, n, h, w, p4);
+      check(name.c_str());
+      return;
+    }
     hipLaunchKernelGGL((pwc_deconv_kernel<TI, TE>), dim3(grid_for((size_t)n * 4 * h * w * 8)), dim3(256), 0, st, in, in_cs, in_co, pd.cin4,
                        pd.d_w, pd.d_b, out, out_cs, out_co, n, h, w, p4);
     check(name.c_str());
@@ -540,7 +547,8 @@ struct PwcRunner {
           hipLaunchKernelGGL(pwc_copy_channels_kernel<TE>, dim3(grid_for(npx * PWC_CH[l] / 4)), dim3(256), 0, st, F[l], items, PWC_CH[l], D,
                              L.total, L.off_c1, px, N);
           check("copy c1");
-          hipError_t e = launch_costvol<TE>(D, L.total, L.off_c1, ident, Wp, ident, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st, corr_pad);   // :1277
+          // (c1 read from the level's own dense tensor, not from its 1152-byte-stride copy in the buffer)
+          hipError_t e = launch_costvol<TE>(F[l], PWC_CH[l], 0, items, Wp, ident, PWC_CH[l], D, L.total, L.off_corr, N, h, w, st, corr_pad);   // :1277
           if (e != hipSuccess && rc == 0) rc = pfail(ctx, FISR_EHIP, std::string("cost volume: ") + hipGetErrorString(e));
         }
       } else if (!rc && !ar.dry) {

@@ -337,6 +337,38 @@ __global__ void pwc_deconv_kernel(const TI* __restrict__ in, int in_cs, int in_c
   }
 }
 
+// The same transpose conv for a FOUR-channel input (up_flow: the 2-channel flow in a 4-channel record): one thread per output pixel --
+// the eight-lane form above leaves seven of its lanes without a channel group (325 us at level 2 of a 5-frame stack).  Same taps in the
+// same order: bit-identical sums.
+template <typename TI, typename TO>
+__global__ void pwc_deconv4_kernel(const TI* __restrict__ in, int in_cs, int in_co, const float* __restrict__ w, const float* __restrict__ bias,
+                                   TO* __restrict__ out, int out_cs, int out_co, int N, int H, int W, int pad4) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)N * OH * OW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH), n = (int)(i / ((size_t)OW * OH));
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+      const int ky = ((oy + 1) & 1) + 2 * ty, iy = (oy + 1 - ky) / 2;
+      if ((oy + 1 - ky) < 0 || iy >= H) continue;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int kx = ((ox + 1) & 1) + 2 * tx, ix = (ox + 1 - kx) / 2;
+        if ((ox + 1 - kx) < 0 || ix >= W) continue;
+        const f32x4 v = PwcElem<TI>::ld4(in + ((size_t)(n * H + iy) * W + ix) * in_cs + in_co);
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 0) * 4);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(w + ((size_t)(ky * 4 + kx) * 2 + 1) * 4);
+        a0 += v.x * k0.x + v.y * k0.y + v.z * k0.z + v.w * k0.w;
+        a1 += v.x * k1.x + v.y * k1.y + v.z * k1.z + v.w * k1.w;
+      }
+    }
+    TO* o = out + i * out_cs + out_co;
+    if (pad4) PwcElem<TO>::st4(o, f32x4{a0 + bias[0], a1 + bias[1], 0.f, 0.f});
+    else { o[0] = (TO)(a0 + bias[0]); o[1] = (TO)(a1 + bias[1]); }
+  }
+}
+
 // The transpose conv of a WIDE tensor (up_feat: 565 -> 2 channels) in two steps, fp16 engine: the 16 taps x 2 outputs are 32 output
 // channels of a 1x1 convolution, P[pixel][tap * 2 + o] = sum_c in[pixel][c] * kernel[tap][o][c] -- run as a 3x3 convolution whose
 // only non-zero tap is the centre on the LDS-DMA kernel (conv3x3_dma.h), so the matrix pipe shares every weight fragment among 32
@@ -596,6 +628,13 @@ constexpr int CV_CH = 16;
 constexpr int CV_REC = CV_CH * 4 + 16;
 constexpr int CV_HW = TILE_W + 8, CV_HH = TILE_H + 8;
 constexpr size_t costvol_lds_bytes() { return (size_t)CV_HH * CV_HW * CV_REC; }
+// fp16 engine (r05): the halo chunk stays fp16 in LDS -- 32 bytes of a 48-byte record (12 banks apart: a ds_read_b128 phase of 16
+// neighbouring pixels still hits every bank once) -- and a displacement's 16 products are eight v_dot2_f32_f16 (two fp16 products + an
+// fp32 accumulator each).  The fp32 form of this kernel is bound by its LDS reads (324 ds_read_b128 per pixel and chunk: twice the
+// cycles of its 1296 FMAs); halving both took level 2 of a 5-frame stack from 944 us to the figure in DESIGN 3.4.
+constexpr int CV_REC16 = CV_CH * 2 + 16;
+typedef _Float16 cv_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 cv_h4 __attribute__((ext_vector_type(4)));
 
 // Batched form: image n of c1 is c1 + (size_t)c1_img[n] * H * W * c1_cs (the features of the item's first frame, or its slot of the
 // decoder buffer), likewise w2.
@@ -620,6 +659,45 @@ __global__ __launch_bounds__(256) void pwc_costvol_kernel(const TE* __restrict__
   float s[81];
 #pragma unroll
   for (int k = 0; k < 81; ++k) s[k] = 0.f;
+  if constexpr (std::is_same<TE, _Float16>::value) {
+    for (int c0 = 0; c0 < C; c0 += CV_CH) {
+      const int nq = min(4, (C - c0) >> 2);               // 4-channel quarters of this chunk that exist (C % 4 == 0)
+      for (int i = tid; i < CV_HH * CV_HW * 4; i += 256) {
+        const int hp = i >> 2, q = i & 3;
+        const int hy = hp / CV_HW, hx = hp - hy * CV_HW;
+        const int gy = y0 - 4 + hy, gx = x0 - 4 + hx;
+        uint2 v = make_uint2(0u, 0u);
+        if (q < nq && gy >= 0 && gy < H && gx >= 0 && gx < W)
+          v = *reinterpret_cast<const uint2*>(w2n + ((size_t)gy * W + gx) * C + c0 + 4 * q);
+        *reinterpret_cast<uint2*>(cv_smem + hp * CV_REC16 + q * 8) = v;
+      }
+      cv_h2 a[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cv_h4 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (q < nq) v = *reinterpret_cast<const cv_h4*>(c1n + pix_in * c1_cs + c0 + 4 * q);
+        a[2 * q] = cv_h2{v.x, v.y}; a[2 * q + 1] = cv_h2{v.z, v.w};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 9; ++dx) {
+          const char* r = cv_smem + ((ty + dy) * CV_HW + tx + dx) * CV_REC16;
+          float acc = s[dy * 9 + dx];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint4 u = *reinterpret_cast<const uint4*>(r + q * 16);
+            acc = __builtin_amdgcn_fdot2(a[4 * q], __builtin_bit_cast(cv_h2, u.x), acc, false);
+            acc = __builtin_amdgcn_fdot2(a[4 * q + 1], __builtin_bit_cast(cv_h2, u.y), acc, false);
+            acc = __builtin_amdgcn_fdot2(a[4 * q + 2], __builtin_bit_cast(cv_h2, u.z), acc, false);
+            acc = __builtin_amdgcn_fdot2(a[4 * q + 3], __builtin_bit_cast(cv_h2, u.w), acc, false);
+          }
+          s[dy * 9 + dx] = acc;
+        }
+      __syncthreads();
+    }
+  } else
   for (int c0 = 0; c0 < C; c0 += CV_CH) {
     const int nq = min(4, (C - c0) >> 2);                 // 16-byte quarters of this chunk that exist (C % 4 == 0)
     for (int i = tid; i < CV_HH * CV_HW * 4; i += 256) {  // halo chunk of w2 -> LDS, zeros outside the image
