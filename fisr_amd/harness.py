@@ -357,6 +357,7 @@ def run_test(net):
     print("######### Test (average) test_SSIM: FISR %.8f, SR %.8f #########" % (res["FISR_SSIM"], res["SR_SSIM"]))
     print("######### (extra) Y-channel-only test_PSNR: FISR %.8f[dB], SR %.8f[dB]  #########" % (res["FISR_PSNR_Y"], res["SR_PSNR_Y"]))
     print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % res["inference_time_per_frame"])
+    print("          (timed: a tile's share of one fisr_forward_frames call = input assembly + forward of up to 16 tiles; the reference times sess.run of one tile, FISRnet.py:868-874)")
     # (what is timed differs from the reference's sess.run of ONE tile, FISRnet.py:868-874: here a tile's share of one batched
     #  fisr_forward_frames call -- input assembly, tile cut and level inputs included -- times the tiles of a frame)
     res["inference_time_is"] = "tile's share of a batched fisr_forward_frames call (input assembly included) x tiles per frame"
@@ -491,4 +492,5 @@ def run_fisr_for_video(net, flow_file_name, warp_file_name, parallel=None):
         import torch.distributed as dist
         dist.barrier()
     print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % per_frame)
+    print("          (timed: a tile's share of one fisr_forward_frames call = input assembly + forward of up to 16 tiles; the reference times sess.run of one tile, FISRnet.py:868-874)")
     return dict(frames=sorted(set(written)), out_dir=out_dir, inference_time_per_frame=per_frame)
