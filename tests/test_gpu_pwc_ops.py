@@ -399,6 +399,27 @@ def test_warp_with_flows_leaving_the_image_vs_oracle(shape):
     assert err < 2e-4
 
 
+@pytest.mark.parametrize("shape,c", [((17, 30), 196), ((34, 61), 128), ((75, 133), 32), ((9, 40), 20)])
+def test_costvol_fp16_dot2_kernel_vs_oracle(shape, c):
+    """The fp16 engine's cost volume (r05: halo chunk kept in fp16 in LDS, v_dot2_f32_f16 products): channel counts that are not a
+    multiple of the 16-channel chunk (196 = 12 x 16 + 4, 20), ragged tiles, an output slot inside a wider buffer whose neighbours stay."""
+    h, wd = shape
+    rng = np.random.default_rng(h * 1000 + c)
+    c1 = _h16(rng.standard_normal((2, h, wd, c)) * 0.7)
+    c2 = _h16(rng.standard_normal((2, h, wd, c)) * 0.7)
+    c1b, c2b = _dev(c1, "fp16"), _dev(c2, "fp16")
+    cv = torch.full((2, h, wd, 96), 9.5, dtype=torch.float16, device="cuda")
+    flib.check(flib.lib().fisr_pwc_op_costvol(_ptr(c1b), _ptr(c2b), c, _ptr(cv), 96, 8, 2, h, wd, flib.PREC_F16, _stream()))
+    torch.cuda.synchronize()
+    t = lambda a: torch.from_numpy(a).double().permute(0, 3, 1, 2)
+    exp = P.lrelu(P.cost_volume(t(c1), t(c2))).permute(0, 2, 3, 1).numpy()
+    got = _host(cv)
+    err = np.abs(got[..., 8:89] - exp).max()
+    print(f"fp16 cost volume {shape} x {c}: max|err| {err:.2e}")
+    assert err < 1e-3 * max(1.0, np.abs(exp).max())
+    assert (got[..., :8] == 9.5).all() and (got[..., 89:] == 9.5).all()
+
+
 def test_op_entry_errors():
     x = torch.zeros((1, 16, 32, 32), device="cuda")
     o = torch.zeros((1, 16, 32, 64), device="cuda")
