@@ -18,7 +18,7 @@
 #include <algorithm>
 #include <cstring>
 #include <vector>
-#include "conv3x3_wino8p.h"      // (the shared constants and LDS-DMA macros; first_t / rest_t)
+#include "../conv3x3_wino8p.h"      // (the shared constants and LDS-DMA macros; first_t / rest_t)
 
 namespace fisr {
 
@@ -322,7 +322,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8b_kernel(const ConvArgs p
 
   // ---- prologue of the workgroup's FIRST item ----
   int b_cur = blockIdx.x;
-  if (ph == 1) __builtin_amdgcn_s_setprio(3);
+  // -DFISR_WB_PRIO: 1 (default, as conv3x3_wino8p.h) the copy waves go first where the two waves of a SIMD compete, 2 the
+  // transform waves, 0 nobody
+#ifndef FISR_WB_PRIO
+#define FISR_WB_PRIO 1
+#endif
+  if (FISR_WB_PRIO == 1 && ph == 1) __builtin_amdgcn_s_setprio(3);
+  if (FISR_WB_PRIO == 2 && ph == 0) __builtin_amdgcn_s_setprio(3);
   Item cur = item_of(b_cur);
   int b_nxt = b_cur + gridDim.x;
   bool has_next = valid(b_nxt);

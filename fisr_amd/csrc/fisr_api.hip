@@ -29,7 +29,6 @@
 #endif
 #include "conv3x3.h"
 #include "conv3x3_wino8p.h"
-#include "conv3x3_wino8b.h"
 #include "conv3x3_wf4.h"
 #include "conv3x3_dma.h"
 #include "conv3x3_dma_fs.h"
@@ -61,7 +60,6 @@ struct ConvW {
   bool rows16 = false;    // fp32, Cout == 16: take the 16-row variant too (PWC-Net's level-1 features fill its rows exactly; NT = 1 computes 32)
   int wexp = 0;  // f16f8: power-of-two pre-scale of the fp8 weight parts
   void* d_wu = nullptr;   // FISR_PREC_F32W: U = G g G^T in the Winograd kernel's LDS image (conv3x3_wino_common.h), else NULL
-  void* d_wub = nullptr;  // FISR_PREC_F32WB: U = Uh + Ul as bf16 pairs in the LDS image of conv3x3_wino8b.h, else NULL
   void* d_wu4 = nullptr;  // FISR_PREC_F32W4: U = G g G^T of F(4x4,3x3) in the LDS image of conv3x3_wf4.h, else NULL
   float* d_wh = nullptr;  // FISR_PREC_F32W, Cout <= 6: [9][cin_pad][4 | 6] for the vector-ALU head kernel (head_conv.h), else NULL
   void* d_wd = nullptr;   // FISR_PREC_F16, Cout > 32: the weight slabs of the LDS-DMA kernel (conv3x3_dma.h); FISR_PREC_F16F8, Cout % 64 == 0: of
@@ -83,7 +81,6 @@ struct fisr_ctx {
   int precision = -1;
   bool wino = false;      // FISR_PREC_F32W / F32W4: eligible convs run the Winograd F(2x2,3x3) kernel
   bool wf4 = false;       // FISR_PREC_F32W4: ... and those conv3x3_wf4.h takes (wf4_wins) the F(4x4,3x3) kernel
-  bool wsplit = false;    // FISR_PREC_F32WB: the Winograd F(2x2,3x3) kernel with split-bf16 products (conv3x3_wino8b.h)
   bool finalized = false;
   std::map<std::string, ConvW> convs;  // keyed by conv name (without /w, /b)
   std::string err;
@@ -196,7 +193,7 @@ template <> struct PrecName<fsplit> { static const char* get() { return "f16f8";
 // call f(T()) with the activation type of `precision`
 template <typename F>
 auto with_prec(int precision, F&& f) {
-  if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4 || precision == FISR_PREC_F32WB) return f(float());
+  if (precision == FISR_PREC_F32 || precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4) return f(float());
   if (precision == FISR_PREC_F16 || precision == FISR_PREC_F16R) return f(_Float16());
   if (precision == FISR_PREC_F16F8 || precision == FISR_PREC_F16F8R) return f(fsplit());
   return f(bsplit());
@@ -204,7 +201,7 @@ auto with_prec(int precision, F&& f) {
 inline bool prec_ok(int precision) {
   return precision == FISR_PREC_F32 || precision == FISR_PREC_F16 || precision == FISR_PREC_BF16X3 ||
          precision == FISR_PREC_F16F8 || precision == FISR_PREC_F32W || precision == FISR_PREC_F16R || precision == FISR_PREC_F32W4 ||
-         precision == FISR_PREC_F16F8R || precision == FISR_PREC_F32WB;
+         precision == FISR_PREC_F16F8R;
 }
 // FISR_PREC_MIXED: which layers keep a split-precision arithmetic (f16f8) -- everything that works at the full and at
 // the half resolution of level 3 (its first two encoder levels, its last two decoder levels, both heads: 55 % of the
@@ -249,7 +246,7 @@ inline uint8_t host_fp8_e4m3(float f) {
   return sign | (uint8_t)(((ex + 7) << 3) | ((int)r - 8));
 }
 inline int prec_chunk(int precision) { return precision == FISR_PREC_F16 || precision == FISR_PREC_F16R ? 32 : 16; }
-inline bool prec_f32w(int precision) { return precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4 || precision == FISR_PREC_F32WB; }   // fp32 tensors, Winograd engines
+inline bool prec_f32w(int precision) { return precision == FISR_PREC_F32W || precision == FISR_PREC_F32W4; }   // fp32 tensors, Winograd engines
 inline int prec_unit(int precision) { return precision == FISR_PREC_F32 || prec_f32w(precision) ? 4 : 8; }   // glue kernels: channels per 16 bytes
 constexpr int CONV_REC = 16;   // the conv kernel stores whole 16-channel records
 
@@ -413,7 +410,7 @@ template <typename T> inline int nt_for(int co) {
 }
 
 template <typename T>
-int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, bool wf4 = false, bool winob = false) {
+int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, bool wf4 = false) {
   constexpr int CC = Prec<T>::CC;
   cw.nt = (cw.rows16 && cw.co == 16 && std::is_same<T, float>::value) ? 0 : nt_for<T>(cw.co);
   cw.cin_pad = round_up(cw.ci, CC);
@@ -437,16 +434,10 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, b
   HIP_OK(ctx, hipMemcpy(cw.d_w, wp.data(), wp.size(), hipMemcpyHostToDevice));
   HIP_OK(ctx, hipMemcpy(cw.d_b, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
   if (cw.d_wu) { (void)hipFree(cw.d_wu); cw.d_wu = nullptr; }
-  if (wino && !winob && std::is_same<T, float>::value && wino_eligible(cw.ci, cw.co)) {
+  if (wino && std::is_same<T, float>::value && wino_eligible(cw.ci, cw.co)) {
     pack_weights_wino(cw.w.data(), cw.ci, cw.co, cw.cin_pad, wp);
     HIP_OK(ctx, hipMalloc(&cw.d_wu, wp.size()));
     HIP_OK(ctx, hipMemcpy(cw.d_wu, wp.data(), wp.size(), hipMemcpyHostToDevice));
-  }
-  if (cw.d_wub) { (void)hipFree(cw.d_wub); cw.d_wub = nullptr; }
-  if (winob && std::is_same<T, float>::value && wino_eligible(cw.ci, cw.co)) {
-    pack_weights_winob(cw.w.data(), cw.ci, cw.co, cw.cin_pad, wp);
-    HIP_OK(ctx, hipMalloc(&cw.d_wub, wp.size()));
-    HIP_OK(ctx, hipMemcpy(cw.d_wub, wp.data(), wp.size(), hipMemcpyHostToDevice));
   }
   if (cw.d_wu4) { (void)hipFree(cw.d_wu4); cw.d_wu4 = nullptr; }
   if (wf4 && std::is_same<T, float>::value && cw.co % F4_BN == 0 && cw.cin_pad % F4_CH == 0) {
@@ -872,9 +863,6 @@ struct Runner {
     if (use_wino) a.wpk = cw.d_wu;
     const bool use_wf4 = std::is_same<T, float>::value && ctx->wf4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cw.co) && wf4_wins(h, w, c0 + c1);
     if (use_wf4) a.wpk = cw.d_wu4;
-    const bool use_winob = std::is_same<T, float>::value && ctx->wsplit && cw.d_wub && !out_f32 && !pool_out && !ups && wino_chunks_ok(c0, c1) &&
-                           wino_fits(n, h, w, c0, c1, cw.co);
-    if (use_winob) a.wpk = cw.d_wub;
     if (pool_out) {
       if (!use_wf4 && !(split_pool_ok<T>() && cw.nt >= 1 && !out_f32 && !a.d2s && !(h & 1) && !(w & 1))) {
         rc = fail(ctx, FISR_ESTATE, name + ": fused pooling asked of a conv that runs on neither the F(4x4) kernel nor the split formats' record store");
@@ -894,7 +882,6 @@ struct Runner {
     if (use_dma) snprintf(cls, sizeof cls, "conv3x3_dma<f16>");
     else if (use_dmafs) snprintf(cls, sizeof cls, "conv3x3_dma_fs<f16f8,tw%d,%s,%s>", dmafs_tile_w(a), a.relu_in ? "relu_in" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
     else if (use_wf4) snprintf(cls, sizeof cls, "conv3x3_wf4<f32w4,%s,%s>", a.relu_in ? "relu_in" : ups ? "up2" : "plain", pool_out ? "res+pool" : res ? "res" : "nores");
-    else if (use_winob) snprintf(cls, sizeof cls, "conv3x3_wino8b<f32wb,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_wino) snprintf(cls, sizeof cls, "conv3x3_wino8p<f32w,%s,%s>", a.relu_in ? "relu_in" : "plain", res ? "res" : "nores");
     else if (use_head) snprintf(cls, sizeof cls, "head_conv_f32<valu>");
     else snprintf(cls, sizeof cls, "conv3x3_mfma<%s,NT%d>%s", PrecName<T>::get(), cw.nt, out_f32 ? "_f32out" : "");
@@ -909,7 +896,6 @@ struct Runner {
     check(use_dma ? launch_conv_dma(a, st)
                   : use_dmafs ? launch_conv_dmafs(a, st)
                   : use_wf4 ? launch_conv_wf4(a, st)
-                  : use_winob ? launch_conv_winob(a, st)
                   : use_wino ? launch_conv_wino(a, st) : (use_head ? launch_head_valu(a, cw.d_wh, st) : launch_conv<T>(a, cw.nt, out_f32, st)), name.c_str());
   }
 
@@ -1226,7 +1212,6 @@ void fisr_destroy(fisr_ctx* ctx) {
     if (kv.second.d_w) (void)hipFree(kv.second.d_w);
     if (kv.second.d_b) (void)hipFree(kv.second.d_b);
     if (kv.second.d_wu) (void)hipFree(kv.second.d_wu);
-    if (kv.second.d_wub) (void)hipFree(kv.second.d_wub);
     if (kv.second.d_wu4) (void)hipFree(kv.second.d_wu4);
     if (kv.second.d_wh) (void)hipFree(kv.second.d_wh);
     if (kv.second.d_wd) (void)hipFree(kv.second.d_wd);
@@ -1282,13 +1267,12 @@ int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   HIP_OK(ctx, guard.err);
   for (auto& kv : ctx->convs) {
     const int lp = layer_prec(precision, kv.first);
-    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, prec_f32w(lp), prec_dma(lp), lp == FISR_PREC_F32W4, lp == FISR_PREC_F32WB); });
+    int rc = with_prec(lp, [&](auto tag) { return upload_conv<decltype(tag)>(ctx, kv.second, prec_f32w(lp), prec_dma(lp), lp == FISR_PREC_F32W4); });
     if (rc) return rc;
     kv.second.prec = lp;
   }
   ctx->wino = prec_f32w(precision);
   ctx->wf4 = precision == FISR_PREC_F32W4;
-  ctx->wsplit = precision == FISR_PREC_F32WB;
   ctx->precision = precision;
   ctx->finalized = true;
   return 0;
@@ -1547,7 +1531,7 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   cw.ci = c0 + c1; cw.co = cout;
   cw.w.assign(w_host, w_host + (size_t)9 * cw.ci * cout);
   cw.b.assign(b_host, b_host + cout);
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), prec_dma(precision), precision == FISR_PREC_F32W4, precision == FISR_PREC_F32WB); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), prec_dma(precision), precision == FISR_PREC_F32W4); });
   if (rc) return rc;
   // (FISR_PREC_F32W4 at op level: the F(4x4) kernel for every shape it takes -- the engine adds its map-size rule, wf4_wins)
   const bool use_wf4 = precision == FISR_PREC_F32W4 && cw.d_wu4 && !out_f32 && wf4_fits(h, w, c0, c1, cout) && !(res && (flags & FISR_CONV_D2S));
@@ -1556,10 +1540,8 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   // (FISR_PREC_F16F8: the persistent LDS-DMA kernel wherever it has an instantiation)
   bool use_dmafs = precision == FISR_PREC_F16F8 && cw.d_wd && !out_f32 && dmafs_fits(h, w, c0, c1, cout) &&
                    !(pool_out && ((flags & FISR_CONV_RELU_IN) || !res));
-  const bool use_winob = precision == FISR_PREC_F32WB && cw.d_wub && !out_f32 && !pool_out && !(flags & FISR_CONV_UP2_IN) && wino_chunks_ok(c0, c1) &&
-                         wino_fits(n, h, w, c0, c1, cout);
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : use_winob ? cw.d_wub : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
+  a.in0 = in0; a.in1 = in1; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma || use_dmafs ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = c0; a.in1_cs = c1; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
@@ -1575,7 +1557,6 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   hipError_t e = use_dma ? launch_conv_dma(a, st)
                  : use_dmafs ? launch_conv_dmafs(a, st)
                  : use_wf4 ? launch_conv_wf4(a, st)
-                 : use_winob ? launch_conv_winob(a, st)
                  : use_wino ? launch_conv_wino(a, st)
                  : use_head ? launch_head_valu(a, cw.d_wh, st)
                             : with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, out_f32 != 0, st); });
@@ -1583,7 +1564,6 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   (void)hipFree(cw.d_w);
   (void)hipFree(cw.d_b);
   if (cw.d_wu) (void)hipFree(cw.d_wu);
-  if (cw.d_wub) (void)hipFree(cw.d_wub);
   if (cw.d_wu4) (void)hipFree(cw.d_wu4);
   if (cw.d_wh) (void)hipFree(cw.d_wh);
   if (cw.d_wd) (void)hipFree(cw.d_wd);
@@ -1667,9 +1647,8 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   cw.b.assign(cout, 0.01f);
   uint32_t st = 12345u;
   for (auto& v : cw.w) { st = st * 1664525u + 1013904223u; v = zero_fill ? 0.f : ((int)(st >> 9) % 2001 - 1000) * 2e-5f; }
-  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), prec_dma(precision), precision == FISR_PREC_F32W4, precision == FISR_PREC_F32WB); });
+  int rc = with_prec(precision, [&](auto tag) { return upload_conv<decltype(tag)>(nullptr, cw, prec_f32w(precision), prec_dma(precision), precision == FISR_PREC_F32W4); });
   if (rc) return rc;
-  const bool use_winob = precision == FISR_PREC_F32WB && cw.d_wub && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
   const bool use_wf4 = precision == FISR_PREC_F32W4 && cw.d_wu4 && wf4_fits(h, w, cin, 0, cout) && !(with_res && (flags & FISR_CONV_D2S));
   const bool use_wino = !use_wf4 && prec_f32w(precision) && cw.d_wu && wino_chunks_ok(cin, 0) && wino_fits(n, h, w, cin, 0, cout);
   const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && dma_fits(h, w, cin, 0, cin, 0);
@@ -1690,7 +1669,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
         HIP_OK(nullptr, hipMemcpy((char*)d_res + o, hbuf.data(), std::min(hbuf.size() * 2, out_b - o), hipMemcpyHostToDevice));
   }
   ConvArgs a;
-  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : use_winob ? cw.d_wub : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
+  a.in0 = d_in; a.in1 = nullptr; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = d_res; a.out = d_out;
   a.C0 = cin; a.C1 = 0; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma || use_dmafs ? cw.cout_pad_d : cw.cout_pad;
   a.in0_cs = cin; a.in1_cs = 0; a.rec_cs = cout; a.rec_co = 0; a.slope = 0.f; a.dil = 1;
   a.relu_in = (flags & FISR_CONV_RELU_IN) != 0;
@@ -1717,7 +1696,6 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
     if (use_dma) return launch_conv_dma(a, nullptr);
     if (use_dmafs) return launch_conv_dmafs(a, nullptr);
     if (use_wf4) return launch_conv_wf4(a, nullptr);
-    if (use_winob) return launch_conv_winob(a, nullptr);
     if (use_wino) return launch_conv_wino(a, nullptr);
     return with_prec(precision, [&](auto tag) { return launch_conv<decltype(tag)>(a, cw.nt, false, nullptr); });
   };
@@ -1738,7 +1716,7 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(d_in); (void)hipFree(d_out); if (d_res) (void)hipFree(d_res);
-  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wub) (void)hipFree(cw.d_wub); if (cw.d_wu4) (void)hipFree(cw.d_wu4); if (cw.d_wh) (void)hipFree(cw.d_wh); if (cw.d_wd) (void)hipFree(cw.d_wd);
+  (void)hipFree(cw.d_w); (void)hipFree(cw.d_b); if (cw.d_wu) (void)hipFree(cw.d_wu); if (cw.d_wu4) (void)hipFree(cw.d_wu4); if (cw.d_wh) (void)hipFree(cw.d_wh); if (cw.d_wd) (void)hipFree(cw.d_wd);
   if (e != hipSuccess) return fail(nullptr, FISR_EHIP, std::string("bench launch: ") + hipGetErrorString(e));
   return 0;
 }

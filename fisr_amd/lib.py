@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_PKG)
 SO_PATH = os.environ.get("FISR_HIP_SO") or os.path.join(_PKG, "libfisr_hip.so")   # override: A/B kernel builds
 CSRC = os.path.join(_PKG, "csrc")
 
-PREC_F32, PREC_F16, PREC_BF16X3, PREC_F16F8, PREC_F32W, PREC_MIXED, PREC_F16R, PREC_MIXEDR, PREC_F32W4, PREC_F16F8R, PREC_F32WB = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+PREC_F32, PREC_F16, PREC_BF16X3, PREC_F16F8, PREC_F32W, PREC_MIXED, PREC_F16R, PREC_MIXEDR, PREC_F32W4, PREC_F16F8R = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 CONV_RELU_IN, CONV_RELU_OUT, CONV_D2S, CONV_UP2_IN = 1, 2, 4, 8
 
 EXPORTS = [

@@ -86,12 +86,8 @@ enum {
                           is a second store of that level's last convolution.  The F(4,3) transforms are worse conditioned: ~2e-5
                           instead of ~2e-6 per convolution against float64 -- through the network it does not add up (1.5e-6 on the
                           full tile, the F(2x2) engine's figure).  What fisrnet.py's "fp32" selects since round 3. */
-  FISR_PREC_F16F8R = 9, /* FISR_PREC_F16F8 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h).
+  FISR_PREC_F16F8R = 9 /* FISR_PREC_F16F8 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h).
                           For A/B runs, as FISR_PREC_F16R is for fp16. */
-  FISR_PREC_F32WB = 10 /* r06: fp32 activation tensors and fp32 transforms like FISR_PREC_F32W, the Winograd-domain PRODUCTS on the 16-bit
-                          matrix pipe: U = Uh + Ul, V = Vh + Vl as bf16 pairs (V is split in the kernel, behind the input transform), every
-                          product (Uh + Ul)(Vh + Vl) = 2 x v_mfma_f32_32x32x16_bf16 per 8 channels, fp32 accumulate (conv3x3_wino8b.h):
-                          ~2^-16 relative per product, 16 of the direct algorithm's 36 multiplies.  The 3 / 6-channel heads stay exact fp32. */
 };
 
 /* flags of fisr_op_conv3x3 */

@@ -10,7 +10,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "conv3x3_wino8b.h"
+#include "diag/conv3x3_wino8b.h"
 using namespace fisr;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
