@@ -13,7 +13,8 @@ inner loops of `FISRnet.test` / `FISR_for_video` (reference FISRnet.py:798-910),
 The headline (`value`, `dtype`) is the fp32 engine -- cfg2 says fp32, the reference computes in fp32: fp32 tensors,
 fp32 arithmetic, Winograd minimal filtering for the 3x3 convolutions (as cuDNN does under the reference's
 TensorFlow): F(4x4,3x3) on every map >= 48x64 and on the 512-channel maps, F(2x2,3x3) on the rest; under
-`other_precisions`, `fp32w` is the all-F(2x2) engine and `fp32d` the same engine with the direct exact-fp32 kernel.
+`other_precisions`, `fp32d` is the same engine with the direct exact-fp32 kernel (the exact reference; `fp32w`, the all-F(2x2) engine of
+round 2, is an A/B engine of the diagnostics build since r06).
 The split-precision engines (bf16x3, f16f8: fp32-grade results on the 16-bit / fp8 matrix pipes, far
 inside the reference tolerance of +-0.02 dB) are timed in the same run under `other_precisions`, each
 with its own roofline, its full-size comparison against the fp32 engine of this run and a check of one
@@ -168,7 +169,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--precision", default="fp32", choices=sorted(PEAK))
-    ap.add_argument("--others", default="fp32w,fp32d,bf16x3,f16f8,mixed",
+    ap.add_argument("--others", default="fp32d,bf16x3,f16f8,mixed",
                     help="further engines timed on rank 0 at N=1 under other_precisions ('' = none)")
     ap.add_argument("--parallelism", default="frame", choices=["frame", "tile"])
     ap.add_argument("--patch", default="2,2", help="tiles per frame, reference default (2,2)")
@@ -446,6 +447,9 @@ def main():
                             "backend": backend}),
             "library": flib_version,
             "roofline": roofline, "cpu_baseline": cpu_port, "cpu_baseline_onednn": cpu_onednn,
+            # where roofline.traffic / pmc_mfma_busy_frac come from: a committed rocprofv3 PMC table of THIS library (replayed, not
+            # measured in this process) or dropped -- also here at top level so that a consumer that keeps only known roofline keys sees it
+            "counter_fields_source": (roofline or {}).get("counter_fields_source"),
             "parity_vs_oracle": parity_oracle, "cfg5": cfg5, "training_step": training,
             "other_precisions": other or None,
             "extras_failed": extras_failed,

@@ -39,6 +39,7 @@ namespace fisr {
 
 constexpr int FS_TH = 8, FS_HH = FS_TH + 2;             // rows of a workgroup's pixel tile; its width TW is 64 or 32 (below)
 constexpr int FS_BN = 64;                                // output channels per item
+constexpr int FS_TRACE_WORDS = 16;                // 8-byte words of a workgroup's trace record (diagnostics: p.trace)
 constexpr int FS_CH = 16;                                // channels per K chunk = one 64-byte record
 constexpr int FS_REC = 64;
 constexpr int fs_halo_units(int tw) { return FS_HH * (tw + 2) * 4; }               // 16-byte units of a halo chunk: 2640 / 1360
@@ -562,8 +563,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
     if (!has_next) break;
     cur = nxt; b_cur = b_nxt;
   }
-  if (p.trace && tid == 0) {      // (two 64-byte records per workgroup: scripts/trace_fs.py)
-    unsigned long long* tr = p.trace + (size_t)blockIdx.x * 16;
+  if (p.trace && tid == 0) {      // (FS_TRACE_WORDS words per workgroup: fisr_api.hip sizes the buffer with it, scripts/trace_fs.py reads it)
+    unsigned long long* tr = p.trace + (size_t)blockIdx.x * FS_TRACE_WORDS;
     tr[0] = t_start; tr[1] = c_k; tr[2] = __builtin_readcyclecounter();
     tr[3] = c_ep; tr[4] = (unsigned long long)n_done; tr[5] = t_real; tr[6] = __builtin_amdgcn_s_memrealtime(); tr[7] = c_wait;
     tr[8] = c_comp; tr[9] = c_bar; tr[10] = c_issue;

@@ -209,8 +209,15 @@ __device__ __forceinline__ void wf4_store8(wf4_u32x2 data, __amdgpu_buffer_rsrc_
 // (ablations 8192 + 16384, wrong results) the same launches run 9-13 % faster than the product: that is all the redundant
 // transforms cost.  The instantiations are compiled into scripts/probes/wf4_bench (-DFISR_F4_SHARE, `WF4_SHARE=n wf4_bench check`)
 // and nowhere else.
+// In the product build SHARE is not even a template parameter: a constant false, every branch on it compiles out.
+#ifdef FISR_F4_SHARE
 template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false, bool GENERAL = false, bool SHARE = false>
 __global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
+#else
+template <bool RELU_IN, bool HAS_RES, bool POOL = false, bool UPS = false, bool GENERAL = false>
+__global__ __launch_bounds__(512) void conv3x3_wf4_kernel(const ConvArgs p, const int n_items) {
+  constexpr bool SHARE = false;
+#endif
   static_assert(!GENERAL || (!RELU_IN && !HAS_RES && !POOL && !UPS), "GENERAL is the plain instantiation on channel ranges");
   static_assert(!SHARE || (!UPS && !GENERAL), "V sharing: the plain / relu-on-load / residual / pooling instantiations");
   extern __shared__ __attribute__((aligned(16))) char smem[];

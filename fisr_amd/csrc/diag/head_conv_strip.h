@@ -22,7 +22,7 @@
 // the halves added last -- a different summation order than head_conv.h's chunk-major one, equal to rounding (parity tests:
 // tests/test_gpu_parity.py, against the fp64 oracle).
 #pragma once
-#include "head_conv.h"
+#include "../head_conv.h"
 
 namespace fisr {
 

@@ -37,9 +37,8 @@
 #include "diag/conv3x3_wino8.h"
 #endif
 #include "head_conv.h"
-#include "head_conv_strip.h"
-#ifndef FISR_HEAD_STRIP_DEFAULT
-#define FISR_HEAD_STRIP_DEFAULT 0      // decided by measurement
+#ifdef FISR_DIAG
+#include "diag/head_conv_strip.h"      // the strip-walking LDS-DMA heads (r05): measured, not adopted; FISR_HEAD_STRIP=1 runs them
 #endif
 #include "glue_kernels.h"
 
@@ -422,9 +421,11 @@ int upload_conv(fisr_ctx* ctx, ConvW& cw, bool wino = false, bool dma = false, b
     float mx = 0.f;
     for (float v : cw.w) mx = std::max(mx, std::fabs(v));
     // wh8 = fp8(w_h * 2^wexp), wl8 = fp8((w - w_h) * 2^(wexp+14)): one block scale for both cross terms (conv3x3.h).  The
-    // remainder is <= 2^-11 |w|, so the largest power of two with max|w| * 2^(wexp+3) <= 448 (fp8 e4m3 max) keeps both inside
-    // the format (wh8 <= 56: its 4 significant bits reach down to max|w| / 3584), kept inside the scale byte's range
-    cw.wexp = mx > 0.f ? std::min(30, std::max(-30, 5 - std::ilogb(mx) - 1)) : 0;
+    // remainder is <= 2^-11 |w| for weights in fp16's normal range, so the largest power of two with max|w| * 2^(wexp+3) <= 448 (fp8
+    // e4m3 max) keeps both inside the format (wh8 < 32: its 4 significant bits reach down to max|w| / 2048).  Below fp16's normal range
+    // the remainder is bounded absolutely, by 2^-25: wexp <= 19 keeps 2^-25 * 2^(wexp+14) inside fp8 for layers of tiny weights too
+    // (they then lose low-order bits of wh8 instead of saturating wl8).
+    cw.wexp = mx > 0.f ? std::min(19, std::max(-30, 5 - std::ilogb(mx) - 1)) : 0;
   }
   pack_weights<T>(cw.w.data(), cw.b.data(), cw.ci, cw.co, cw.cin_pad, cw.cout_pad, wp, bp, cw.wexp);
   if (cw.d_w) { (void)hipFree(cw.d_w); cw.d_w = nullptr; }
@@ -521,13 +522,12 @@ inline bool head_valu_enabled() {
   return true;
 #endif
 }
-inline bool head_strip_enabled() {
 #ifdef FISR_DIAG
-  static const int forced = [] { const char* e = getenv("FISR_HEAD_STRIP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  if (forced >= 0) return forced != 0;
-#endif
-  return FISR_HEAD_STRIP_DEFAULT != 0;
+inline bool head_strip_enabled() {
+  static const bool on = [] { const char* e = getenv("FISR_HEAD_STRIP"); return e && e[0] != '0'; }();
+  return on;
 }
+#endif
 hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st) {
   static bool attr_done[64] = {};
   int dev = 0;
@@ -543,8 +543,9 @@ hipError_t launch_head_valu(const ConvArgs& a, const float* d_wh, hipStream_t st
   h.in = (const float*)a.in0; h.w = d_wh; h.bias = a.bias; h.out = (float*)a.out;
   h.N = a.N; h.H = a.H; h.W = a.W; h.Cin = a.C0; h.Cout = a.Cout; h.relu_in = a.relu_in; h.relu_out = a.relu_out;
   h.out_cstride = a.out_cstride; h.out_coff = a.out_coff; h.out_split = a.out_split; h.out_gap = a.out_gap;
-  // the strip-walking LDS-DMA form (head_conv_strip.h, r05) where it takes the shape; FISR_DIAG builds: FISR_HEAD_STRIP=0 | 1 forces one
-  if (head_strip_enabled() && head_strip_fits(a.H, a.W, a.C0)) return launch_head_strip(h, st);
+#ifdef FISR_DIAG
+  if (head_strip_enabled() && head_strip_fits(a.H, a.W, a.C0)) return launch_head_strip(h, st);      // (A/B runs: diag/head_conv_strip.h)
+#endif
   const int tiles = ((a.W + TILE_W - 1) / TILE_W) * ((a.H + HEAD_TH - 1) / HEAD_TH) * a.N;
   if (a.Cout <= 4) hipLaunchKernelGGL(head_conv_f32_kernel<2>, dim3(tiles), dim3(HEAD_NTHR), head_lds_bytes<2>(), st, h);
   else hipLaunchKernelGGL(head_conv_f32_kernel<3>, dim3(tiles), dim3(HEAD_NTHR), head_lds_bytes<3>(), st, h);
@@ -648,7 +649,13 @@ hipError_t launch_conv_dma(const ConvArgs& a, hipStream_t st, int nt = 2) {
 
 // The persistent f16f8 LDS-DMA kernel (conv3x3_dma_fs.h; a.wpk = the conv's d_wd, a.CoutPad = Cout).  Pooling with relu-on-load is
 // not instantiated (no layer asks for it): the callers keep that combination on the direct kernel.
-inline bool dmafs_takes(const ConvArgs& a) { return !(a.pool_out && a.relu_in) && !(a.pool_out && !a.res); }
+// The kernel reads dense tensors (pixel stride == channel count), has no dilation / leaky relu / channel-range or scattered store, and
+// with depth_to_space it stores in the shuffled layout while a residual would be read in the plain one: all of that is refused here,
+// so such a call falls back to the direct kernel (Runner::conv, op level) instead of computing something else.
+inline bool dmafs_takes(const ConvArgs& a) {
+  return !(a.pool_out && a.relu_in) && !(a.pool_out && !a.res) && a.dil == 1 && a.slope == 0.f && a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) &&
+         a.rec_cs == a.Cout && a.rec_co == 0 && a.out_cstride == a.Cout && a.out_coff == 0 && a.out_split >= a.Cout && !(a.d2s && a.res);
+}
 // Tile width: 32 for the layers with one 64-channel output block (their half-line re-visits must survive in L2: conv3x3_dma_fs.h), else 64.
 // (FISR_DIAG builds: FISR_FS_TW=32|64 forces one for A/B runs.)
 inline int dmafs_tile_w(const ConvArgs& a) {
@@ -1258,6 +1265,13 @@ int fisr_num_variables_set(const fisr_ctx* ctx) {
 int fisr_finalize_weights(fisr_ctx* ctx, int precision) {
   if (!ctx) return fail(nullptr, FISR_EINVAL, "fisr_finalize_weights: ctx is NULL");
   if (!prec_ok(precision) && precision != FISR_PREC_MIXED && precision != FISR_PREC_MIXEDR) return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: unknown precision");
+#ifndef FISR_DIAG
+  // The A/B engines (superseded kernels everywhere) exist in diagnostics builds only; their ids stay valid at op level, where
+  // they name a kernel the product still runs on the layers its successors do not take.
+  if (precision == FISR_PREC_F32W || precision == FISR_PREC_F16R || precision == FISR_PREC_F16F8R || precision == FISR_PREC_MIXEDR)
+    return fail(ctx, FISR_EINVAL, "fisr_finalize_weights: FISR_PREC_F32W / F16R / F16F8R / MIXEDR are A/B engines of the diagnostics build (-DFISR_DIAG); "
+                                  "the shipped engines are FISR_PREC_F32W4, F32, BF16X3, F16F8, F16, MIXED");
+#endif
   for (auto& s : all_specs()) {
     const ConvW& cw = ctx->convs[s.name];
     if (!cw.have_w) return fail(ctx, FISR_EMISSING, "missing variable " + s.name + "/w");
@@ -1539,7 +1553,7 @@ static int op_conv3x3_impl(const void* in0, int c0, const void* in1, int c1, con
   const bool use_dma = precision == FISR_PREC_F16 && cw.d_wd && !out_f32 && dma_fits(h, w, c0, c1, c0, c1);
   // (FISR_PREC_F16F8: the persistent LDS-DMA kernel wherever it has an instantiation)
   bool use_dmafs = precision == FISR_PREC_F16F8 && cw.d_wd && !out_f32 && dmafs_fits(h, w, c0, c1, cout) &&
-                   !(pool_out && ((flags & FISR_CONV_RELU_IN) || !res));
+                   !(pool_out && ((flags & FISR_CONV_RELU_IN) || !res)) && !((flags & FISR_CONV_D2S) && res);
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.wpk = use_dma || use_dmafs ? cw.d_wd : use_wf4 ? cw.d_wu4 : (use_wino ? cw.d_wu : cw.d_w); a.bias = cw.d_b; a.res = res; a.out = out;
   a.C0 = c0; a.C1 = c1; a.N = n; a.H = h; a.W = w; a.Cout = cout; a.CoutPad = use_dma || use_dmafs ? cw.cout_pad_d : cw.cout_pad;
@@ -1683,9 +1697,11 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
                          : use_wf4 ? (size_t)(((w + F4_TW - 1) / F4_TW) * ((h + F4_TH - 1) / F4_TH) * n) * (cw.cout_pad / F4_BN)
                                  : (size_t)(((w + TILE_W - 1) / TILE_W) * ((h + TILE_H - 1) / TILE_H) * n) *
                                        (use_wino ? cw.cout_pad / W_BN : cw.cout_pad / (cw.nt ? 32 * cw.nt : 16));
+  // (conv3x3_dma_fs.h writes FS_TRACE_WORDS words per workgroup -- its grid is at most 2 workgroups per CU --, the other kernels 8)
+  const size_t trace_rec = use_dmafs ? (size_t)FS_TRACE_WORDS * 8 : 64;
   if (trace_file) {
-    HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * 64));
-    HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * 64));
+    HIP_OK(nullptr, hipMalloc((void**)&d_trace, nblocks * trace_rec));
+    HIP_OK(nullptr, hipMemset(d_trace, 0, nblocks * trace_rec));
     a.trace = d_trace;
   }
   hipEvent_t e0, e1;
@@ -1709,8 +1725,8 @@ static int bench_conv_impl(int precision, int n, int h, int w, int cin, int cout
   HIP_OK(nullptr, hipEventElapsedTime(&ms, e0, e1));
   *out_us = (double)ms * 1e3 / iters;
   if (trace_file) {
-    std::vector<unsigned long long> tr(nblocks * 8);
-    HIP_OK(nullptr, hipMemcpy(tr.data(), d_trace, nblocks * 64, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tr(nblocks * trace_rec / 8);
+    HIP_OK(nullptr, hipMemcpy(tr.data(), d_trace, nblocks * trace_rec, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(trace_file, "wb")) { fwrite(tr.data(), 8, tr.size(), f); fclose(f); }
     (void)hipFree(d_trace);
   }

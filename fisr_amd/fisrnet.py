@@ -43,7 +43,10 @@ _PREC = {"fp32": _lib.PREC_F32W4, "f32": _lib.PREC_F32W4, "float32": _lib.PREC_F
 # ONE default arithmetic for every entry point (FISRnet(), main.py, bench.py): the reference computes in
 # fp32 (cfg2 of BASELINE.json), so the default is the fp32 engine; the split-precision modes are opt-in.
 DEFAULT_PRECISION = "fp32"
-PRECISIONS = ("fp32", "fp32w4", "fp32w", "fp32d", "bf16x3", "f16f8", "mixed", "fp16", "fp16r", "mixedr", "f16f8r")     # CLI names
+PRECISIONS = ("fp32", "fp32w4", "fp32d", "bf16x3", "f16f8", "mixed", "fp16")     # CLI names: the shipped engines ("fp32d": the exact direct-conv reference)
+# A/B engines of the diagnostics build (lib.build(diag=True), loaded through FISR_HIP_SO): superseded kernels everywhere.  The product
+# library refuses them in fisr_finalize_weights (FISR_EINVAL); FISRnet(precision=...) still maps the names for those runs.
+DIAG_PRECISIONS = ("fp32w", "fp16r", "mixedr", "f16f8r")
 
 
 def _torch():

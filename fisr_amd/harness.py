@@ -203,6 +203,12 @@ def prepare_scene_set(net, args, ss: int = 1, data_path=None, flow_path=None, wa
     data_path = data_path or net.test_data_path
     flow_path = flow_path or (net.test_flow_data_path if ss == 1 else net.test_flow_data_path.replace("ss1", "ss2"))
     warp_path = warp_path or (net.test_warped_data_path if ss == 1 else net.test_warped_data_path.replace("ss1", "ss2"))
+    if ss == 2 and write and (os.path.abspath(flow_path) == os.path.abspath(net.test_flow_data_path) or
+                              os.path.abspath(warp_path) == os.path.abspath(net.test_warped_data_path)):
+        # the derived name only differs from the ss1 file when that one carries "ss1": never overwrite the stride-1 files with
+        # [N, 4, ...] stride-2 data that `--phase test` would then index as stride 1
+        raise ValueError(f"--prepare_ss 2: the stride-2 file names are derived by 'ss1' -> 'ss2', but {net.test_flow_data_path!r} / "
+                         f"{net.test_warped_data_path!r} do not contain 'ss1'; pass flow_path= / warp_path= (or rename the ss1 files)")
     paths = sorted_pngs(data_path)
     n_scenes = len(paths) // n_seq
     if n_scenes == 0:
@@ -238,6 +244,14 @@ def prepare_scene_set(net, args, ss: int = 1, data_path=None, flow_path=None, wa
             writer(arr, tmp)
             os.replace(tmp, name)
     return flow, warp, flow_path, warp_path
+
+
+def _pwc_available(args) -> bool:
+    """open_pwc's precondition without opening anything: seeded stand-ins asked for, or a checkpoint (TF bundle prefix / .npz) present"""
+    if getattr(args, "synthetic_weights", None) is not None:
+        return True
+    ck = getattr(args, "pwc_ckpt", None)
+    return bool(ck) and (os.path.isfile(ck) or os.path.isfile(ck + ".index"))
 
 
 def _pad_mode(net) -> bool:
@@ -286,17 +300,43 @@ def run_test(net):
     data_paths = sorted_pngs(net.test_data_path)
     label_paths = sorted_pngs(net.test_label_path)
     prepare = getattr(net.args, "prepare", "auto")
-    neither = not os.path.isfile(net.test_flow_data_path) and not os.path.isfile(net.test_warped_data_path)
-    if prepare == "always" or (prepare == "auto" and neither):
+    have_flo, have_mat = os.path.isfile(net.test_flow_data_path), os.path.isfile(net.test_warped_data_path)
+    if prepare == "auto" and have_flo != have_mat:
+        # one of the two pre-made files without the other: they are made together (the warps FROM the flows), so say which is missing
+        raise FileNotFoundError(f"only one of the pre-made files exists: {net.test_flow_data_path!r} ({'found' if have_flo else 'MISSING'}), "
+                                f"{net.test_warped_data_path!r} ({'found' if have_mat else 'MISSING'}); remove the other or pass --prepare always "
+                                "to make both again on the GPU")
+    if prepare == "auto" and not have_flo and not _pwc_available(net.args):
+        # auto mode would open PWC-Net: without its weights the missing FILES are the error to name (as the reference's reader would)
+        raise FileNotFoundError(f"{net.test_flow_data_path!r} and {net.test_warped_data_path!r} not found, and no PWC-Net weights to make them "
+                                "(--pwc_ckpt / --synthetic_weights); run the pre-processing first or pass --prepare always with weights")
+    if prepare == "always" or (prepare == "auto" and not have_flo):
         # neither pre-made file exists (or --prepare always): make both on the GPU from the scene folder, as the reference's two
-        # pre-processing scripts do, and continue with the arrays that were written
-        print(" Start to make flow and warped data (test) on the GPU.")
-        flow, warp, _, _ = prepare_scene_set(net, net.args, ss=1)
+        # pre-processing scripts do, and continue with the arrays that were written.  Under torchrun rank 0 makes the files, the
+        # others wait and read them (one PWC-Net pass over the scene set instead of world-size identical ones).
+        rank, world = _dist_state()
+        if world > 1:
+            import torch.distributed as dist
+            if rank == 0:
+                print(" Start to make flow and warped data (test) on the GPU.")
+                prepare_scene_set(net, net.args, ss=1)
+            dist.barrier()
+            flow = fio.read_flo_file_5dim(net.test_flow_data_path)
+            warp = fio.read_warp_file(net.test_warped_data_path, "pred")
+        else:
+            print(" Start to make flow and warped data (test) on the GPU.")
+            flow, warp, _, _ = prepare_scene_set(net, net.args, ss=1)
     else:
         print(" Start to read flow data (test).")
         flow = fio.read_flo_file_5dim(net.test_flow_data_path)        # [N_scenes, 8, H, W, 2]
         print(" Start to read warped data (test).")
         warp = fio.read_warp_file(net.test_warped_data_path, "pred")  # [N_scenes, 8, H, W, 3] 0..255
+    if flow.ndim != 5 or flow.shape[1] != 8 or warp.shape[1] != 8:
+        raise ValueError(f"{net.test_flow_data_path!r} / {net.test_warped_data_path!r}: expected [N_scenes, 8, H, W, 2 | 3] (temporal stride 1, "
+                         f"main.py:36-44), got {tuple(flow.shape)} / {tuple(warp.shape)} -- stride-2 (ss2) files have 4 entries per scene")
+    if flow.ndim != 5 or flow.shape[1] != 8 or warp.shape[1] != 8:
+        raise ValueError(f"{net.test_flow_data_path!r} / {net.test_warped_data_path!r}: expected [N_scenes, 8, H, W, 2 | 3] (temporal stride 1, "
+                         f"main.py:36-44), got {tuple(flow.shape)} / {tuple(warp.shape)} -- stride-2 (ss2) files have 4 entries per scene")
     num_patch = tuple(net.test_patch)
     H, W = net.test_input_size
     sf = net.scale_factor
@@ -357,7 +397,6 @@ def run_test(net):
     print("######### Test (average) test_SSIM: FISR %.8f, SR %.8f #########" % (res["FISR_SSIM"], res["SR_SSIM"]))
     print("######### (extra) Y-channel-only test_PSNR: FISR %.8f[dB], SR %.8f[dB]  #########" % (res["FISR_PSNR_Y"], res["SR_PSNR_Y"]))
     print("######### Estimated Inference Time (per one output 4K frame): %.8f[s]  #########" % res["inference_time_per_frame"])
-    print("          (timed: a tile's share of one fisr_forward_frames call = input assembly + forward of up to 16 tiles; the reference times sess.run of one tile, FISRnet.py:868-874)")
     # (what is timed differs from the reference's sess.run of ONE tile, FISRnet.py:868-874: here a tile's share of one batched
     #  fisr_forward_frames call -- input assembly, tile cut and level inputs included -- times the tiles of a frame)
     res["inference_time_is"] = "tile's share of a batched fisr_forward_frames call (input assembly included) x tiles per frame"

@@ -46,7 +46,13 @@ enum {
   FISR_ENOMEM = -5    /* workspace too small */
 };
 
-/* Arithmetic the conv kernels compute in (activations are stored in the same type). */
+/* Arithmetic the conv kernels compute in (activations are stored in the same type).
+ * ENGINES a caller selects with fisr_finalize_weights: FISR_PREC_F32W4 (fp32, the default engine), FISR_PREC_F32 (fp32, every conv on
+ * the direct kernel: the exact reference), FISR_PREC_BF16X3, FISR_PREC_F16F8, FISR_PREC_F16, FISR_PREC_MIXED.
+ * DIAGNOSTICS ids -- FISR_PREC_F32W as an engine, FISR_PREC_F16R, FISR_PREC_F16F8R, FISR_PREC_MIXEDR: A/B engines that run a superseded
+ * kernel everywhere.  fisr_finalize_weights refuses them (FISR_EINVAL) unless the library is a -DFISR_DIAG build (fisr_version() then
+ * ends in "DIAG").  At OP level (fisr_op_conv3x3 ...) the same ids stay valid: there they name a kernel the product still ships for
+ * the layers its successors do not take (F(2x2) on small maps; the register-staged direct kernel for heads and narrow layers). */
 enum {
   FISR_PREC_F32 = 0, /* fp32 activations/weights, v_mfma_f32_32x32x2_f32 (exact fp32, fmaf chain) */
   FISR_PREC_F16 = 1, /* fp16 activations/weights, v_mfma_f32_32x32x16_f16, fp32 accumulate */
@@ -60,7 +66,9 @@ enum {
                          v_mfma_f32_32x32x2_f32 with fp32 accumulation, 16 instead of 36 multiplies per 2x2 outputs --
                          the algorithm cuDNN uses for fp32 3x3 convolutions under the reference's TF 1.13; the rest
                          (3/6-channel heads) use the direct kernel.  Results differ from FISR_PREC_F32 by fp32
-                         rounding only (different summation order). */
+                         rounding only (different summation order).  As an ENGINE (F(2x2) on every map: round 2's headline) it is
+                         a DIAGNOSTICS id since r06 (-DFISR_DIAG builds); at op level it names the F(2x2) kernel, which the
+                         FISR_PREC_F32W4 engine runs on the small maps, and fisr_pwc_finalize_precision accepts it. */
   FISR_PREC_MIXED = 5, /* engine only (fisr_finalize_weights; not an op-level precision): FISR_PREC_F16 everywhere
                           except at the full and the half resolution of level 3 -- its first two encoder levels, its last
                           two decoder levels and both heads --, which keep a split format (FISR_PREC_F16F8).  The
@@ -75,10 +83,10 @@ enum {
                           relative per product at 2.1 instead of 3 MFMA-units (fp32 accumulate).  Values beyond
                           the fp16 range saturate to +-65504 when stored (no inf).  r05: the convolutions with Cout % 64 == 0
                           run on the persistent LDS-DMA kernel (conv3x3_dma_fs.h: same products, another summation order). */
-  FISR_PREC_F16R = 6,  /* FISR_PREC_F16 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h);
+  FISR_PREC_F16R = 6,  /* DIAGNOSTICS (engine: -DFISR_DIAG builds only).  FISR_PREC_F16 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h);
                           FISR_PREC_F16 itself runs the convolutions with Cout > 32 on the LDS-DMA kernel (conv3x3_dma.h: same
                           products, another summation order inside a chunk -> results agree to fp32 rounding).  For A/B runs. */
-  FISR_PREC_MIXEDR = 7, /* engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
+  FISR_PREC_MIXEDR = 7, /* DIAGNOSTICS (-DFISR_DIAG builds only).  Engine only: FISR_PREC_MIXED with FISR_PREC_F16R for its fp16 stages (A/B runs) */
   FISR_PREC_F32W4 = 8, /* fp32 activations/weights and arithmetic like FISR_PREC_F32W, with Winograd F(4x4,3x3) (conv3x3_wf4.h: 36
                           multiplies per 4x4 outputs on v_mfma_f32_16x16x4_f32, a quarter of the direct algorithm's) for the
                           convolutions with Cout % 64 == 0 on maps of at least 48 x 64 pixels and on 512-channel maps (op level: on
@@ -86,7 +94,7 @@ enum {
                           is a second store of that level's last convolution.  The F(4,3) transforms are worse conditioned: ~2e-5
                           instead of ~2e-6 per convolution against float64 -- through the network it does not add up (1.5e-6 on the
                           full tile, the F(2x2) engine's figure).  What fisrnet.py's "fp32" selects since round 3. */
-  FISR_PREC_F16F8R = 9 /* FISR_PREC_F16F8 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h).
+  FISR_PREC_F16F8R = 9 /* DIAGNOSTICS (engine: -DFISR_DIAG builds only).  FISR_PREC_F16F8 arithmetic and tensors on round 1's register-staged direct kernel everywhere (conv3x3.h).
                           For A/B runs, as FISR_PREC_F16R is for fp16. */
 };
 

@@ -3,7 +3,7 @@
 # gpurun_out/prof_*; copy what should be judged into profiles/.
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 PREC="${PREC:-fp32}"
-OTHERS="${OTHERS:-fp32w,fp32d,bf16x3,f16f8,mixed}"     # every engine in one run: one pmc_traffic.json for all kernel names; OTHERS=none: the engine
+OTHERS="${OTHERS:-fp32d,bf16x3,f16f8,mixed}"     # every engine in one run: one pmc_traffic.json for all kernel names; OTHERS=none: the engine
                                                       # alone (-> profiles/pmc_traffic_<engine>.json: `mixed` shares kernel names with f16f8 / fp16)
 OUT="$REPO/gpurun_out/prof_${PREC}"
 mkdir -p "$OUT"

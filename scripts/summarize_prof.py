@@ -98,17 +98,27 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
         except sqlite3.Error:
             continue
     agg = defaultdict(dict)
-    for n, cn, c, s_, _ in rows:
-        agg[short(n)][cn] = (c, s_)
+    for n, cn, c, s_, dsum in rows:
+        agg[short(n)][cn] = (c, s_, dsum)
     for k, d in agg.items():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"][1] > 0:
             e = out.setdefault(k, {"dispatches": d["GRBM_GUI_ACTIVE"][0]})
             e["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"][1] / (1024.0 * d["GRBM_GUI_ACTIVE"][1] / 8.0)
             e["gui_active_cycles_per_launch"] = d["GRBM_GUI_ACTIVE"][1] / max(d["GRBM_GUI_ACTIVE"][0], 1)
-            if k in durations:
-                e["shader_clock_mhz"] = e["gui_active_cycles_per_launch"] / (durations[k][1] / 1e3)
             if "SQ_INSTS_VALU" in d:      # a wave64 vector instruction holds its SIMD's vector ALU for 4 cycles (packed fp32 included)
                 e["valu_issue_frac"] = 4.0 * d["SQ_INSTS_VALU"][1] / (1024.0 * d["GRBM_GUI_ACTIVE"][1] / 8.0)
+            # shader clock while the kernel ran: cycles and duration OF THE SAME PASS (r06: cycles of the counter pass over durations
+            # of the trace pass gave 3.4 - 5.7 GHz on short kernels).  GRBM_GUI_ACTIVE also counts the dispatch's ramp-up and drain,
+            # which a 20-us kernel does not amortise: a clock outside 0.5 - 2.5 GHz cannot be true -- the row's cycle-derived columns
+            # are nulled instead of published (tests/test_host.py checks the committed tables).
+            dsum = d["GRBM_GUI_ACTIVE"][2]
+            clk = e["gui_active_cycles_per_launch"] / (dsum / max(d["GRBM_GUI_ACTIVE"][0], 1) / 1e3) if dsum else None
+            e["shader_clock_mhz"] = clk
+            if clk is None or not (500.0 <= clk <= 2500.0):
+                e["shader_clock_mhz"] = None
+                e["cycle_columns_nulled"] = "no same-pass duration" if clk is None else f"derived clock {clk:.0f} MHz outside 500-2500"
+                e["mfma_busy_frac"] = None
+                e["valu_issue_frac"] = None
 # ---- which run this is: the library string (it carries the sha256 of csrc/ + include/fisr.h) and the number of steps, read from the
 # bench line of the trace pass -- bench.py drops counter-derived fields whose run is not the running library's, or whose launch
 # population (dispatches per step) is not the one it sees

@@ -112,7 +112,9 @@ def test_fp16_engine_runs_the_dma_kernel_and_matches_the_register_staged_engine(
     W = weights.synthetic_weights(2020)
     x = torch.from_numpy(make_full_size_input(21, 96, 160, 2)).cuda()
     outs, prof = {}, {}
-    for prec in ("fp32", "fp16", "fp16r"):
+    # (the register-staged engine is an A/B engine of the diagnostics build since r06: compared only when that library is loaded)
+    diag = b"DIAG" in flib.lib().fisr_version()
+    for prec in ("fp32", "fp16") + (("fp16r",) if diag else ()):
         net = FISRnet(device="cuda:0", precision=prec)
         net.set_weights(W)
         net.profile(1)
@@ -120,10 +122,13 @@ def test_fp16_engine_runs_the_dma_kernel_and_matches_the_register_staged_engine(
         torch.cuda.synchronize()
         prof[prec] = {p["name"]: p["launches"] for p in net.profile_read()}
         net.close()
-    assert prof["fp16"].get("conv3x3_dma<f16>", 0) == 132 and "conv3x3_dma<f16>" not in prof["fp16r"]
+    assert prof["fp16"].get("conv3x3_dma<f16>", 0) == 132 and (not diag or "conv3x3_dma<f16>" not in prof["fp16r"])
     for k, name in enumerate(("pred_l1", "pred_l2", "pred_l3")):
-        d_old = np.abs(outs["fp16"][k] - outs["fp16r"][k])
         d_32 = np.sqrt(((outs["fp16"][k] - outs["fp32"][k]) ** 2).mean())
-        d_32r = np.sqrt(((outs["fp16r"][k] - outs["fp32"][k]) ** 2).mean())
-        print(f"{name}: |dma - register-staged| max {d_old.max():.2e}; rms vs fp32: dma {d_32:.2e}, register-staged {d_32r:.2e}")
-        assert d_32 < 1.3 * d_32r + 1e-5          # the same rounding noise as the old kernel's, not more
+        print(f"{name}: rms vs fp32: dma {d_32:.2e}")
+        assert d_32 < 8e-4                        # fp16's rounding noise on this network (measured 2e-4 .. 4e-4), not a wrong tap (>= 1e-2)
+        if diag:
+            d_old = np.abs(outs["fp16"][k] - outs["fp16r"][k])
+            d_32r = np.sqrt(((outs["fp16r"][k] - outs["fp32"][k]) ** 2).mean())
+            print(f"{name}: |dma - register-staged| max {d_old.max():.2e}; rms vs fp32: register-staged {d_32r:.2e}")
+            assert d_32 < 1.3 * d_32r + 1e-5      # the same rounding noise as the old kernel's, not more

@@ -163,7 +163,9 @@ def test_f16f8_engine_runs_the_dma_kernel_and_matches_the_register_staged_engine
     W = weights.synthetic_weights(2020)
     x = torch.from_numpy(make_full_size_input(21, 96, 160, 2)).cuda()
     outs, prof = {}, {}
-    for prec in ("fp32", "f16f8", "f16f8r"):
+    # (the register-staged engine is an A/B engine of the diagnostics build since r06: compared only when that library is loaded)
+    diag = b"DIAG" in flib.lib().fisr_version()
+    for prec in ("fp32", "f16f8") + (("f16f8r",) if diag else ()):
         net = FISRnet(device="cuda:0", precision=prec)
         net.set_weights(W)
         net.profile(1)
@@ -172,10 +174,13 @@ def test_f16f8_engine_runs_the_dma_kernel_and_matches_the_register_staged_engine
         prof[prec] = {p["name"]: p["launches"] for p in net.profile_read()}
         net.close()
     n_new = sum(v for k, v in prof["f16f8"].items() if k.startswith("conv3x3_dma_fs<"))
-    assert n_new == 132 and not any(k.startswith("conv3x3_dma_fs<") for k in prof["f16f8r"]), prof["f16f8"]
+    assert n_new == 132 and (not diag or not any(k.startswith("conv3x3_dma_fs<") for k in prof["f16f8r"])), prof["f16f8"]
     for k, name in enumerate(("pred_l1", "pred_l2", "pred_l3")):
-        d_old = np.abs(outs["f16f8"][k] - outs["f16f8r"][k])
         d_32 = np.sqrt(((outs["f16f8"][k] - outs["fp32"][k]) ** 2).mean())
-        d_32r = np.sqrt(((outs["f16f8r"][k] - outs["fp32"][k]) ** 2).mean())
-        print(f"{name}: |dma - register-staged| max {d_old.max():.2e}; rms vs fp32: dma {d_32:.2e}, register-staged {d_32r:.2e}")
-        assert d_32 < 1.3 * d_32r + 2e-6
+        print(f"{name}: rms vs fp32: dma {d_32:.2e}")
+        assert d_32 < 4e-5                        # the split format's noise on this network (measured ~1e-5)
+        if diag:
+            d_old = np.abs(outs["f16f8"][k] - outs["f16f8r"][k])
+            d_32r = np.sqrt(((outs["f16f8r"][k] - outs["fp32"][k]) ** 2).mean())
+            print(f"{name}: |dma - register-staged| max {d_old.max():.2e}; rms vs fp32: register-staged {d_32r:.2e}")
+            assert d_32 < 1.3 * d_32r + 2e-6

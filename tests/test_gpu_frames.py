@@ -145,10 +145,14 @@ def test_level3_input_of_the_fused_kernel_vs_oracle_assembly(dev, syn_weights):
         net.close()
 
 
-def test_forward_frames_full_size_stack_bit_identical(dev, syn_weights):
+@pytest.mark.parametrize("precision", ["f16f8", "fp32", "mixed"])
+def test_forward_frames_full_size_stack_bit_identical(dev, syn_weights, precision):
     """cfg2's own shape: 3 windows of 1080x1920 frames cropped to 1024x1920, 2x2 tiles of 544x992 -> the 12 items of one call (what
-    bench.py's step runs), f16f8 engine; and unpack_output writing into caller-owned slots."""
-    net = FISRnet(device="cuda:0", precision="f16f8")
+    bench.py's step runs) against pack_input -> 12-tile forward, bit for bit -- on f16f8 and, r06, on the engines that carry the
+    numbers (fp32: the headline; mixed: cfg5's); and unpack_output writing into caller-owned slots.  With
+    test_gpu_parity.py::test_full_size_batch_of_twelve_equals_single_tiles (12-tile forward == single tiles == the oracle's sparse
+    grid on tiles 0 and 11) this ties the schedule the bench times to the oracle."""
+    net = FISRnet(device="cuda:0", precision=precision)
     net.set_weights(syn_weights)
     try:
         h, w = 1024, 1920

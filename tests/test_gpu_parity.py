@@ -734,12 +734,12 @@ def test_forward_fp32_cfg1_96x96_windows(net32, gold_dir):
 
 def test_fp32_engine_runs_the_kernels_it_claims(dev, syn_weights):
     """Which kernel a conv runs on is decided per map (wf4_wins): on a 96 x 160 input the fp32 engine must run BOTH Winograd kernels
-    -- F(4x4) on the 96 x 160 / 48 x 80 maps, F(2x2) below --, 'fp32w' only the F(2x2) one, 'fp32d' neither; and the three engines
-    agree to fp32 rounding."""
+    -- F(4x4) on the 96 x 160 / 48 x 80 maps, F(2x2) below --, 'fp32d' neither; and the two engines agree to fp32 rounding.  ('fp32w',
+    the all-F(2x2) engine of round 2, is an A/B engine of the diagnostics build since r06: the product library refuses it.)"""
     x = np.random.default_rng(3).random((1, 96, 160, 29)).astype(np.float32)
     x[..., 9:17] = (x[..., 9:17] - 0.5) * 0.4
     outs = {}
-    for prec in ("fp32", "fp32w", "fp32d"):
+    for prec in ("fp32", "fp32d"):
         net = FISRnet(device="cuda:0", precision=prec)
         net.set_weights(syn_weights)
         net.profile(1)
@@ -751,7 +751,26 @@ def test_fp32_engine_runs_the_kernels_it_claims(dev, syn_weights):
         assert ("conv3x3_wf4" in names) == (prec == "fp32"), (prec, names)
         assert ("conv3x3_wino8p" in names) == (prec != "fp32d"), (prec, names)
     assert np.abs(outs["fp32"] - outs["fp32d"]).max() < 2e-5
-    assert np.abs(outs["fp32w"] - outs["fp32d"]).max() < 2e-5
+
+
+def test_product_library_refuses_the_ab_engines(dev, syn_weights):
+    """The A/B engines (superseded kernels everywhere: FISR_PREC_F32W, F16R, F16F8R, MIXEDR) exist in -DFISR_DIAG builds only: the
+    shipped library's fisr_finalize_weights returns FISR_EINVAL and says so; the shipped engines still finalize afterwards."""
+    L = flib.lib()
+    if b"DIAG" in L.fisr_version():
+        pytest.skip("diagnostics build loaded through FISR_HIP_SO")
+    net = FISRnet(device="cuda:0", precision="fp32")
+    try:
+        net.set_weights(syn_weights)           # (finalizes in fp32)
+        for pid in (flib.PREC_F32W, flib.PREC_F16R, flib.PREC_MIXEDR, flib.PREC_F16F8R):
+            assert L.fisr_finalize_weights(net._ctx, pid) == -1, pid
+            assert b"diagnostics build" in L.fisr_last_error(net._ctx)
+        assert L.fisr_finalize_weights(net._ctx, 99) == -1
+        assert L.fisr_finalize_weights(net._ctx, flib.PREC_F32W4) == 0
+    finally:
+        net.close()
+    from fisr_amd.fisrnet import DIAG_PRECISIONS, PRECISIONS
+    assert not set(DIAG_PRECISIONS) & set(PRECISIONS) and set(DIAG_PRECISIONS) == {"fp32w", "fp16r", "mixedr", "f16f8r"}
 
 
 def test_forward_fp32_winograd_vs_goldens(net32w, gold_dir, syn_blob):
@@ -1080,12 +1099,27 @@ def test_full_size_tile_sparse_golden(net32, gold_dir):
     _report(got, g["l3_sparse"], F32_FWD_TOL, "544x992 tile sparse grid")
 
 
-@pytest.mark.parametrize("engine", ["net32", "netx3"])
+@pytest.fixture(scope="module")
+def netmixed(dev, syn_weights):
+    n = FISRnet(device="cuda:0", precision="mixed")        # cfg5's network engine
+    n.set_weights(syn_weights)
+    yield n
+    n.close()
+
+
+# tile 0 / 11 against the fp64 oracle's sparse grid: the fp32 engines at the forward bound, bf16x3 at 5e-4, `mixed` (fp16 outside the
+# full / half resolution of level 3) at its 32 x 64 golden's bound for the level-3 prediction (test_forward_mixed_precision_vs_golden)
+_BATCH12_TOL = {"net32": F32_FWD_TOL, "net32w": F32_FWD_TOL, "netx3": 5e-4, "netmixed": 4e-3}
+
+
+@pytest.mark.parametrize("engine", ["net32", "net32w", "netx3", "netmixed"])
 def test_full_size_batch_of_twelve_equals_single_tiles(engine, request, gold_dir):
     """The bench's schedule (all 12 tiles of a 5-frame 1080p stack in one forward: activations of up to
     1.66e9 elements / 6.6e9 bytes) must give, tile for tile, exactly what the reference's one-tile-at-a-time
-    schedule gives -- the kernels' work order is batch-independent -- and tile 0 must match the oracle's
-    sparse golden grid.  Guards the 64-bit indexing at the largest sizes the path sees."""
+    schedule gives -- the kernels' work order is batch-independent -- and tiles 0 and 11 must match the oracle's
+    sparse golden grid.  Guards the 64-bit indexing at the largest sizes the path sees.  r06: also on the engines that carry the
+    numbers -- `net32w` = "fp32", the headline, and `mixed`, cfg5's; that the 12-ITEM fisr_forward_frames call bench.py times equals
+    this 12-tile forward bit for bit on the same engines is test_gpu_frames.py::test_forward_frames_full_size_stack_bit_identical."""
     net = request.getfixturevalue(engine)
     from tests_support import make_full_size_input
     g = np.load(os.path.join(gold_dir, "model_544x992_sparse.npz"))
@@ -1101,9 +1135,14 @@ def test_full_size_batch_of_twelve_equals_single_tiles(engine, request, gold_dir
         s1, s2, s3 = net.model(x[t:t + 1].contiguous())
         assert torch.equal(s3[0], l3[t]) and torch.equal(s2[0], l2[t]) and torch.equal(s1[0], l1[t]), f"tile {t}"
     st = int(g["stride"])
-    tol = F32_FWD_TOL if engine == "net32" else 5e-4
+    tol = _BATCH12_TOL[engine]
     for t in (0, 11):
-        _report(l3[t, ::st, ::st, :].cpu().numpy(), g["l3_sparse"], tol, f"batched tile {t} sparse grid")
+        got = l3[t, ::st, ::st, :].cpu().numpy()
+        err = np.abs(got.astype(np.float64) - g["l3_sparse"])
+        print(f"{engine} batched tile {t}: max {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}")
+        _report(got, g["l3_sparse"], tol, f"{engine} batched tile {t} sparse grid")
+        if engine == "netmixed":
+            assert np.sqrt((err ** 2).mean()) < tol / 8
     del l1, l2, l3, x
     torch.cuda.empty_cache()
 
