@@ -6,6 +6,8 @@
   prepare_scene_set   <-> the two pre-processing scripts that make `--phase test`'s inputs for a folder of 5-frame scenes:
                           FISR_tfoptflow/FISR_pwcnet_predict_from_img_test.py:84-147 (flow, [N_scenes, 8/ss, H, W, 2] .flo) and
                           FISR_tfoptflow/FISR_warp_mat_with_flo.py:95-129 (warped frames, [N_scenes, 8/ss, H, W, 3] HDF5 .mat)
+  prepare_patch_set   <-> the same two steps for the TRAINING set, from the `.mat` of LR patch sequences (r06):
+                          FISR_tfoptflow/FISR_pwcnet_predict_from_mat.py:80-133 and FISR_warp_mat_with_flo.py:95-129
 
 Everything between "frames are on the GPU" and "uint8 predictions come back" runs in
 libfisr_hip.so kernels (pack -> tiled forward -> stitch -> clip/quantise/colour -> SSE).  PNG
@@ -226,23 +228,107 @@ def prepare_scene_set(net, args, ss: int = 1, data_path=None, flow_path=None, wa
             frames = [torch.from_numpy(np.ascontiguousarray(fio.read_png(p)[:h, :w])).to(net.device) for p in scene[::ss]]
             if frames[0].shape[0] < h or frames[0].shape[1] < w:
                 raise ValueError(f"{scene[0]}: {tuple(frames[0].shape[:2])} is smaller than --test_input_size {h}x{w}")
-            f = pwc.compute_flow(frames[:len(pairs) + 1])                        # [pairs, 2, h, w, 2]: [seq, 0] = 1 -> 2, [seq, 1] = 2 -> 1
-            flow[num] = f.reshape(2 * len(pairs), h, w, 2).cpu().numpy()
-            for seq in range(len(pairs)):
-                warp[num, 2 * seq] = net.warp(frames[seq + 1], f[seq, 0]).cpu().numpy()
-                warp[num, 2 * seq + 1] = net.warp(frames[seq], f[seq, 1]).cpu().numpy()
+            flow[num], warp[num] = _flows_and_warps(net, pwc, frames[:len(pairs) + 1])
             print(num)                                                           # (script :139, warp script :125)
     finally:
         if own:
             pwc.close()
     print(flow.shape)
     if write:
-        for name, arr, writer in ((flow_path, flow, lambda a, fn: fio.write_flow(a, fn)), (warp_path, warp, lambda a, fn: fio.write_warp_file(fn, a))):
-            os.makedirs(os.path.dirname(os.path.abspath(name)), exist_ok=True)
-            root, ext = os.path.splitext(name)
-            tmp = root + ".tmp%d" % os.getpid() + ext                            # (the extension picks the container)
-            writer(arr, tmp)
-            os.replace(tmp, name)
+        _write_flow_and_warp(flow, warp, flow_path, warp_path)
+    return flow, warp, flow_path, warp_path
+
+
+def _flows_and_warps(net, pwc, frames):
+    """One sample of the two pre-processing scripts: `frames` = k + 1 consecutive (already temporally strided) YUV uint8 frames on the
+    device -> flow [2 k, h, w, 2] (entry 2 seq = frame seq -> seq + 1, entry 2 seq + 1 the reverse) and the warped middle frames
+    [2 k, h, w, 3] float32 0..255 (entry 2 seq = frame seq + 1 pulled back by half of flow 2 seq, entry 2 seq + 1 = frame seq by half of
+    flow 2 seq + 1) -- FISR_pwcnet_predict_from_{img_test,mat}.py and FISR_warp_mat_with_flo.py:115-124, both as numpy arrays."""
+    k = len(frames) - 1
+    h, w = frames[0].shape[:2]
+    f = pwc.compute_flow(frames)                                                 # [k, 2, h, w, 2]: [seq, 0] = 1 -> 2, [seq, 1] = 2 -> 1
+    warp = np.zeros((2 * k, h, w, 3), np.float32)
+    for seq in range(k):
+        warp[2 * seq] = net.warp(frames[seq + 1], f[seq, 0]).cpu().numpy()
+        warp[2 * seq + 1] = net.warp(frames[seq], f[seq, 1]).cpu().numpy()
+    return f.reshape(2 * k, h, w, 2).cpu().numpy(), warp
+
+
+def _write_flow_and_warp(flow, warp, flow_path, warp_path):
+    """`write_flow` (script :57-81) and the MATLAB-compatible `.mat` of hdf5storage (warp script :131-136; `.npy` by extension), each
+    through a per-process temporary name and an atomic rename."""
+    for name, arr, writer in ((flow_path, flow, lambda a, fn: fio.write_flow(a, fn)), (warp_path, warp, lambda a, fn: fio.write_warp_file(fn, a))):
+        os.makedirs(os.path.dirname(os.path.abspath(name)), exist_ok=True)
+        root, ext = os.path.splitext(name)
+        tmp = root + ".tmp%d" % os.getpid() + ext                            # (the extension picks the container)
+        writer(arr, tmp)
+        os.replace(tmp, name)
+
+
+def read_mat_frames(path, key="LR_data"):
+    """The 5-D frame arrays of the reference's pre-made `.mat` files (utils.py:29-43 / the scripts' read_mat_file): dataset
+    [N, N_seq, C, W, H] on disk -> uint8 [N, N_seq, H, W, C] (YUV 0..255; `.npy` / `.npz` hold [N, N_seq, H, W, C] directly)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        a = np.load(path)
+    elif ext == ".npz":
+        a = np.load(path)[key]
+    else:
+        try:
+            import h5py
+        except ImportError:
+            from . import hdf5_min
+            a = hdf5_min.read_dataset(path, key)
+        else:
+            with h5py.File(path, "r") as f:
+                a = np.array(f[key])
+        a = np.swapaxes(a, 2, 4)
+    if a.ndim != 5 or a.shape[4] != 3:
+        raise ValueError(f"{path}: expected [N, N_seq, H, W, 3] frames under {key!r}, got {a.shape}")
+    if a.dtype != np.uint8:
+        r = np.rint(a)
+        if float(np.abs(a - r).max()) > 1e-3 or r.min() < 0 or r.max() > 255:
+            raise ValueError(f"{path}: {key!r} is not 8-bit YUV data (the scripts cast the frames to uint8 for PWC-Net)")
+        a = r.astype(np.uint8)
+    return np.ascontiguousarray(a)
+
+
+def prepare_patch_set(net, args, ss: int = 1, data_path=None, flow_path=None, warp_path=None, key: str = "LR_data", pwc=None, write: bool = True):
+    """The reference's TRAINING-set pre-processing (r06), both scripts on the GPU, from the pre-made `.mat` of LR patch sequences:
+
+      flow  FISR_tfoptflow/FISR_pwcnet_predict_from_mat.py:80-133: `LR_data` [N, 5, h, w, 3] (YUV) -> per sample and frame pair
+            (ss seq, ss (seq + 1)) PWC-Net-large on the x2 up-resized RGB frames (`adapt_info` (1, 2 h, 2 w, 2)) in both directions,
+            resized back with anti-aliasing and halved -> float32 [N, 8 / ss, h, w, 2], written by `write_flow`;
+      warp  FISR_tfoptflow/FISR_warp_mat_with_flo.py:95-129: [N, 8 / ss, h, w, 3] float32 0..255, the MATLAB-compatible `.mat`
+            `FISRnet.train` reads (`--train_warped_data_path` / `--train_wapred_ss2_data_path`).
+
+    Paths default to `--train_data_path` and, per stride, `--train_flow_data_path` / `--train_flow_ss2_data_path` and
+    `--train_warped_data_path` / `--train_wapred_ss2_data_path` (main.py:30-44).  Returns (flow, warp, flow_path, warp_path)."""
+    import torch
+    if ss not in (1, 2):
+        raise ValueError("temporal stride ss must be 1 or 2")
+    data_path = data_path or args.train_data_path
+    flow_path = flow_path or (args.train_flow_data_path if ss == 1 else args.train_flow_ss2_data_path)
+    warp_path = warp_path or (args.train_warped_data_path if ss == 1 else args.train_wapred_ss2_data_path)
+    data = read_mat_frames(data_path, key)
+    n, n_seq, h, w, _ = data.shape
+    pairs = scene_set_pairs(n_seq, ss)
+    flow = np.zeros((n, 2 * len(pairs), h, w, 2), np.float32)                    # (script :117: 8 // ss entries for 5 frames)
+    warp = np.zeros((n, 2 * len(pairs), h, w, 3), np.float32)
+    own = pwc is None
+    if own:
+        pwc = open_pwc(net, args)
+    try:
+        for num in range(n):
+            frames = [torch.from_numpy(data[num, k]).to(net.device) for k in range(0, n_seq, ss)][:len(pairs) + 1]
+            flow[num], warp[num] = _flows_and_warps(net, pwc, frames)
+            print(num)
+    finally:
+        if own:
+            pwc.close()
+    print(flow.shape)
+    if write:
+        _write_flow_and_warp(flow, warp, flow_path, warp_path)
     return flow, warp, flow_path, warp_path
 
 

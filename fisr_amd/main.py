@@ -106,7 +106,8 @@ def parse_args(argv=None):
     p.add_argument("--prepare", type=str, default="auto", choices=["auto", "always", "never", "only"],
                    help="--phase test: make --test_flow_data_path / --test_warped_data_path from the scene folder --test_data_path on the "
                         "GPU (the reference's FISR_pwcnet_predict_from_img_test.py + FISR_warp_mat_with_flo.py): 'auto' = when neither "
-                        "file exists, 'always', 'never', 'only' = make the files (also the ss2 pair with --prepare_ss 2) and stop")
+                        "file exists, 'always', 'never', 'only' = make the files (also the ss2 pair with --prepare_ss 2) and stop; "
+                        "--phase train --prepare only: the TRAINING set's flow / warp files from --train_data_path's LR_data (r06)")
     p.add_argument("--prepare_ss", type=int, default=1, choices=[1, 2], help="temporal stride of --prepare only (ss1 / ss2 files)")
     p.add_argument("--pad_mode", action="store_true",
                    help="not in the reference (FISRnet.py:820-825 crops the frame to a multiple of 32 x patches: 1080 -> 1024 rows, a "
@@ -166,6 +167,19 @@ def main(argv=None):
         from . import train_harness
         if args.device is None:
             args.device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        if args.prepare == "only":
+            # the training set's pre-processing (FISR_pwcnet_predict_from_mat.py + FISR_warp_mat_with_flo.py): --train_data_path's
+            # LR_data -> the ss1 (or, --prepare_ss 2, the ss2) .flo / _warp.mat pair --phase train reads, on the GPU, and stop
+            from . import harness
+            from .fisrnet import FISRnet
+            net = FISRnet(args)
+            try:
+                _, _, fp, wp = harness.prepare_patch_set(net, args, ss=args.prepare_ss)
+            finally:
+                net.close()
+            print(" [*] Flow file saved: %s" % fp)
+            print(" [*] Warp file saved: %s" % wp)
+            return 0
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             import torch
             import torch.distributed as dist

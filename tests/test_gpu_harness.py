@@ -551,3 +551,83 @@ def _cli_list(r, out):
             "--test_flow_data_path", str(out / "flow" / "LR_set_test_ss1.flo"), "--test_warped_data_path", str(out / "warped" / "LR_set_test_ss1_warp.mat"),
             "--checkpoint_dir", str(r / "checkpoint_dir"), "--test_img_dir", str(out / "img"), "--text_dir", str(out / "text"),
             "--log_dir", str(out / "log"), "--test_patch", "2,2", "--test_input_size", f"{S3},{S3}", "--synthetic_weights", "7"]
+
+
+# ------------------------------------------------------------------------------------------------
+# r06: the TRAINING set's pre-processing from the `.mat` of LR patch sequences
+def _patch_set(tmp_path, n=3, seed=11):
+    """A stand-in for ./data/train/LR_LFR/LR_*_5seq.mat: `LR_data` [N, 5, 96, 96, 3] uint8 YUV patches with motion between the frames
+    (one blocky texture seen through shifting windows), stored as the reference's file is -- MATLAB v7.3 = HDF5, dims reversed."""
+    from fisr_amd import hdf5_min
+    from tests_support import make_flow_frames
+    rng = np.random.default_rng(seed)
+    data = np.zeros((n, 5, 96, 96, 3), np.uint8)
+    for i in range(n):
+        a, _ = make_flow_frames(seed + i, 160, 160)
+        for t in range(5):
+            dy, dx = 8 + int(rng.integers(-2, 3)) * t // 2, 8 + 2 * t
+            data[i, t] = a[dy:dy + 96, dx:dx + 96]
+    path = str(tmp_path / "LR_patches_5seq.mat")
+    hdf5_min.write_dataset(path, "LR_data", np.ascontiguousarray(np.swapaxes(data, 2, 4)), matlab=True)       # [N, N_seq, C, W, H] on disk (utils.py:29-43)
+    return data, path
+
+
+@pytest.mark.parametrize("ss", [1, 2])
+def test_prepare_patch_set_from_mat_round_trips_through_the_train_loader(tmp_path, ss, capsys):
+    """FISR_pwcnet_predict_from_mat.py:80-133 + FISR_warp_mat_with_flo.py:95-129 through `--phase train --prepare only`: LR_data
+    [N, 5, 96, 96, 3] -> [N, 8 / ss, 96, 96, 2] .flo and [N, 8 / ss, 96, 96, 3] warp .mat under the names --phase train reads, entry
+    [num, 2 seq + d] = the scripts' pair (frame ss seq, ss (seq + 1)) in direction d (recomputed pair by pair), the warps the
+    kernel's (and the oracle's remap on one entry), and train_harness.load_train_set reads the files back in the layout the
+    training graph takes (FISRnet.py:177-209)."""
+    from fisr_amd import harness, train_harness
+    from fisr_amd.fisrnet import FISRnet
+    data, mat = _patch_set(tmp_path)
+    n = data.shape[0]
+    back = harness.read_mat_frames(mat)
+    assert back.dtype == np.uint8 and np.array_equal(back, data)
+    cli = ["--phase", "train", "--prepare", "only", "--prepare_ss", str(ss), "--train_data_path", mat, "--synthetic_weights", "7",
+           "--train_flow_data_path", str(tmp_path / "flow" / "LR_ss1.flo"), "--train_flow_ss2_data_path", str(tmp_path / "flow" / "LR_ss2.flo"),
+           "--train_warped_data_path", str(tmp_path / "warped" / "LR_ss1_warp.mat"), "--train_wapred_ss2_data_path", str(tmp_path / "warped" / "LR_ss2_warp.mat")]
+    assert fmain.main(cli) == 0
+    out = capsys.readouterr().out
+    fp = str(tmp_path / "flow" / f"LR_ss{ss}.flo")
+    wp = str(tmp_path / "warped" / f"LR_ss{ss}_warp.mat")
+    assert "Flow file saved: " + fp in out and "Warp file saved: " + wp in out and os.path.isfile(fp) and os.path.isfile(wp)
+    other = 3 - ss
+    assert not os.path.exists(str(tmp_path / "flow" / f"LR_ss{other}.flo"))                 # only the asked-for stride is written
+    flow, warp = fio.read_flo_file_5dim(fp), fio.read_warp_file(wp, "pred")
+    n_ent = 8 // ss
+    assert flow.shape == (n, n_ent, 96, 96, 2) and warp.shape == (n, n_ent, 96, 96, 3) and flow.dtype == np.float32
+    assert 0.0 <= warp.min() and warp.max() <= 255.0 and np.isfinite(flow).all() and float(np.abs(flow).max()) > 0.5
+    args = fmain.parse_args(cli)
+    net = FISRnet(args)
+    pwc = harness.open_pwc(net, args)
+    try:
+        for num in (0, n - 1):
+            for seq, (a, b) in enumerate(harness.scene_set_pairs(5, ss)):
+                fa, fb = torch.from_numpy(data[num, a]).cuda(), torch.from_numpy(data[num, b]).cuda()
+                fab, fba = pwc.flow_pair(fa, fb)
+                assert float((fab.cpu() - torch.from_numpy(flow[num, 2 * seq])).abs().max()) < 2e-3
+                assert float((fba.cpu() - torch.from_numpy(flow[num, 2 * seq + 1])).abs().max()) < 2e-3
+                w12 = net.warp(fb, torch.from_numpy(flow[num, 2 * seq]).cuda()).cpu().numpy()
+                w21 = net.warp(fa, torch.from_numpy(flow[num, 2 * seq + 1]).cuda()).cpu().numpy()
+                assert np.array_equal(w12, warp[num, 2 * seq]) and np.array_equal(w21, warp[num, 2 * seq + 1])
+    finally:
+        pwc.close()
+        net.close()
+    ref = O.warp_frame(data[0, ss], flow[0, 0])
+    assert np.abs(ref.astype(np.float64) - warp[0, 0]).max() <= 3.1e-5
+    # the training loader's view of the files (both strides are needed there: make the other pair, then load)
+    assert fmain.main([c if c != str(ss) else str(other) for c in cli]) == 0
+    capsys.readouterr()
+    args.train_label_path = mat                                                               # (any [N, *, h, w, 3] array: only shapes are checked here)
+    real_read = train_harness.read_mat_5d
+    train_harness.read_mat_5d = lambda path, key: real_read(path, "LR_data")
+    try:
+        ts = train_harness.load_train_set(args)
+    finally:
+        train_harness.read_mat_5d = real_read
+    assert ts["data"].shape == (n, 96, 96, 15) and ts["flow"].shape == (n, 96, 96, 16) and ts["flow_ss2"].shape == (n, 96, 96, 8)
+    assert ts["warp"].shape == (n, 96, 96, 24) and ts["warp_ss2"].shape == (n, 96, 96, 12)
+    f1 = fio.read_flo_file_5dim(str(tmp_path / "flow" / "LR_ss1.flo"))
+    assert np.allclose(ts["flow"][0, :, :, 0:2], f1[0, 0] / 96 / 2) and np.allclose(ts["data"][0, :, :, 3:6], data[0, 1] / 255.0)
