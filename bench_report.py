@@ -281,7 +281,7 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
             e = pmc_entry(_pmc_key(name), name)
         except (KeyError, IndexError, ValueError):
             e = None
-        return None if e is None or field not in e else round(e[field] * scale, 4)
+        return None if e is None or e.get(field) is None else round(e[field] * scale, 4)      # (None: a row summarize_prof.py nulled)
 
     dom = max(convs, key=lambda p: p["ms"])
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -301,7 +301,7 @@ def roofline_pass(net, wl, precision, reps, layer_profile=None):
         if e and "hbm_bytes_per_launch" in e:
             rec["pmc_gb_per_launch"] = round(e["hbm_bytes_per_launch"] / 1e9, 4)
             rec["pmc_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / max(alg_bytes / launches, 1.0), 3)
-        if e and "valu_issue_frac" in e:      # (the heads: vector-ALU kernels -- their floor is this, not the bytes; profiles/r05_heads_pmc.txt)
+        if e and e.get("valu_issue_frac") is not None:      # (the heads: vector-ALU kernels -- their floor is this, not the bytes; profiles/r05_heads_pmc.txt)
             rec["pmc_valu_issue_frac"] = round(e["valu_issue_frac"], 3)
         hbm[name] = rec
 

@@ -126,6 +126,24 @@ def test_conv3x3_dma_f16f8_vs_oracle_and_vs_register_staged_kernel(shape):
         assert got.min() >= 0
 
 
+def test_conv3x3_f16f8_d2s_with_residual_falls_back_to_the_direct_kernel():
+    """depth_to_space + residual: the persistent kernel would read the residual in the plain layout while storing in the
+    shuffled one -- dmafs_takes() refuses it, so FISR_PREC_F16F8 runs the call on the direct kernel and must give, bit for bit, what
+    FISR_PREC_F16F8R (that kernel by name) gives, and the oracle's d2s(conv + res) to the format's tolerance."""
+    shape = (1, 16, 64, 64, 0, 256, flib.CONV_D2S | flib.CONV_RELU_OUT, True)
+    n, h, wd, c0, c1, cout, flags, _ = shape
+    rng = np.random.default_rng(41)
+    x0 = rng.standard_normal((n, h, wd, c0)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, c0, cout)) * np.sqrt(2.0 / (9 * c0))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    res = rng.standard_normal((n, h, wd, cout)).astype(np.float32)
+    got = _conv(flib.PREC_F16F8, x0, w, b, None, res, flags)
+    old = _conv(flib.PREC_F16F8R, x0, w, b, None, res, flags)
+    exp = _ref(x0, w, b, None, res, flags)
+    assert got.shape == (n, 2 * h, 2 * wd, cout // 4) and np.array_equal(got, old)
+    assert np.abs(got - exp).max() < 2.5e-4 * max(1.0, float(np.abs(exp).max()))
+
+
 def test_conv3x3_dma_f16f8_in_place_residual():
     """res_block conv/1 writes its result over its residual input (ops.py:43): every record is read before it is written."""
     rng = np.random.default_rng(3)

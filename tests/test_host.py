@@ -346,3 +346,45 @@ def test_bench_counter_fields_need_the_same_launch_population():
     assert "conv3x3_dma_f16_kernel<false, 2>".startswith(b._pmc_key("conv3x3_dma<f16>"))
     # an engine profiled alone has its own table (r05: `mixed` shares its kernel names with f16f8 / fp16)
     assert b._pmc_file("no_such_engine").endswith(os.path.join("profiles", "pmc_traffic.json"))
+
+
+def test_prepare_paths_are_refused_before_anything_is_overwritten(tmp_path):
+    """(a) `--prepare_ss 2` derives the stride-2 names by 'ss1' -> 'ss2' -- names without 'ss1' would make it overwrite the
+    stride-1 files with [N, 4, ...] data: refused before a frame is read; (b) `--phase test` in auto mode with neither pre-made file
+    and no PWC-Net weights names the missing FILES (not the estimator); (c) only one of the two files present is its own error.
+    All three are decided on the host before the GPU is touched, so a stand-in `net` will do."""
+    from types import SimpleNamespace
+    from fisr_amd import harness
+    flo, mat = str(tmp_path / "flow.flo"), str(tmp_path / "warp.mat")
+    args = SimpleNamespace(prepare="auto", pwc_ckpt=str(tmp_path / "nope" / "pwcnet.ckpt"), synthetic_weights=None)
+    net = SimpleNamespace(_finalized=True, args=args, test_data_path=str(tmp_path), test_label_path=str(tmp_path), test_flow_data_path=flo,
+                          test_warped_data_path=mat, test_input_size=(96, 96), test_patch=(1, 1), device="cuda:0")
+    with pytest.raises(ValueError, match="do not contain 'ss1'"):
+        harness.prepare_scene_set(net, args, ss=2)
+    with pytest.raises(FileNotFoundError, match="flow.flo.*warp.mat.*no PWC-Net weights"):
+        harness.run_test(net)
+    open(flo, "wb").close()
+    with pytest.raises(FileNotFoundError, match="only one of the pre-made files"):
+        harness.run_test(net)
+    assert not harness._pwc_available(args)
+    assert harness._pwc_available(SimpleNamespace(synthetic_weights=3, pwc_ckpt=None))
+
+
+def test_committed_pmc_tables_hold_no_impossible_clock():
+    """review r05, item 6: profiles/pmc_traffic*.json derive a shader clock per kernel; rows whose cycles and durations came from
+    different passes once read 3.4 - 5.7 GHz.  scripts/summarize_prof.py now nulls such rows: every clock in a committed table lies in
+    0.5 - 2.5 GHz or is null (with the reason beside it), and a null clock takes the cycle-derived columns with it."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "pmc_traffic*.json")))
+    assert files
+    for f in files:
+        for k, e in json.load(open(f)).items():
+            if k == "_meta" or "gui_active_cycles_per_launch" not in e:
+                continue
+            clk = e.get("shader_clock_mhz")
+            if clk is None:
+                assert e.get("cycle_columns_nulled") and e.get("mfma_busy_frac") is None, (f, k)
+            else:
+                assert 500.0 <= clk <= 2500.0, (f, k, clk)
