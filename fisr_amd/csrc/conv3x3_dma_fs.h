@@ -49,7 +49,17 @@ constexpr int FS_WM_BYTES = 9 * FS_BN * 32;                            // 18432:
 constexpr int FS_WX_BYTES = 4 * 4096 + 2048;                           // 18432: four tap pairs x 4 planes + tap 8 x 2 planes
 constexpr int FS_W_BYTES = FS_WM_BYTES + FS_WX_BYTES;                  // 36864
 constexpr int FS_W_COPIES = FS_W_BYTES / 1024;                         // 36: nine per wave
-constexpr size_t dmafs_lds_bytes(int tw) { return (size_t)fs_halo_bytes(tw) + FS_W_BYTES; }      // 79872 / 59392: two workgroups per CU
+// FISR_FS_HALO2 (r06, narrow tile only): TWO halo stages beside the one weight slab -- 2 x 22 528 + 36 864 = 81 920 B, exactly half of a
+// CU's LDS, so two workgroups per CU still fit.  The halo of chunk k + 1 (HBM) is requested BEFORE chunk k is multiplied and flies
+// under its MFMAs; only the weight slab (L2) is requested behind the barrier that releases it.  Same-box A/B (two alternating rounds):
+// 64 -> 64 @ 12 x 544 x 992 1449 -> 1407 / 1492 -> 1451 us, 48 -> 64 1121 -> 1084, 64 -> 64 @ 272 x 496 370 -> 355; `mixed` step 61.4 -> 60.8 ms
+// (113.9 -> 115.2 frames/s).  (One copy per MFMA block INSIDE the multiply phase was tried behind it and faulted; not pursued.)
+// -DFISR_FS_HALO2=0: the one-stage form, for A/B runs.
+#ifndef FISR_FS_HALO2
+#define FISR_FS_HALO2 1
+#endif
+constexpr bool fs_halo2(int tw) { return FISR_FS_HALO2 != 0 && tw == 32; }
+constexpr size_t dmafs_lds_bytes(int tw) { return (size_t)fs_halo_bytes(tw) * (fs_halo2(tw) ? 2 : 1) + FS_W_BYTES; }      // 79872 / 59392 (81920): two workgroups per CU
 
 #define FISR_FS_BEGIN(KEEP, LDS)   "s_mov_b32 %[" #KEEP "], m0\n\ts_mov_b32 m0, %[" #LDS "]\n\ts_nop 0\n\t"
 #define FISR_FS_COPY(OFF, RS, SO)  "buffer_load_dwordx4 %[" #OFF "], %[" #RS "], %[" #SO "] offen lds\n\t"
@@ -106,8 +116,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
   constexpr int NJ = TW / 32;                          // 32-channel output blocks of a wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [halo chunk][weight slab]
+  constexpr bool H2 = fs_halo2(TW);
   char* const sH = smem;
-  char* const sW = smem + FS_HALO_BYTES;
+  char* const sW = smem + FS_HALO_BYTES * (H2 ? 2 : 1);
+  int hst = 0;                                         // H2: byte offset of the halo stage the chunk being multiplied lives in
 
   asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1" ::: "memory");      // MODE.FP16_OVFL: the f16 / fp8 conversions saturate
   const int tid = threadIdx.x;
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
     }
   };
   // chunk kc of item `it` -> LDS (KEEP_GEOM: hoff_item describes `it`)
-  auto copy_chunk = [&](int kc, const Item& it) {
+  auto copy_chunk = [&](int kc, const Item& it, bool do_halo = true, bool do_w = true, int stage_off = 0) {
     const int nb = it.nb, nblk = it.nblk;
     const bool first = kc < nch0;
     const unsigned so = (unsigned)(first ? kc : kc - nch0) * (unsigned)FS_REC;
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
     } else {
       halo_geom(hoff, it);
     }
-    const unsigned lh = lds_h;
+    const unsigned lh = lds_h + (unsigned)stage_off;
+    if (do_halo) {
     // the wave's copies: NQ of them, or NQ - 1 for the waves behind the last partial round
     constexpr int LASTW = FS_HALO_COPIES - 4 * (NQ - 1);      // waves < LASTW issue NQ copies
 #define FISR_FS_H1(Q)  FISR_FS_COPY(o##Q, rs, so)
@@ -225,6 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
     }
 #undef FISR_FS_H1
 #undef FISR_FS_HN
+    }
+    if (!do_w) return;
     // weight slab: 36 linear copies of 1 KB, wave w takes copies w, w + 4, ... (nine each)
     unsigned sw = (unsigned)(((size_t)kc * nblocks + nblk) * FS_W_BYTES) + (unsigned)wave * 1024u;
     const unsigned lw = lds_w;
@@ -282,11 +297,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
   auto compute = [&]() {
     auto ld_h = [&](uint4 (&H)[6], int dx) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) H[r] = *reinterpret_cast<const uint4*>(a_main[dx] + r * (FS_HW * FS_REC));
+      for (int r = 0; r < 6; ++r) H[r] = *reinterpret_cast<const uint4*>(a_main[dx] + (H2 ? hst : 0) + r * (FS_HW * FS_REC));
     };
     auto ld_x = [&](uint4 (&X)[6], int dx) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) X[r] = *reinterpret_cast<const uint4*>(a_x[dx] + r * (FS_HW * FS_REC));
+      for (int r = 0; r < 6; ++r) X[r] = *reinterpret_cast<const uint4*>(a_x[dx] + (H2 ? hst : 0) + r * (FS_HW * FS_REC));
     };
     auto ld_bm = [&](uint4 (&B)[NJ], int tap) {
 #pragma unroll
@@ -535,6 +550,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
       if (p.trace) t1 = __builtin_readcyclecounter();
       copies_landed_barrier();            // this chunk has landed
       if (p.trace) { t2 = __builtin_readcyclecounter(); c_wait += t2 - t1; }
+      if constexpr (H2) {
+        // the next chunk's halo -> the other stage (last read a chunk ago: the barrier above lies behind those reads), before the MFMAs
+        if (kc + 1 < nch) copy_chunk(kc + 1, cur, true, false, hst ^ FS_HALO_BYTES);
+        else if (has_next) {
+          halo_geom(hoff_item, nxt);
+          copy_chunk(0, nxt, true, false, hst ^ FS_HALO_BYTES);
+        }
+      }
       // the wave that multiplies goes first on its SIMD: its partner (the CU's other workgroup) is then in its epilogue or its copy
       // phase -- vector and memory instructions that wait anyway.  `mixed` 111.2 -> 113.3 frames/s (two alternating rounds on one
       // box, priority 1 / 2 / 3 alike; the same on the fp16 kernel's K loop: nothing)
@@ -549,10 +572,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_fs_kernel(const ConvArgs p
       __builtin_amdgcn_s_barrier();       // everybody is done reading it
       asm volatile("" ::: "memory");
       if (p.trace) { t4 = __builtin_readcyclecounter(); c_bar += t4 - t3; }
-      if (kc + 1 < nch) copy_chunk(kc + 1, cur);
-      else if (has_next) {
-        if constexpr (KEEP_GEOM) halo_geom(hoff_item, nxt);
-        copy_chunk(0, nxt);
+      if constexpr (H2) {
+        if (kc + 1 < nch) copy_chunk(kc + 1, cur, false, true);
+        else if (has_next) copy_chunk(0, nxt, false, true);
+        hst ^= FS_HALO_BYTES;
+      } else {
+        if (kc + 1 < nch) copy_chunk(kc + 1, cur);
+        else if (has_next) {
+          if constexpr (KEEP_GEOM) halo_geom(hoff_item, nxt);
+          copy_chunk(0, nxt);
+        }
       }
       if (p.trace) c_issue += __builtin_readcyclecounter() - t4;
     }

@@ -656,14 +656,21 @@ inline bool dmafs_takes(const ConvArgs& a) {
   return !(a.pool_out && a.relu_in) && !(a.pool_out && !a.res) && a.dil == 1 && a.slope == 0.f && a.in0_cs == a.C0 && (a.C1 == 0 || a.in1_cs == a.C1) &&
          a.rec_cs == a.Cout && a.rec_co == 0 && a.out_cstride == a.Cout && a.out_coff == 0 && a.out_split >= a.Cout && !(a.d2s && a.res);
 }
-// Tile width: 32 for the layers with one 64-channel output block (their half-line re-visits must survive in L2: conv3x3_dma_fs.h), else 64.
-// (FISR_DIAG builds: FISR_FS_TW=32|64 forces one for A/B runs.)
+// Tile width: 32 everywhere since r06.  r05 kept the 8 x 64 tile for the layers with several 64-channel output blocks (half the fragment
+// reads per MFMA; their half-visited lines are shared between the blocks of a tile); with two halo stages (FISR_FS_HALO2, narrow tile only:
+// two wide stages do not fit beside a second workgroup) the narrow tile wins there too -- same box, micro-benchmark: 128->128 + residual
+// 1305 -> 1206 us, 64->256 + d2s 4715 -> 4619, 256->128 2027 -> 1936, 64->128 730 -> 650 (128->128 relu-on-load: 1200 -> 1258, the one loss);
+// `mixed` step 60.8 -> 59.9 ms, `f16f8` 84.7 -> 81.3 ms.  The wide instantiations are compiled into -DFISR_DIAG builds only
+// (FISR_FS_TW=64 forces them, =1 is r05's rule, =2 wide for relu-on-load multi-block layers only: no better than 32 everywhere).
 inline int dmafs_tile_w(const ConvArgs& a) {
 #ifdef FISR_DIAG
   static const int forced = [] { const char* e = getenv("FISR_FS_TW"); return e ? atoi(e) : 0; }();
   if (forced == 32 || forced == 64) return forced;
+  if (forced == 1) return a.Cout / FS_BN == 1 ? 32 : 64;
+  if (forced == 2) return (a.relu_in && !a.res && a.Cout / FS_BN >= 2) ? 64 : 32;
 #endif
-  return a.Cout / FS_BN == 1 ? 32 : 64;
+  (void)a;
+  return 32;
 }
 template <int TW>
 hipError_t launch_conv_dmafs_tw(const ConvArgs& a, hipStream_t st, int n_cu, bool set_attr) {
@@ -702,7 +709,11 @@ hipError_t launch_conv_dmafs(const ConvArgs& a, hipStream_t st) {
   if (!dmafs_fits(a.H, a.W, a.C0, a.C1, a.Cout) || a.CoutPad != a.Cout || !dmafs_takes(a) || (a.pool_out && ((a.H | a.W) & 1))) return hipErrorInvalidValue;
   const int tw = dmafs_tile_w(a);
   bool& done = attr_done[dev][tw == 64];
+#ifdef FISR_DIAG
   const hipError_t e = tw == 64 ? launch_conv_dmafs_tw<64>(a, st, n_cu[dev], !done) : launch_conv_dmafs_tw<32>(a, st, n_cu[dev], !done);
+#else
+  const hipError_t e = launch_conv_dmafs_tw<32>(a, st, n_cu[dev], !done);
+#endif
   if (e == hipSuccess) done = true;
   return e;
 }
