@@ -68,11 +68,53 @@ constexpr size_t dmafs_lds_bytes(int tw) { return (size_t)fs_halo_bytes(tw) * (f
 #define FISR_FS_END(KEEP)          "s_mov_b32 m0, %[" #KEEP "]"
 
 // The record encoder of Rec16<fsplit> without its 48 clamps per record: with MODE.FP16_OVFL set (the kernel sets it at its start)
-// v_cvt_pk_f16_f32 saturates to +-65504 and v_cvt_pk_fp8_f32 to +-448 by themselves (probed on MI355X:
+// v_cvt_pk_f16_f32 saturates to +-65504 and the fp8 conversions to +-448 by themselves (probed on MI355X:
 // scripts/probes/fp16_ovfl_cvt_probe.hip) -- the same bytes as fsplit_encode8 for every finite input.
+// r06: 40 vector instructions per record instead of 72 (the epilogue is a fifth to a third of an item: 8-10.6 k cycles of vector work).
+//   * the remainder v - h comes from ONE v_fma_mix_f32 per value (h read as the f16 half it is: no f16 -> f32 conversion, exact);
+//   * its scaling by 2^14 is the scale operand of v_cvt_scalef32_pk_fp8_f32 (which DIVIDES by it: 2^-14), no multiply;
+//   * the fp8 copy of h is v_cvt_scalef32_pk_fp8_f16 straight from the packed halves.
+// Bit-identical to the form above over 4 M random records of magnitudes 2^-22 .. 2^17, zeros, +-1e30 and values beyond fp16's range
+// (scripts/probes/f8_encoder_probe.hip).  -DFISR_FS_ENC=0: the r05 form, for A/B runs.
+#ifndef FISR_FS_ENC
+#define FISR_FS_ENC 1
+#endif
 __device__ __forceinline__ void fsplit_encode16_sat(const float* v, uint4* q) {
   typedef float f2_t __attribute__((ext_vector_type(2)));
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+#if FISR_FS_ENC
+  typedef short s2_t __attribute__((ext_vector_type(2)));
+  uint32_t hw[8];
+  float r[16];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    f2_t f; f.x = v[2 * d]; f.y = v[2 * d + 1];
+    hw[d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[2 * d]) : "v"(hw[d]), "v"(v[2 * d]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[2 * d + 1]) : "v"(hw[d]), "v"(v[2 * d + 1]));
+  }
+  q[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  q[1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+  const float sr = 1.f / (float)(1 << FS_LSHIFT);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {      // channels 8 g .. 8 g + 7: {l8 | h8}
+    s2_t t;
+    uint4 x;
+    t = s2_t{0, 0};
+    t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(t, r[8 * g], r[8 * g + 1], sr, false); t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(t, r[8 * g + 2], r[8 * g + 3], sr, true);
+    x.x = __builtin_bit_cast(uint32_t, t);
+    t = s2_t{0, 0};
+    t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(t, r[8 * g + 4], r[8 * g + 5], sr, false); t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(t, r[8 * g + 6], r[8 * g + 7], sr, true);
+    x.y = __builtin_bit_cast(uint32_t, t);
+    t = s2_t{0, 0};
+    t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(t, __builtin_bit_cast(h2_t, hw[4 * g]), 1.f, false); t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(t, __builtin_bit_cast(h2_t, hw[4 * g + 1]), 1.f, true);
+    x.z = __builtin_bit_cast(uint32_t, t);
+    t = s2_t{0, 0};
+    t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(t, __builtin_bit_cast(h2_t, hw[4 * g + 2]), 1.f, false); t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(t, __builtin_bit_cast(h2_t, hw[4 * g + 3]), 1.f, true);
+    x.w = __builtin_bit_cast(uint32_t, t);
+    q[2 + g] = x;
+  }
+#else
   uint32_t hw[8];
   float hf[16], r[16];
 #pragma unroll
@@ -96,6 +138,7 @@ __device__ __forceinline__ void fsplit_encode16_sat(const float* v, uint4* q) {
     t = __builtin_amdgcn_cvt_pk_fp8_f32(hf[8 * g + 4], hf[8 * g + 5], 0, false); t = __builtin_amdgcn_cvt_pk_fp8_f32(hf[8 * g + 6], hf[8 * g + 7], t, true); x.w = (uint32_t)t;
     q[2 + g] = x;
   }
+#endif
 }
 
 // TW: width of the workgroup's pixel tile.  64: wave (rg, cg) owns rows 4 rg .., columns 32 cg .., all 64 channels (8 accumulators:
