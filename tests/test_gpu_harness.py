@@ -631,3 +631,57 @@ def test_prepare_patch_set_from_mat_round_trips_through_the_train_loader(tmp_pat
     assert ts["warp"].shape == (n, 96, 96, 24) and ts["warp_ss2"].shape == (n, 96, 96, 12)
     f1 = fio.read_flo_file_5dim(str(tmp_path / "flow" / "LR_ss1.flo"))
     assert np.allclose(ts["flow"][0, :, :, 0:2], f1[0, 0] / 96 / 2) and np.allclose(ts["data"][0, :, :, 3:6], data[0, 1] / 255.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# r06: `--phase test --prepare auto` under several ranks -- rank 0 makes the files, the others wait and read them
+def _prepare_auto_worker(rank, world, port, root, out, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import io as _io
+        from contextlib import redirect_stdout
+        from pathlib import Path
+        from fisr_amd.fisrnet import FISRnet
+        torch.cuda.set_device(0)
+        args = _prep_args(Path(root), Path(out))
+        buf = _io.StringIO()
+        with redirect_stdout(buf):
+            net = FISRnet(args)
+            res = net.test()
+            net.close()
+        q.put((rank, {k: res[k] for k in ("FISR_PSNR", "SR_PSNR", "FISR_SSIM", "SR_SSIM")}, "Start to make flow and warped data" in buf.getvalue()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_phase_test_prepare_auto_two_ranks_one_prepares(scenes10, tmp_path):
+    """Two gloo ranks on cuda:0 run `--phase test` with neither pre-made file present: ONE PWC-Net pass over the scene set (rank 0's),
+    a barrier, both ranks read the files rank 0 left and print the same four averages as a single process does."""
+    import socket
+    import torch.multiprocessing as mp
+    from fisr_amd.fisrnet import FISRnet
+    r = scenes10["root"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    out = tmp_path / "two"
+    procs = [ctx.Process(target=_prepare_auto_worker, args=(k, 2, port, str(r), str(out), q)) for k in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=900) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][2] and not got[1][2]                      # only rank 0 ran the pre-processing
+    assert os.path.isfile(str(out / "flow" / "LR_set_test_ss1.flo")) and os.path.isfile(str(out / "warped" / "LR_set_test_ss1_warp.mat"))
+    solo_args = _prep_args(r, tmp_path / "solo")
+    net = FISRnet(solo_args)
+    solo = net.test()
+    net.close()
+    for k in ("FISR_PSNR", "SR_PSNR", "FISR_SSIM", "SR_SSIM"):
+        assert abs(got[0][1][k] - got[1][1][k]) <= 1e-12 and abs(got[0][1][k] - solo[k]) <= 1e-9, (k, got[0][1][k], got[1][1][k], solo[k])
